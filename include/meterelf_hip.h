@@ -1,0 +1,171 @@
+/*
+ * meterelf_hip.h -- C ABI of libmeterelf_hip.so, the MI355X (gfx950) drop-in
+ * for meterelf's per-image hot path.
+ *
+ * The reference (suutari/meterelf) has no FFI/plugin boundary: its hot path is
+ * Python calling cv2.  The boundary is therefore its Python API, which
+ * meterelf_amd/ keeps (get_meter_values, MeterImageData, ImageFile,
+ * get_meter_value), and this header is what that host layer binds through
+ * ctypes.  Each entry point cites the reference code it replaces (paths relative
+ * to the reference checkout).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function
+ * returns 0 on success or a negative melf_status; the message is available from
+ * melf_last_error() (thread-local).  A context belongs to one GPU and is driven
+ * by one host thread at a time.  The caller owns every buffer it passes in; the
+ * context owns its device memory.  "_dev" entry points take device pointers
+ * (e.g. torch tensors' data_ptr()) and enqueue on `stream` (a hipStream_t passed
+ * as void*, NULL = the context's own stream) without synchronising it unless
+ * stated.
+ */
+#ifndef METERELF_HIP_H
+#define METERELF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define MELF_MAX_DIALS 8
+#define MELF_ABI_VERSION 1
+
+/* API status codes (negative) */
+enum {
+    MELF_SUCCESS = 0,
+    MELF_ERR_INVALID = -1,  /* bad argument / shape mismatch          */
+    MELF_ERR_HIP = -2,      /* HIP runtime error, see melf_last_error  */
+    MELF_ERR_NO_DEVICE = -3,
+    MELF_ERR_TOO_LARGE = -4 /* template/dial does not fit the kernels' LDS tiles */
+};
+
+/* Per-frame status: mirrors the reference's exception classes
+ * (meterelf/exceptions.py:35-52). */
+enum {
+    MELF_FRAME_OK = 0,
+    MELF_FRAME_DIALS_NOT_FOUND = 1,           /* DialsNotFoundError, meterelf/_image.py:62-64      */
+    MELF_FRAME_NEEDLE_CONTOURS_NOT_FOUND = 2, /* NeedleContoursNotFoundError, _reading.py:137-138  */
+    MELF_FRAME_ANGLE_UNDETERMINED = 3         /* DialAngleDeterminingError, _reading.py:98-106     */
+};
+
+/* One entry of params.yml `needle_data` (meterelf/_params.py:71-81). */
+typedef struct {
+    double cx, cy;            /* center                                   */
+    double angle_of_zero;     /* degrees                                  */
+    int32_t range_h, range_l, range_s; /* color_range                     */
+    int32_t negative_momentum;
+    int32_t diameter;
+    int32_t dist_from_center;
+    int32_t circle_thickness;
+    int32_t reserved;
+} melf_dial;
+
+/* Scalars of params.yml (meterelf/_params.py:30-64). */
+typedef struct {
+    int32_t abi_version;      /* MELF_ABI_VERSION                          */
+    int32_t rect_x0, rect_y0, rect_x1, rect_y1; /* meter_rect              */
+    int32_t th, tw;           /* template rows, cols (dials_template_size as (h, w)) */
+    int32_t hue_shift;
+    int32_t ndials;
+    int32_t needle_lo[3];     /* fixed H,L,S bounds of the fused full-frame */
+    int32_t needle_hi[3];     /*   stage: needle_color -/+ needle_color_range, clamped */
+    int32_t name_order[MELF_MAX_DIALS]; /* dial indices sorted by name string (_reading.py:171) */
+    int32_t reserved;
+    double match_threshold;   /* dials_template_match_threshold            */
+    melf_dial dial[MELF_MAX_DIALS];
+} melf_params;
+
+/* Per-frame record.  The Python host rebuilds the reference's return dict /
+ * exception objects from it (meterelf/_reading.py:19-115). */
+typedef struct {
+    int32_t status;           /* MELF_FRAME_*                              */
+    int32_t match_x, match_y; /* minMaxLoc max_loc, meterelf/_utils.py:94-95 */
+    int32_t failed_dial;      /* NEEDLE_CONTOURS_NOT_FOUND: dial index, else -1 */
+    uint32_t unreadable_mask; /* ANGLE_UNDETERMINED: bit d = dial d unreadable */
+    float match_val;          /* minMaxLoc max_val (float32)               */
+    double pos[MELF_MAX_DIALS];   /* dial positions in [0, 10)             */
+    double angle[MELF_MAX_DIALS]; /* needle angle in turns, before angle_of_zero */
+    double value;             /* determine_value_by_dial_positions, valid iff OK and ndials == 4 */
+} melf_result;
+
+typedef struct melf_ctx melf_ctx;
+
+const char* melf_last_error(void);
+int melf_abi_version(void);
+int melf_device_count(int* count);
+
+/* Host precompute of the per-dial masks, replaces _dial_data._get_dial_data
+ * (meterelf/_dial_data.py:22-55): masks[ndials][2][th*tw], plane 0 = `mask`
+ * (disk), plane 1 = `circle_mask` (annulus). */
+int melf_build_dial_masks(const melf_params* p, uint8_t* masks);
+
+/* The calibration blob = params + template + dial masks, the only shared
+ * read-only state of the path (meterelf/_image.py:69-81, _dial_data.py:11-19).
+ * Rank 0 packs it, the host layer broadcasts it (RCCL) and every rank creates
+ * its context from the same bytes. */
+size_t melf_blob_size(const melf_params* p);
+int melf_blob_pack(const melf_params* p, const uint8_t* templ /* th*tw */, void* blob, size_t blob_bytes);
+int melf_blob_params(const void* blob, size_t blob_bytes, melf_params* out);
+
+/* One context per GPU.  `blob` is a host pointer unless blob_on_device != 0. */
+int melf_ctx_create(int device, const void* blob, size_t blob_bytes, int blob_on_device, melf_ctx** out);
+void melf_ctx_destroy(melf_ctx* ctx);
+int melf_ctx_params(const melf_ctx* ctx, melf_params* out);
+/* copy the context's dial masks back (tests) */
+int melf_ctx_get_masks(const melf_ctx* ctx, uint8_t* masks);
+
+/* ---- the whole path: replaces get_meter_value(imgf) per frame
+ * (meterelf/_reading.py:19-115 with meterelf/_image.py:23-66) ---------------
+ * frames: n full camera frames, H x W x 3 u8 BGR (cv2.imread layout), frame f at
+ * frames + f*frame_stride bytes.  The meter_rect crop is taken inside, with
+ * numpy-slice clamping (meterelf/_image.py:54-55). */
+int melf_process_batch(melf_ctx* ctx, const uint8_t* frames_host, int n, int H, int W,
+                       size_t frame_stride, melf_result* out_host);
+/* frames already in HBM; results go to d_results (device, may be NULL) and/or
+ * out_host (host, may be NULL; when given the call synchronises the stream). */
+int melf_process_batch_dev(melf_ctx* ctx, const void* d_frames, int n, int H, int W,
+                           size_t frame_stride, void* d_results, melf_result* out_host, void* stream);
+
+/* ---- stage entry points (parity tests and roofline runs) ----------------- */
+
+/* convert_to_hls (meterelf/_utils.py:100-102): cvtColor(BGR2HLS_FULL) + uint8
+ * hue shift.  src rows x cols x 3 u8 with row stride in bytes; dst packed. */
+int melf_bgr2hls(melf_ctx* ctx, const uint8_t* src_host, int rows, int cols, size_t row_stride,
+                 uint8_t* dst_host);
+
+/* Fused full-frame stage (BASELINE config 2): HLS(+shift) -> inRange with the
+ * context's fixed needle bounds (get_mask_by_color, meterelf/_utils.py:113-119,
+ * bounds as meterelf/_calibration.py:82-84) -> dilate 3x3 -> erode 3x3
+ * (meterelf/_reading.py:128-130).  n frames H x W x 3 -> n masks H x W u8 {0,255}. */
+int melf_hls_inrange_close(melf_ctx* ctx, const uint8_t* frames_host, int n, int H, int W,
+                           uint8_t* masks_host);
+int melf_hls_inrange_close_dev(melf_ctx* ctx, const void* d_frames, int n, int H, int W,
+                               void* d_masks, void* stream);
+
+/* match_template (meterelf/_utils.py:91-97): TM_CCOEFF of n single-channel u8
+ * images (rows x cols, packed) against the context's template + minMaxLoc.
+ * result_map (optional) receives n*(rows-th+1)*(cols-tw+1) float32. */
+int melf_match_ccoeff(melf_ctx* ctx, const uint8_t* images_host, int n, int rows, int cols,
+                      float* max_val, int32_t* max_x, int32_t* max_y, float* result_map);
+
+/* Per-dial reading on n already-located dials crops (th x tw x 3 HLS u8, packed):
+ * get_needle_points + angle estimate + digit combine
+ * (meterelf/_reading.py:28-111, :118-182). */
+int melf_read_dials(melf_ctx* ctx, const uint8_t* dials_hls_host, int n, melf_result* out_host);
+
+/* ---- measurement ---------------------------------------------------------
+ * With profiling on, every kernel launched by a *_dev entry point is bracketed
+ * by hipEvents on its stream; melf_ctx_timings drains them (synchronising) and
+ * returns per-kernel accumulated milliseconds and launch counts. */
+enum { MELF_K_LPLANE = 0, MELF_K_MATCH = 1, MELF_K_DIALS = 2, MELF_K_FUSED_MASK = 3, MELF_K_HLS = 4, MELF_K_COUNT = 5 };
+int melf_ctx_set_profiling(melf_ctx* ctx, int on);
+int melf_ctx_timings(melf_ctx* ctx, double ms[MELF_K_COUNT], int64_t launches[MELF_K_COUNT]);
+const char* melf_kernel_name(int k);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* METERELF_HIP_H */

@@ -1,0 +1,69 @@
+"""Public API with the reference's signature (meterelf/_api.py:9-33):
+
+    get_meter_values(params_file, filenames) -> Iterator[MeterImageData]
+
+Lazy, yields in input order, per-image ImageProcessingError becomes the `error`
+field (re-raised only when DEBUG is set).  Unlike the reference's one-at-a-time
+loop, files are decoded and sent to the GPU in chunks (METERELF_BATCH, default
+64), so up to one chunk is read ahead of the consumer.
+"""
+import os
+from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional
+
+from . import _debug, _params
+from ._engine import MeterReader, result_to_python
+from ._image import ImageFile
+from .exceptions import ImageProcessingError
+
+
+class MeterImageData(NamedTuple):
+    filename: str
+    value: Optional[float]
+    error: Optional[ImageProcessingError]
+    meter_values: Dict[str, float]
+
+
+def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
+    chunk: List[str] = []
+    for item in items:
+        chunk.append(item)
+        if len(chunk) == size:
+            yield chunk
+            chunk = []
+    if chunk:
+        yield chunk
+
+
+def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[MeterImageData]:
+    params = _params.load(params_file)
+    batch = max(1, int(os.getenv('METERELF_BATCH', '64')))
+    if _debug.DEBUG:
+        batch = 1  # DEBUG re-raises at the failing file, before any later file is touched
+    reader: Optional[MeterReader] = None
+    try:
+        for chunk in _chunks(filenames, batch):
+            if reader is None:
+                reader = MeterReader(params)
+            assert len(reader.dial_names) == 4  # meterelf/_reading.py:166
+            errors: Dict[int, ImageProcessingError] = {}
+            frames, where = [], []
+            for (i, filename) in enumerate(chunk):
+                try:
+                    frames.append(ImageFile(filename, params).get_frame())
+                    where.append(i)
+                except ImageProcessingError as e:
+                    errors[i] = e
+                    _debug.reraise_if_debug_on()
+            records = reader.read_many(frames) if frames else []
+            by_index = dict(zip(where, records))
+            for (i, filename) in enumerate(chunk):
+                meter_values: Dict[str, float] = {}
+                error = errors.get(i)
+                if error is None:
+                    (meter_values, error) = result_to_python(by_index[i], reader.dial_names, filename)
+                    if error is not None and _debug.DEBUG:
+                        raise error
+                yield MeterImageData(filename, meter_values.get('value'), error, meter_values)
+    finally:
+        if reader is not None:
+            reader.close()

@@ -1,0 +1,105 @@
+"""MeterReader: the batched GPU engine behind the reference-shaped API.
+
+One MeterReader owns one melf_ctx (one GPU).  Frames go in as uint8 BGR arrays
+(N, H, W, 3); records come back as a numpy structured array (_hip.RESULT_DTYPE)
+and are turned into the reference's dicts / exceptions by result_to_python().
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _hip
+from ._params import Params
+from ._types import Rect
+from .exceptions import (
+    DialAngleDeterminingError, DialsNotFoundError, ImageProcessingError, NeedleContoursNotFoundError)
+
+
+def load_template(params: Params) -> np.ndarray:
+    """cv2.imread(dials_file, IMREAD_GRAYSCALE) (reference: meterelf/_image.py:72-81)."""
+    from PIL import Image
+    try:
+        with Image.open(params.dials_file) as im:
+            template = np.ascontiguousarray(np.asarray(im.convert('L'), dtype=np.uint8))
+    except Exception:
+        raise IOError("Cannot read dials template: {}".format(params.dials_file))
+    assert template.shape == params.dials_template_size
+    return template
+
+
+def make_blob(params: Params, meter_rect: Optional[Rect] = None) -> np.ndarray:
+    return _hip.pack_blob(params.to_c(meter_rect), load_template(params))
+
+
+def result_to_python(rec, dial_names: List[str], filename: str = '') -> Tuple[Dict[str, float], Optional[ImageProcessingError]]:
+    """One record -> (meter_values dict, error) exactly as get_meter_value would
+    return / raise (reference: meterelf/_reading.py:98-115, _image.py:62-64)."""
+    status = int(rec['status'])
+    if status == _hip.FRAME_OK:
+        values = {name: float(rec['pos'][i]) for (i, name) in enumerate(dial_names)}
+        if len(dial_names) == 4:
+            values['value'] = float(rec['value'])
+        return values, None
+    if status == _hip.FRAME_DIALS_NOT_FOUND:
+        return {}, DialsNotFoundError(filename, extra_info={'match val': float(rec['match_val'])})
+    if status == _hip.FRAME_NEEDLE_CONTOURS_NOT_FOUND:
+        return {}, NeedleContoursNotFoundError(extra_info={'dial': dial_names[int(rec['failed_dial'])]})
+    if status == _hip.FRAME_ANGLE_UNDETERMINED:
+        bad = [name for (i, name) in enumerate(dial_names) if int(rec['unreadable_mask']) >> i & 1]
+        return {}, DialAngleDeterminingError(filename, extra_info={'unreadable dials': ', '.join(bad)})
+    raise RuntimeError('unknown frame status {}'.format(status))
+
+
+class MeterReader:
+    def __init__(self, params: Params, device: int = 0, blob: Optional[np.ndarray] = None) -> None:
+        self.params = params
+        self.device = device
+        self.dial_names = params.dial_names
+        self.blob = blob if blob is not None else make_blob(params)
+        self.ctx = _hip.Context(self.blob, device)
+        self._crop_ctx: Dict[Tuple[int, int], _hip.Context] = {}
+
+    def close(self) -> None:
+        self.ctx.close()
+        for c in self._crop_ctx.values():
+            c.close()
+        self._crop_ctx.clear()
+
+    def read_frames(self, frames: np.ndarray) -> np.ndarray:
+        """Full camera frames (N, H, W, 3) BGR -> records."""
+        return self.ctx.process_batch(frames)
+
+    def read_crops(self, crops: np.ndarray) -> np.ndarray:
+        """Already meter_rect-cropped images (the reference's bgr_image injection)."""
+        (_n, h, w, _c) = crops.shape
+        ctx = self._crop_ctx.get((h, w))
+        if ctx is None:
+            blob = make_blob(self.params, Rect((0, 0), (w, h)))
+            ctx = self._crop_ctx[(h, w)] = _hip.Context(blob, self.device)
+        return ctx.process_batch(crops)
+
+    def read_many(self, images: List[np.ndarray], cropped: Optional[List[bool]] = None) -> List[np.void]:
+        """Heterogeneous list of frames: grouped by shape, one batched call per group."""
+        cropped = cropped or [False] * len(images)
+        groups: Dict[Tuple[bool, Tuple[int, ...]], List[int]] = {}
+        for (i, img) in enumerate(images):
+            groups.setdefault((cropped[i], img.shape), []).append(i)
+        out: List[Optional[np.void]] = [None] * len(images)
+        for ((is_crop, _shape), idxs) in groups.items():
+            batch = np.stack([images[i] for i in idxs])
+            recs = self.read_crops(batch) if is_crop else self.read_frames(batch)
+            for (k, i) in enumerate(idxs):
+                out[i] = recs[k]
+        return out  # type: ignore
+
+
+_readers: Dict[int, MeterReader] = {}
+
+
+def get_reader(params: Params) -> MeterReader:
+    """Per-Params cache, like the reference's id(params)-keyed caches
+    (meterelf/_image.py:69-81, meterelf/_dial_data.py:11-19)."""
+    r = _readers.get(id(params))
+    if r is None or r.params is not params:
+        r = _readers[id(params)] = MeterReader(params)
+    return r

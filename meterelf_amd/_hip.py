@@ -1,0 +1,253 @@
+"""ctypes binding of libmeterelf_hip.so (C ABI: include/meterelf_hip.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no
+MI355X is visible, everything here raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libmeterelf_hip.so')
+
+MAX_DIALS = 8
+ABI_VERSION = 1
+
+FRAME_OK = 0
+FRAME_DIALS_NOT_FOUND = 1
+FRAME_NEEDLE_CONTOURS_NOT_FOUND = 2
+FRAME_ANGLE_UNDETERMINED = 3
+
+K_LPLANE, K_MATCH, K_DIALS, K_FUSED_MASK, K_HLS, K_COUNT = 0, 1, 2, 3, 4, 5
+
+
+class MelfDial(C.Structure):
+    _fields_ = [('cx', C.c_double), ('cy', C.c_double), ('angle_of_zero', C.c_double),
+                ('range_h', C.c_int32), ('range_l', C.c_int32), ('range_s', C.c_int32),
+                ('negative_momentum', C.c_int32), ('diameter', C.c_int32),
+                ('dist_from_center', C.c_int32), ('circle_thickness', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class MelfParams(C.Structure):
+    _fields_ = [('abi_version', C.c_int32),
+                ('rect_x0', C.c_int32), ('rect_y0', C.c_int32), ('rect_x1', C.c_int32), ('rect_y1', C.c_int32),
+                ('th', C.c_int32), ('tw', C.c_int32), ('hue_shift', C.c_int32), ('ndials', C.c_int32),
+                ('needle_lo', C.c_int32 * 3), ('needle_hi', C.c_int32 * 3),
+                ('name_order', C.c_int32 * MAX_DIALS), ('reserved', C.c_int32),
+                ('match_threshold', C.c_double),
+                ('dial', MelfDial * MAX_DIALS)]
+
+
+class MelfResult(C.Structure):
+    _fields_ = [('status', C.c_int32), ('match_x', C.c_int32), ('match_y', C.c_int32),
+                ('failed_dial', C.c_int32), ('unreadable_mask', C.c_uint32), ('match_val', C.c_float),
+                ('pos', C.c_double * MAX_DIALS), ('angle', C.c_double * MAX_DIALS), ('value', C.c_double)]
+
+
+RESULT_DTYPE = np.dtype([('status', '<i4'), ('match_x', '<i4'), ('match_y', '<i4'), ('failed_dial', '<i4'),
+                         ('unreadable_mask', '<u4'), ('match_val', '<f4'),
+                         ('pos', '<f8', (MAX_DIALS,)), ('angle', '<f8', (MAX_DIALS,)), ('value', '<f8')])
+assert RESULT_DTYPE.itemsize == C.sizeof(MelfResult)
+
+
+class HipError(RuntimeError):
+    pass
+
+
+# every symbol include/meterelf_hip.h declares
+EXPORTS = [
+    'melf_last_error', 'melf_abi_version', 'melf_device_count', 'melf_build_dial_masks',
+    'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
+    'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev',
+    'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
+    'melf_read_dials', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
+]
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError(
+            'libmeterelf_hip.so is not built (run `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C meterelf_amd/csrc`); meterelf_amd has no CPU fallback')
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.melf_last_error.restype = C.c_char_p
+    L.melf_kernel_name.restype = C.c_char_p
+    L.melf_kernel_name.argtypes = [C.c_int]
+    L.melf_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.melf_build_dial_masks.argtypes = [C.POINTER(MelfParams), vp]
+    L.melf_blob_size.restype = C.c_size_t
+    L.melf_blob_size.argtypes = [C.POINTER(MelfParams)]
+    L.melf_blob_pack.argtypes = [C.POINTER(MelfParams), vp, vp, C.c_size_t]
+    L.melf_blob_params.argtypes = [vp, C.c_size_t, C.POINTER(MelfParams)]
+    L.melf_ctx_create.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.melf_ctx_destroy.argtypes = [vp]
+    L.melf_ctx_destroy.restype = None
+    L.melf_ctx_params.argtypes = [vp, C.POINTER(MelfParams)]
+    L.melf_ctx_get_masks.argtypes = [vp, vp]
+    L.melf_process_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp]
+    L.melf_process_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]
+    L.melf_bgr2hls.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp]
+    L.melf_hls_inrange_close.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.melf_hls_inrange_close_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.melf_match_ccoeff.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.melf_read_dials.argtypes = [vp, vp, C.c_int, vp]
+    L.melf_ctx_set_profiling.argtypes = [vp, C.c_int]
+    L.melf_ctx_timings.argtypes = [vp, vp, vp]
+    if L.melf_abi_version() != ABI_VERSION:
+        raise HipError('libmeterelf_hip.so ABI version mismatch')
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise HipError('libmeterelf_hip: %s (code %d)' % (lib().melf_last_error().decode(), rc))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().melf_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_blob(cparams, template):
+    """params + template -> calibration blob (numpy uint8), masks built inside."""
+    L = lib()
+    template = np.ascontiguousarray(template, dtype=np.uint8)
+    assert template.shape == (cparams.th, cparams.tw), (template.shape, cparams.th, cparams.tw)
+    size = L.melf_blob_size(C.byref(cparams))
+    if size == 0:
+        raise HipError('libmeterelf_hip: %s' % L.melf_last_error().decode())
+    blob = np.zeros(size, np.uint8)
+    check(L.melf_blob_pack(C.byref(cparams), _ptr(template), _ptr(blob), size))
+    return blob
+
+
+def blob_params(blob):
+    p = MelfParams()
+    check(lib().melf_blob_params(_ptr(blob), blob.nbytes, C.byref(p)))
+    return p
+
+
+def build_dial_masks(cparams):
+    out = np.zeros((cparams.ndials, 2, cparams.th, cparams.tw), np.uint8)
+    check(lib().melf_build_dial_masks(C.byref(cparams), _ptr(out)))
+    return out
+
+
+class Context:
+    """One melf_ctx = one GPU's resident calibration state + workspaces."""
+
+    def __init__(self, blob, device=0, blob_device_ptr=None):
+        L = lib()
+        self._h = C.c_void_p()
+        self._L = L
+        if blob_device_ptr is not None:
+            check(L.melf_ctx_create(device, C.c_void_p(blob_device_ptr), int(blob.nbytes), 1, C.byref(self._h)))
+        else:
+            blob = np.ascontiguousarray(blob, dtype=np.uint8)
+            check(L.melf_ctx_create(device, _ptr(blob), blob.nbytes, 0, C.byref(self._h)))
+        self.device = device
+        self.params = MelfParams()
+        check(L.melf_ctx_params(self._h, C.byref(self.params)))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._L.melf_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- whole path ---
+    def process_batch(self, frames):
+        """frames: (N, H, W, 3) uint8 BGR host array -> structured array of records."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        assert frames.ndim == 4 and frames.shape[3] == 3, frames.shape
+        n, H, W, _ = frames.shape
+        out = np.zeros(n, RESULT_DTYPE)
+        if n:
+            check(self._L.melf_process_batch(self._h, _ptr(frames), n, H, W, H * W * 3, _ptr(out)))
+        return out
+
+    def process_batch_dev(self, d_frames_ptr, n, H, W, frame_stride=None, d_results_ptr=None, want_host=True,
+                          stream=None):
+        """Frames already in HBM (device pointer as int).  Returns records when want_host."""
+        out = np.zeros(n, RESULT_DTYPE) if want_host else None
+        check(self._L.melf_process_batch_dev(
+            self._h, C.c_void_p(d_frames_ptr), n, H, W, frame_stride or H * W * 3,
+            C.c_void_p(d_results_ptr) if d_results_ptr else None,
+            _ptr(out) if want_host else None, C.c_void_p(stream) if stream else None))
+        return out
+
+    # --- stages ---
+    def bgr2hls(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        rows, cols, _ = bgr.shape
+        out = np.empty((rows, cols, 3), np.uint8)
+        check(self._L.melf_bgr2hls(self._h, _ptr(bgr), rows, cols, cols * 3, _ptr(out)))
+        return out
+
+    def hls_inrange_close(self, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, H, W, _ = frames.shape
+        out = np.empty((n, H, W), np.uint8)
+        check(self._L.melf_hls_inrange_close(self._h, _ptr(frames), n, H, W, _ptr(out)))
+        return out
+
+    def hls_inrange_close_dev(self, d_frames_ptr, n, H, W, d_masks_ptr, stream=None):
+        check(self._L.melf_hls_inrange_close_dev(self._h, C.c_void_p(d_frames_ptr), n, H, W,
+                                                  C.c_void_p(d_masks_ptr), C.c_void_p(stream) if stream else None))
+
+    def match_ccoeff(self, images, want_map=False):
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        n, rows, cols = images.shape
+        mv = np.zeros(n, np.float32)
+        mx = np.zeros(n, np.int32)
+        my = np.zeros(n, np.int32)
+        rmap = None
+        if want_map:
+            rmap = np.zeros((n, rows - self.params.th + 1, cols - self.params.tw + 1), np.float32)
+        check(self._L.melf_match_ccoeff(self._h, _ptr(images), n, rows, cols, _ptr(mv), _ptr(mx), _ptr(my),
+                                        _ptr(rmap) if want_map else None))
+        return mv, mx, my, rmap
+
+    def read_dials(self, dials_hls):
+        dials_hls = np.ascontiguousarray(dials_hls, dtype=np.uint8)
+        n = dials_hls.shape[0]
+        assert dials_hls.shape[1:] == (self.params.th, self.params.tw, 3), dials_hls.shape
+        out = np.zeros(n, RESULT_DTYPE)
+        check(self._L.melf_read_dials(self._h, _ptr(dials_hls), n, _ptr(out)))
+        return out
+
+    def masks(self):
+        p = self.params
+        out = np.zeros((p.ndials, 2, p.th, p.tw), np.uint8)
+        check(self._L.melf_ctx_get_masks(self._h, _ptr(out)))
+        return out
+
+    # --- measurement ---
+    def set_profiling(self, on):
+        check(self._L.melf_ctx_set_profiling(self._h, 1 if on else 0))
+
+    def timings(self):
+        ms = np.zeros(K_COUNT, np.float64)
+        cnt = np.zeros(K_COUNT, np.int64)
+        check(self._L.melf_ctx_timings(self._h, _ptr(ms), _ptr(cnt)))
+        return {self._L.melf_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(K_COUNT)}

@@ -1,0 +1,49 @@
+"""Image loading for the path (reference: meterelf/_image.py:12-55).
+
+JPEG decode stays on the host (cv2.imread in the reference, Pillow's
+libjpeg-turbo here: ISLOW IDCT + fancy upsampling, same as cv2's defaults).
+Everything after the decode -- crop, HLS, dial finding -- happens on the GPU.
+"""
+from typing import Optional
+
+import numpy as np
+
+from ._params import Params as _Params
+from .exceptions import ImageLoadingError
+
+
+def imread_bgr(filename: str) -> Optional[np.ndarray]:
+    """cv2.imread(filename): H x W x 3 uint8 BGR, or None if unreadable."""
+    from PIL import Image
+    try:
+        with Image.open(filename) as im:
+            rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
+    except Exception:
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+class ImageFile:
+    """Same constructor as the reference's ImageFile (meterelf/_image.py:13-21).
+
+    `bgr_image`, when given, is used instead of reading `filename` and -- as in
+    the reference (:47-48) -- is taken to be the meter_rect crop already.
+    """
+
+    def __init__(self, filename: str, params: _Params, bgr_image: Optional[np.ndarray] = None) -> None:
+        self.filename = filename
+        self.params = params
+        self.bgr_image = bgr_image
+
+    @property
+    def is_cropped(self) -> bool:
+        return self.bgr_image is not None
+
+    def get_frame(self) -> np.ndarray:
+        """The array handed to the GPU: the full decoded frame, or the injected crop."""
+        if self.bgr_image is not None:
+            return self.bgr_image
+        img = imread_bgr(self.filename)
+        if img is None:
+            raise ImageLoadingError(self.filename)
+        return img

@@ -1,0 +1,392 @@
+// K3 -- per-dial needle reading + digit combine
+// (reference: meterelf/_reading.py:19-115 get_meter_value, :118-151
+// get_needle_points, :154-160 get_dial_color, :163-182
+// determine_value_by_dial_positions; meterelf/_utils.py:18-42
+// get_angle_by_vector; meterelf/_colors.py:38-50 get_range).
+//
+// Mapping (gfx950, wave64): one workgroup per frame, one wave per dial.
+// Everything a dial needs lives inside its disk mask (radius R <= 29) plus the
+// 2-px halo of the 3x3 closing, i.e. a window of at most 64 x 64 pixels, so a
+// binary image is ONE 64-bit register per lane (lane = window row, bit = window
+// column).  inRange masks come out of __ballot, the closing / flood fills / 8-
+// connected labelling are shifts within the register plus neighbour-lane reads,
+// contour areas are popcounts.  No pixel of the HLS image is ever written to
+// memory: the window's BGR pixels are converted on the fly.
+//
+// cv2 semantics restated here:
+//  * external contours of M = closed_mask & disk: the 8-connected components of
+//    G = M u {pixels not 4-connected to the outside through ~M}; a component
+//    inside another one's hole is not external and is swallowed by it;
+//  * contourArea of an outer border = Q4(F) + Q3(F)/2 over the hole-filled
+//    component F (2x2 blocks with 4 resp. 3 pixels set) -- tests/ check this
+//    identity against a traced shoelace area;
+//  * drawContours(thickness=-1) paints F.
+#include <limits.h>
+
+#include "melf_device.h"
+#include "melf_internal.h"
+
+namespace melf {
+
+__device__ inline double py_fmod(double a, double b)
+{
+    // CPython float_rem
+    double m = fmod(a, b);
+    if (m != 0.0) {
+        if ((b < 0) != (m < 0)) m += b;
+    } else {
+        m = copysign(0.0, b);
+    }
+    return m;
+}
+
+// get_angle_by_vector, meterelf/_utils.py:18-42; false = None
+__device__ inline bool angle_by_vector(double x, double y, double& out)
+{
+    if (y == 0) {
+        if (x > 0) { out = 0.25; return true; }
+        if (x < 0) { out = 0.75; return true; }
+        return false;
+    }
+    const double at = atan(x / y) / (2 * 3.141592653589793);
+    out = py_fmod(-at + (y > 0 ? 0.5 : 0.0), 1.0);
+    return true;
+}
+
+// determine_value_by_dial_positions, meterelf/_reading.py:163-182
+__device__ inline double value_by_positions(double r4, double r3, double r2, double r1)
+{
+    int d3 = (int)r3 + ((py_fmod(r3, 1.0) > 0.55 && r4 <= 2) ? 1 : 0) - ((py_fmod(r3, 1.0) < 0.45 && r4 >= 8) ? 1 : 0);
+    d3 = ((d3 % 10) + 10) % 10;
+    int d2 = (int)r2 + ((py_fmod(r2, 1.0) > 0.55 && d3 <= 2) ? 1 : 0) - ((py_fmod(r2, 1.0) < 0.45 && d3 >= 8) ? 1 : 0);
+    d2 = ((d2 % 10) + 10) % 10;
+    int d1 = (int)r1 + ((py_fmod(r1, 1.0) > 0.55 && d2 <= 2) ? 1 : 0) - ((py_fmod(r1, 1.0) < 0.45 && d2 >= 8) ? 1 : 0);
+    d1 = ((d1 % 10) + 10) % 10;
+    return (d1 * 100.0) + (d2 * 10.0) + (d3 * 1.0) + r4 / 10.0;
+}
+
+struct Key {
+    double a, d;
+};
+__device__ inline bool key_lt(const Key& p, const Key& q) { return p.a < q.a || (p.a == q.a && p.d < q.d); }
+__device__ inline Key shfl_key(const Key& k, int o)
+{
+    Key r;
+    r.a = __shfl_xor(k.a, o, 64);
+    r.d = __shfl_xor(k.d, o, 64);
+    return r;
+}
+__device__ inline Key wave_min_key(Key k)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Key q = shfl_key(k, o);
+        if (key_lt(q, k)) k = q;
+    }
+    return k;
+}
+__device__ inline Key wave_max_key(Key k)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Key q = shfl_key(k, o);
+        if (key_lt(k, q)) k = q;
+    }
+    return k;
+}
+
+// Visits the ring points that the reference keeps (meterelf/_reading.py:53-69):
+// set bits of `outer` (lane = row), angle within 0.25 turn of the momentum angle.
+template <class F>
+__device__ inline void for_each_kept(uint64_t outer, int lane, int wx0, int wy0, double cx, double cy,
+                                     bool have_mom, double mom, F&& fn)
+{
+    const double dy = (double)(wy0 + lane) - cy;
+    uint64_t bits = outer;
+    while (bits) {
+        const int x = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const double dx = (double)(wx0 + x) - cx;
+        double a;
+        if (angle_by_vector(dx, dy, a) && have_mom) {
+            double dist = fabs(a - mom);
+            const double dist2 = fabs(fabs(a - mom) - 1);
+            if (dist2 < dist) dist = dist2;
+            if (dist < 0.25) fn(a, dx * dx + dy * dy);
+        }
+    }
+}
+
+template <bool FROM_HLS>
+__global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, melf_params P,
+                                                              const DialGeom* __restrict__ geom,
+                                                              const uint64_t* __restrict__ rowmasks,
+                                                              const MatchPartial* __restrict__ partials,
+                                                              int nparts, int rw, melf_result* __restrict__ results)
+{
+    __shared__ int s_status[MELF_MAX_DIALS];
+    __shared__ double s_pos[MELF_MAX_DIALS], s_angle[MELF_MAX_DIALS];
+    __shared__ float s_mv;
+    __shared__ int s_mi;
+
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63, d = threadIdx.x >> 6;
+    const uint8_t* frame = src.base + (size_t)f * src.frame_stride;
+
+    // ---- minMaxLoc over the K2 partials; DialsNotFoundError check (_image.py:62-64) ----
+    int mx = 0, my = 0;
+    float mv = 0.f;
+    if (!FROM_HLS) {
+        if (d == 0) {
+            float bv = 0.f;
+            int bi = INT_MAX;
+            for (int k = lane; k < nparts; k += 64) {
+                const MatchPartial p = partials[(size_t)f * nparts + k];
+                if (p.idx != INT_MAX && (bi == INT_MAX || p.val > bv || (p.val == bv && p.idx < bi))) { bv = p.val; bi = p.idx; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (oi != INT_MAX && (bi == INT_MAX || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { s_mv = bv; s_mi = bi; }
+        }
+        __syncthreads();
+        mv = s_mv;
+        const int mi = s_mi;
+        mx = mi % rw;
+        my = mi / rw;
+        if ((double)mv < P.match_threshold) {
+            if (threadIdx.x == 0) {
+                melf_result r = {};
+                r.status = MELF_FRAME_DIALS_NOT_FOUND;
+                r.match_x = mx; r.match_y = my; r.match_val = mv;
+                r.failed_dial = -1;
+                results[f] = r;
+            }
+            return;
+        }
+    }
+
+    // ---- one wave per dial ----
+    const DialGeom G = geom[d];
+    const melf_dial D = P.dial[d];
+    const int wx0 = G.wx0, wy0 = G.wy0, ws = G.ws;
+
+    auto fetch = [&](int X, int Y, int& H, int& L, int& S) {
+        if (FROM_HLS) {
+            const uint8_t* p = frame + ((size_t)Y * P.tw + X) * 3;
+            H = p[0]; L = p[1]; S = p[2];
+        } else {
+            const int cxp = mx + X, cyp = my + Y;  // meter-crop coordinates
+            const uint8_t* p = frame + (size_t)(src.y0 + cyp) * src.row_stride + (size_t)(src.x0 + cxp) * 3;
+            hls_pixel(p[0], p[1], p[2], hls_scalar_tail(cxp, src.crop_cols), P.hue_shift, H, L, S);
+        }
+    };
+
+    // get_dial_color (_reading.py:154-160): mean of the 5x5 core, Python round()
+    int sh = 0, sl = 0, ss = 0, cnt = 0;
+    if (lane < 25) {
+        const int X = G.core_x - 2 + lane % 5, Y = G.core_y - 2 + lane / 5;
+        if (X >= 0 && X < P.tw && Y >= 0 && Y < P.th) {
+            fetch(X, Y, sh, sl, ss);
+            cnt = 1;
+        }
+    }
+    sh = wave_sum_i32(sh); sl = wave_sum_i32(sl); ss = wave_sum_i32(ss); cnt = wave_sum_i32(cnt);
+    const double inv = cnt ? 1.0 / (double)cnt : 0.0;  // cv::mean: sum * (1./N)
+    const int ch = (int)rint((double)sh * inv), cl = (int)rint((double)sl * inv), cs = (int)rint((double)ss * inv);
+    // HlsColor.get_range (_colors.py:38-50): plain clamped ints, hue does not wrap
+    const int loh = max(ch - D.range_h, 0), hih = min(ch + D.range_h, 255);
+    const int lol = max(cl - D.range_l, 0), hil = min(cl + D.range_l, 255);
+    const int los = max(cs - D.range_s, 0), his = min(cs + D.range_s, 255);
+
+    // inRange over the window (get_mask_by_color, _utils.py:113-119): row masks via ballot
+    uint64_t m0 = 0, V = 0;
+    for (int y = 0; y < ws; ++y) {
+        const int X = wx0 + lane, Y = wy0 + y;
+        const bool valid = lane < ws && X >= 0 && X < P.tw && Y >= 0 && Y < P.th;
+        bool in = false;
+        if (valid) {
+            int H, L, S;
+            fetch(X, Y, H, L, S);
+            in = H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his;
+        }
+        const uint64_t b = __ballot(in), vb = __ballot(valid);
+        if (lane == y) { m0 = b; V = vb; }
+    }
+
+    // dilate then erode, 3x3, pixels outside the dials crop never win (_reading.py:128-130)
+    const uint64_t hz = m0 | (m0 << 1) | (m0 >> 1);
+    const uint64_t dil = (hz | row_up(hz, lane, 0) | row_down(hz, lane, 0)) | ~V;
+    const uint64_t he = dil & ((dil << 1) | 1ull) & ((dil >> 1) | (1ull << 63));
+    const uint64_t mde = he & row_up(he, lane, ~0ull) & row_down(he, lane, ~0ull) & V;
+
+    const uint64_t disk = rowmasks[((size_t)d * 2 + 0) * 64 + lane];
+    const uint64_t annulus = rowmasks[((size_t)d * 2 + 1) * 64 + lane];
+    const uint64_t M = mde & disk;
+
+    int status = 0;  // 0 ok, 1 no contours, 2 unreadable
+    double pos = 0.0, angle = 0.0;
+    if (__ballot(M != 0) == 0) {
+        status = 1;  // NeedleContoursNotFoundError (_reading.py:137-138)
+    } else {
+        // pixels of ~M that are 4-connected to the outside of the disk
+        const uint64_t freeb = ~M;
+        uint64_t o = ~disk;
+        for (;;) {
+            const uint64_t n = o | ((((o << 1) | (o >> 1)) | row_up(o, lane, ~0ull) | row_down(o, lane, ~0ull)) & freeb);
+            const bool ch2 = n != o;
+            o = n;
+            if (__ballot(ch2) == 0) break;
+        }
+        const uint64_t Gf = ~o;  // M plus everything its outer borders enclose
+        // 8-connected components of Gf in raster order of their first pixel =
+        // external contours in cv2's discovery order; keep the largest by
+        // contourArea (stable sort + [-1] with cv2's reversed list => earliest wins ties)
+        uint64_t rem = Gf, bestF = 0;
+        int best2 = -1;
+        for (;;) {
+            const uint64_t rowsb = __ballot(rem != 0);
+            if (rowsb == 0) break;
+            const int r0 = __builtin_ctzll(rowsb);
+            const uint64_t rv = shfl_u64(rem, r0);
+            const int b0 = __builtin_ctzll(rv);
+            uint64_t s = (lane == r0) ? (1ull << b0) : 0ull;
+            for (;;) {
+                const uint64_t h3 = s | (s << 1) | (s >> 1);
+                const uint64_t n = (h3 | row_up(h3, lane, 0) | row_down(h3, lane, 0)) & Gf;
+                const bool ch2 = n != s;
+                s = n;
+                if (__ballot(ch2) == 0) break;
+            }
+            const uint64_t a = s, b = row_down(s, lane, 0), a1 = a >> 1, b1 = b >> 1;
+            const int c = 2 * __builtin_popcountll(a & a1 & b & b1) + __builtin_popcountll(a & a1 & b & ~b1) +
+                          __builtin_popcountll(a & a1 & ~b & b1) + __builtin_popcountll(a & ~a1 & b & b1) +
+                          __builtin_popcountll(~a & a1 & b & b1);
+            const int area2 = wave_sum_i32(c);  // 2 * cv2.contourArea
+            if (area2 > best2) { best2 = area2; bestF = s; }
+            rem &= ~s;
+        }
+        // contourArea > 100: filled contour, else the whole closed mask (_reading.py:141-148);
+        // both are used only through `& dial.mask` / `& dial.circle_mask`.
+        const uint64_t N = best2 > 200 ? bestF : M;
+        const uint64_t outer = N & annulus;
+
+        // momentum vector (_reading.py:32-41)
+        const double cx = D.cx, cy = D.cy;
+        double sx = 0.0, sy = 0.0;
+        {
+            const double dy = (double)(wy0 + lane) - cy;
+            const double ty = (dy < 0 ? -1.0 : 1.0) * (dy * dy);
+            uint64_t bits = N;
+            while (bits) {
+                const int x = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const double dx = (double)(wx0 + x) - cx;
+                sx += (dx < 0 ? -1.0 : 1.0) * (dx * dx);
+                sy += ty;
+            }
+        }
+        sx = wave_sum_f64(sx);
+        sy = wave_sum_f64(sy);
+        const double msign = D.negative_momentum ? -1.0 : 1.0;
+        double mom = 0.0;
+        const bool have_mom = angle_by_vector(msign * sx, msign * sy, mom);
+
+        // pass 1: count and minimum of the kept angles (_reading.py:79-82)
+        int nk = 0;
+        double mina = 1e300;
+        for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double) {
+            ++nk;
+            if (a < mina) mina = a;
+        });
+        nk = wave_sum_i32(nk);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mina = fmin(mina, __shfl_xor(mina, o2, 64));
+        if (nk == 0) {
+            status = 2;  // unreadable dial (_reading.py:79-81)
+        } else {
+            // pass 2: the `cut` smallest / largest (angle, sqdist) tuples to drop (_reading.py:86-91)
+            const int cut = nk >= 5 ? min(2, (nk - 3) / 2) : 0;
+            const Key PINF = {1e300, 1e300}, NINF = {-1e300, -1e300};
+            Key klo = NINF, khi = PINF;
+            if (cut > 0) {
+                Key l1 = PINF, l2 = PINF, h1 = NINF, h2 = NINF;
+                for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double dd) {
+                    Key k;
+                    k.a = fabs(a - mina) < 0.75 ? a : a - 1;
+                    k.d = dd;
+                    if (key_lt(k, l1)) { l2 = l1; l1 = k; } else if (key_lt(k, l2)) { l2 = k; }
+                    if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
+                });
+                for (int c2 = 0; c2 < cut; ++c2) {
+                    klo = wave_min_key(l1);
+                    if (l1.a == klo.a && l1.d == klo.d) { l1 = l2; l2 = PINF; }
+                    khi = wave_max_key(h1);
+                    if (h1.a == khi.a && h1.d == khi.d) { h1 = h2; h2 = NINF; }
+                }
+            }
+            // pass 3: distance^2-weighted mean angle of the rest (_reading.py:92-94)
+            double sad = 0.0, sd = 0.0;
+            for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double dd) {
+                Key k;
+                k.a = fabs(a - mina) < 0.75 ? a : a - 1;
+                k.d = dd;
+                if (cut == 0 || (key_lt(klo, k) && key_lt(k, khi))) {
+                    sad += k.a * dd;
+                    sd += dd;
+                }
+            });
+            sad = wave_sum_f64(sad);
+            sd = wave_sum_f64(sd);
+            angle = sad / sd;
+            const double fixed = angle - (D.angle_of_zero / 360.0);
+            pos = py_fmod(10.0 * fixed, 10.0);  // _reading.py:95-96
+        }
+    }
+    if (lane == 0) { s_status[d] = status; s_pos[d] = pos; s_angle[d] = angle; }
+    __syncthreads();
+
+    // ---- error aggregation + digit combine (_reading.py:98-111) ----
+    if (threadIdx.x == 0) {
+        melf_result r = {};
+        r.match_x = mx; r.match_y = my; r.match_val = mv;
+        r.failed_dial = -1;
+        r.status = MELF_FRAME_OK;
+        for (int k = 0; k < P.ndials; ++k) {
+            r.pos[k] = s_pos[k];
+            r.angle[k] = s_angle[k];
+            if (s_status[k] == 2) r.unreadable_mask |= 1u << k;
+        }
+        for (int k = 0; k < P.ndials; ++k)
+            if (s_status[k] == 1) { r.status = MELF_FRAME_NEEDLE_CONTOURS_NOT_FOUND; r.failed_dial = k; break; }
+        if (r.status == MELF_FRAME_NEEDLE_CONTOURS_NOT_FOUND) {
+            // the reference raises at this dial: later dials are never looked at
+            uint32_t keep = (1u << r.failed_dial) - 1u;
+            r.unreadable_mask &= keep;
+        } else if (r.unreadable_mask) {
+            r.status = MELF_FRAME_ANGLE_UNDETERMINED;
+        } else if (P.ndials == 4) {
+            r.value = value_by_positions(r.pos[P.name_order[0]], r.pos[P.name_order[1]], r.pos[P.name_order[2]],
+                                         r.pos[P.name_order[3]]);
+        }
+        results[f] = r;
+    }
+}
+
+void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& P, const DialGeom* d_geom,
+                  const uint64_t* d_rowmasks, const MatchPartial* d_partials, int nparts, int rw,
+                  melf_result* d_results, hipStream_t stream)
+{
+    dim3 grid(n), block(64 * P.ndials);
+    if (from_hls)
+        hipLaunchKernelGGL(k_dials<true>, grid, block, 0, stream, src, P, d_geom, d_rowmasks, d_partials, nparts, rw,
+                           d_results);
+    else
+        hipLaunchKernelGGL(k_dials<false>, grid, block, 0, stream, src, P, d_geom, d_rowmasks, d_partials, nparts, rw,
+                           d_results);
+}
+
+}  // namespace melf

@@ -1,0 +1,610 @@
+// Host side of libmeterelf_hip: calibration blob, per-GPU context, entry points.
+// The C ABI is declared and documented in include/meterelf_hip.h.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "melf_device.h"
+#include "melf_internal.h"
+
+using namespace melf;
+
+// ---------------------------------------------------------------- errors ----
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MELF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+extern "C" const char* melf_last_error(void) { return g_err.c_str(); }
+extern "C" int melf_abi_version(void) { return MELF_ABI_VERSION; }
+extern "C" int melf_device_count(int* count)
+{
+    if (!count) return fail(MELF_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(MELF_ERR_NO_DEVICE, hipGetErrorString(e)); }
+    *count = n;
+    return MELF_SUCCESS;
+}
+extern "C" const char* melf_kernel_name(int k)
+{
+    static const char* names[MELF_K_COUNT] = {"k_lplane", "k_match", "k_dials", "k_fused_mask", "k_bgr2hls"};
+    return (k >= 0 && k < MELF_K_COUNT) ? names[k] : "?";
+}
+
+static int check_params(const melf_params* p)
+{
+    if (!p) return fail(MELF_ERR_INVALID, "params is NULL");
+    if (p->abi_version != MELF_ABI_VERSION) return fail(MELF_ERR_INVALID, "melf_params.abi_version mismatch");
+    if (p->ndials < 1 || p->ndials > MELF_MAX_DIALS) return fail(MELF_ERR_INVALID, "ndials must be 1..8");
+    if (p->th < 1 || p->tw < 1) return fail(MELF_ERR_INVALID, "bad template size");
+    return MELF_SUCCESS;
+}
+
+// ------------------------------------------------- dial masks (host, a5) ----
+// Restates cv2.circle (thickness 1) + cv2.floodFill (4-connected, exact value)
+// as the reference combines them in meterelf/_dial_data.py:22-48.
+
+static inline void plot(uint8_t* img, int rows, int cols, int x, int y)
+{
+    if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) img[(size_t)y * cols + x] = 255;
+}
+
+// integer midpoint circle exactly as OpenCV's Circle() walks it
+static void circle_outline(uint8_t* img, int rows, int cols, int cx, int cy, int radius)
+{
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        plot(img, rows, cols, cx - dx, cy - dy); plot(img, rows, cols, cx - dx, cy + dy);
+        plot(img, rows, cols, cx + dx, cy - dy); plot(img, rows, cols, cx + dx, cy + dy);
+        plot(img, rows, cols, cx - dy, cy - dx); plot(img, rows, cols, cx - dy, cy + dx);
+        plot(img, rows, cols, cx + dy, cy - dx); plot(img, rows, cols, cx + dy, cy + dx);
+        ++dy;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+// scanline flood fill: 4-connected region of pixels equal to the seed value that
+// are not blocked by `blocked`; filled pixels become 255 and blocked.
+static void flood_fill_scanline(uint8_t* img, std::vector<uint8_t>& blocked, int rows, int cols, int sx, int sy)
+{
+    if ((unsigned)sx >= (unsigned)cols || (unsigned)sy >= (unsigned)rows) return;
+    const uint8_t v0 = img[(size_t)sy * cols + sx];
+    auto open = [&](int x, int y) {
+        return !blocked[(size_t)y * cols + x] && img[(size_t)y * cols + x] == v0;
+    };
+    if (!open(sx, sy)) return;
+    std::vector<std::pair<int, int>> todo;
+    todo.emplace_back(sx, sy);
+    while (!todo.empty()) {
+        auto [x, y] = todo.back();
+        todo.pop_back();
+        if (!open(x, y)) continue;
+        int xl = x, xr = x;
+        while (xl > 0 && open(xl - 1, y)) --xl;
+        while (xr + 1 < cols && open(xr + 1, y)) ++xr;
+        for (int i = xl; i <= xr; ++i) blocked[(size_t)y * cols + i] = 1;
+        for (int ny = y - 1; ny <= y + 1; ny += 2) {
+            if (ny < 0 || ny >= rows) continue;
+            bool run = false;
+            for (int i = xl; i <= xr; ++i) {
+                const bool o = open(i, ny);
+                if (o && !run) todo.emplace_back(i, ny);
+                run = o;
+            }
+        }
+        for (int i = xl; i <= xr; ++i) img[(size_t)y * cols + i] = 255;
+    }
+}
+
+static int py_round_int(double v) { return (int)nearbyint(v); }  // Python round(): half to even
+
+extern "C" int melf_build_dial_masks(const melf_params* p, uint8_t* masks)
+{
+    if (int rc = check_params(p)) return rc;
+    if (!masks) return fail(MELF_ERR_INVALID, "masks is NULL");
+    const int th = p->th, tw = p->tw;
+    const size_t n = (size_t)th * tw;
+    for (int d = 0; d < p->ndials; ++d) {
+        const melf_dial& D = p->dial[d];
+        uint8_t* mask = masks + (size_t)d * 2 * n;
+        uint8_t* circle_mask = mask + n;
+        memset(mask, 0, n);
+        const int dial_radius = py_round_int(D.diameter / 2.0);
+        const int cx = py_round_int(D.cx), cy = py_round_int(D.cy);
+        const int start_radius = dial_radius + D.dist_from_center;
+        circle_outline(mask, th, tw, cx, cy, start_radius);
+        circle_outline(mask, th, tw, cx, cy, start_radius + D.circle_thickness - 1);
+        std::vector<uint8_t> blocked(n, 0);
+        if (cx + start_radius + 1 < 0 || cx + start_radius + 1 >= tw || cy < 0 || cy >= th)
+            return fail(MELF_ERR_INVALID, "dial annulus seed point lies outside the dials template");
+        flood_fill_scanline(mask, blocked, th, tw, cx + start_radius + 1, cy);
+        memcpy(circle_mask, mask, n);
+        if (cx < 0 || cx >= tw) return fail(MELF_ERR_INVALID, "dial centre lies outside the dials template");
+        flood_fill_scanline(mask, blocked, th, tw, cx, cy);
+    }
+    return MELF_SUCCESS;
+}
+
+// ------------------------------------------------------------------ blob ----
+struct BlobHeader {
+    uint32_t magic;     // 'MELF'
+    uint32_t version;
+    uint64_t total;
+    melf_params params;
+};
+static const uint32_t BLOB_MAGIC = 0x464c454du;
+
+extern "C" size_t melf_blob_size(const melf_params* p)
+{
+    if (check_params(p)) return 0;
+    const size_t n = (size_t)p->th * p->tw;
+    return sizeof(BlobHeader) + n + (size_t)p->ndials * 2 * n;
+}
+
+extern "C" int melf_blob_pack(const melf_params* p, const uint8_t* templ, void* blob, size_t blob_bytes)
+{
+    if (int rc = check_params(p)) return rc;
+    if (!templ || !blob) return fail(MELF_ERR_INVALID, "NULL argument");
+    const size_t need = melf_blob_size(p);
+    if (blob_bytes < need) return fail(MELF_ERR_INVALID, "blob buffer too small");
+    BlobHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = BLOB_MAGIC;
+    h.version = MELF_ABI_VERSION;
+    h.total = need;
+    h.params = *p;
+    uint8_t* b = (uint8_t*)blob;
+    memcpy(b, &h, sizeof(h));
+    const size_t n = (size_t)p->th * p->tw;
+    memcpy(b + sizeof(h), templ, n);
+    return melf_build_dial_masks(p, b + sizeof(h) + n);
+}
+
+static int blob_check(const void* blob, size_t blob_bytes, BlobHeader* h)
+{
+    if (!blob || blob_bytes < sizeof(BlobHeader)) return fail(MELF_ERR_INVALID, "blob too small");
+    memcpy(h, blob, sizeof(*h));
+    if (h->magic != BLOB_MAGIC || h->version != MELF_ABI_VERSION) return fail(MELF_ERR_INVALID, "not a meterelf blob");
+    if (int rc = check_params(&h->params)) return rc;
+    if (h->total != melf_blob_size(&h->params) || blob_bytes < h->total) return fail(MELF_ERR_INVALID, "blob size mismatch");
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_blob_params(const void* blob, size_t blob_bytes, melf_params* out)
+{
+    BlobHeader h;
+    if (int rc = blob_check(blob, blob_bytes, &h)) return rc;
+    if (out) *out = h.params;
+    return MELF_SUCCESS;
+}
+
+// --------------------------------------------------------------- context ----
+struct TimedEvent {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+struct melf_ctx {
+    int device = 0;
+    melf_params P;
+    std::vector<uint8_t> h_masks;   // [ndials][2][th*tw]
+    std::vector<uint8_t> h_templ;
+    MatchGeom mg;
+    uint32_t* d_tplT = nullptr;
+    DialGeom* d_geom = nullptr;
+    uint64_t* d_rowmasks = nullptr;
+    hipStream_t stream = nullptr;
+    // workspaces (grown on demand)
+    MatchPartial* d_partials = nullptr;
+    size_t partials_cap = 0;
+    melf_result* d_results = nullptr;
+    size_t results_cap = 0;
+    uint8_t* d_stage_in = nullptr;
+    size_t stage_in_cap = 0;
+    uint8_t* d_stage_out = nullptr;
+    size_t stage_out_cap = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<TimedEvent> events;
+    double acc_ms[MELF_K_COUNT] = {0};
+    int64_t acc_n[MELF_K_COUNT] = {0};
+};
+
+template <class T>
+static int grow(T** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap) return MELF_SUCCESS;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc((void**)ptr, need * sizeof(T)));
+    *cap = need;
+    return MELF_SUCCESS;
+}
+
+struct KernelTimer {
+    melf_ctx* c;
+    hipStream_t s;
+    TimedEvent ev;
+    bool on;
+    KernelTimer(melf_ctx* ctx, int k, hipStream_t st) : c(ctx), s(st), on(ctx->profiling)
+    {
+        if (!on) return;
+        ev.kernel = k;
+        if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) { on = false; return; }
+        hipEventRecord(ev.start, s);
+    }
+    ~KernelTimer()
+    {
+        if (!on) return;
+        hipEventRecord(ev.stop, s);
+        c->events.push_back(ev);
+    }
+};
+
+static int setup_device_tables(melf_ctx* c)
+{
+    const melf_params& P = c->P;
+    const int th = P.th, tw = P.tw;
+    // --- K2 geometry + transposed, row-padded template dwords ---
+    MatchGeom& g = c->mg;
+    g.th = th;
+    g.tw = tw;
+    g.tw4 = (tw + 3) / 4;
+    g.trows = th + 2 * (MATCH_R - 1);
+    const int rem = tw & 3;
+    g.last_ones = rem == 0 ? 0x01010101u : (rem == 1 ? 0x00000001u : (rem == 2 ? 0x00000101u : 0x00010101u));
+    g.ldsw = MATCH_CBLK / 4 + g.tw4 + 1;
+    g.lds_rows = MATCH_RBLK + th - 1;
+    if ((size_t)g.ldsw * g.lds_rows * 4 > 64 * 1024)
+        return fail(MELF_ERR_TOO_LARGE, "dials template does not fit the match kernel's 64 KiB LDS tile");
+    long tsum = 0;
+    for (size_t i = 0; i < (size_t)th * tw; ++i) tsum += c->h_templ[i];
+    g.tmean = (double)tsum * (1.0 / ((double)th * tw));
+    std::vector<uint32_t> tplT((size_t)g.tw4 * g.trows, 0u);
+    for (int i = 0; i < th; ++i)
+        for (int jj = 0; jj < g.tw4; ++jj) {
+            uint32_t w = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int j = jj * 4 + k;
+                if (j < tw) w |= (uint32_t)c->h_templ[(size_t)i * tw + j] << (8 * k);
+            }
+            tplT[(size_t)jj * g.trows + (i + MATCH_R - 1)] = w;
+        }
+    HIP_TRY(hipMalloc((void**)&c->d_tplT, tplT.size() * 4));
+    HIP_TRY(hipMemcpy(c->d_tplT, tplT.data(), tplT.size() * 4, hipMemcpyHostToDevice));
+
+    // --- K3 windows and row bit masks ---
+    std::vector<DialGeom> geom(P.ndials);
+    std::vector<uint64_t> rowmasks((size_t)P.ndials * 2 * 64, 0);
+    const size_t n = (size_t)th * tw;
+    for (int d = 0; d < P.ndials; ++d) {
+        const melf_dial& D = P.dial[d];
+        const int R = py_round_int(D.diameter / 2.0) + D.dist_from_center + D.circle_thickness - 1;
+        const int mcx = py_round_int(D.cx), mcy = py_round_int(D.cy);
+        DialGeom& G = geom[d];
+        G.ws = 2 * R + 5;
+        G.wx0 = mcx - R - 2;
+        G.wy0 = mcy - R - 2;
+        G.core_x = (int)D.cx;  // int() truncation, meterelf/_reading.py:156
+        G.core_y = (int)D.cy;
+        if (G.ws > 64) return fail(MELF_ERR_TOO_LARGE, "dial mask radius > 29 px does not fit the 64x64 dial window");
+        const uint8_t* disk = c->h_masks.data() + (size_t)d * 2 * n;
+        for (int pl = 0; pl < 2; ++pl)
+            for (int y = 0; y < th; ++y)
+                for (int x = 0; x < tw; ++x) {
+                    if (!disk[pl * n + (size_t)y * tw + x]) continue;
+                    const int wy = y - G.wy0, wx = x - G.wx0;
+                    // the kernel needs a 2-px margin around the disk inside its window
+                    if (wy < 2 || wy >= G.ws - 2 || wx < 2 || wx >= G.ws - 2)
+                        return fail(MELF_ERR_TOO_LARGE, "dial mask leaks outside its window (clipped circle?)");
+                    rowmasks[((size_t)d * 2 + pl) * 64 + wy] |= 1ull << wx;
+                }
+        if (G.core_x - 2 < G.wx0 || G.core_x + 2 >= G.wx0 + G.ws || G.core_y - 2 < G.wy0 || G.core_y + 2 >= G.wy0 + G.ws)
+            return fail(MELF_ERR_INVALID, "dial colour core outside the dial window");
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_geom, geom.size() * sizeof(DialGeom)));
+    HIP_TRY(hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(DialGeom), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->d_rowmasks, rowmasks.size() * 8));
+    HIP_TRY(hipMemcpy(c->d_rowmasks, rowmasks.data(), rowmasks.size() * 8, hipMemcpyHostToDevice));
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, int blob_on_device, melf_ctx** out)
+{
+    if (!out) return fail(MELF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MELF_ERR_NO_DEVICE, "no HIP device: libmeterelf_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MELF_ERR_INVALID, "bad device index");
+    HIP_TRY(hipSetDevice(device));
+    std::vector<uint8_t> host;
+    if (blob_on_device) {
+        if (!blob || blob_bytes < sizeof(BlobHeader)) return fail(MELF_ERR_INVALID, "blob too small");
+        host.resize(blob_bytes);
+        HIP_TRY(hipMemcpy(host.data(), blob, blob_bytes, hipMemcpyDeviceToHost));
+        blob = host.data();
+    }
+    BlobHeader h;
+    if (int rc = blob_check(blob, blob_bytes, &h)) return rc;
+    melf_ctx* c = new melf_ctx();
+    c->device = device;
+    c->P = h.params;
+    const size_t n = (size_t)c->P.th * c->P.tw;
+    const uint8_t* b = (const uint8_t*)blob + sizeof(BlobHeader);
+    c->h_templ.assign(b, b + n);
+    c->h_masks.assign(b + n, b + n + (size_t)c->P.ndials * 2 * n);
+    int rc = MELF_SUCCESS;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(MELF_ERR_HIP, "hipStreamCreate failed");
+    if (!rc) rc = setup_device_tables(c);
+    if (rc) {
+        melf_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return MELF_SUCCESS;
+}
+
+extern "C" void melf_ctx_destroy(melf_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
+    hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks);
+    hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int melf_ctx_params(const melf_ctx* c, melf_params* out)
+{
+    if (!c || !out) return fail(MELF_ERR_INVALID, "NULL argument");
+    *out = c->P;
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_get_masks(const melf_ctx* c, uint8_t* masks)
+{
+    if (!c || !masks) return fail(MELF_ERR_INVALID, "NULL argument");
+    memcpy(masks, c->h_masks.data(), c->h_masks.size());
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_set_profiling(melf_ctx* c, int on)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    c->profiling = on != 0;
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_timings(melf_ctx* c, double ms[MELF_K_COUNT], int64_t launches[MELF_K_COUNT])
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto& e : c->events) {
+        HIP_TRY(hipEventSynchronize(e.stop));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e.start, e.stop));
+        c->acc_ms[e.kernel] += t;
+        c->acc_n[e.kernel] += 1;
+        hipEventDestroy(e.start);
+        hipEventDestroy(e.stop);
+    }
+    c->events.clear();
+    for (int k = 0; k < MELF_K_COUNT; ++k) {
+        if (ms) ms[k] = c->acc_ms[k];
+        if (launches) launches[k] = c->acc_n[k];
+        c->acc_ms[k] = 0;
+        c->acc_n[k] = 0;
+    }
+    return MELF_SUCCESS;
+}
+
+// ------------------------------------------------------------ full path ----
+static const int MAX_FRAMES_PER_LAUNCH = 32768;
+
+extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
+                                      void* d_results, melf_result* out_host, void* stream_)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (n < 0 || H <= 0 || W <= 0) return fail(MELF_ERR_INVALID, "bad batch shape");
+    if (n == 0) return MELF_SUCCESS;
+    if (!d_frames) return fail(MELF_ERR_INVALID, "d_frames is NULL");
+    if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+    const melf_params& P = c->P;
+    // numpy slicing img[y0:y1, x0:x1] clamps to the image (meterelf/_image.py:54-55)
+    const int x0 = P.rect_x0 < W ? P.rect_x0 : W, x1 = P.rect_x1 < W ? P.rect_x1 : W;
+    const int y0 = P.rect_y0 < H ? P.rect_y0 : H, y1 = P.rect_y1 < H ? P.rect_y1 : H;
+    const int crows = y1 - y0, ccols = x1 - x0;
+    if (x0 < 0 || y0 < 0 || crows < P.th || ccols < P.tw)
+        return fail(MELF_ERR_INVALID, "meter_rect crop is smaller than the dials template (cv2.matchTemplate would assert)");
+    const int nparts = match_parts(c->mg, crows, ccols);
+    const int rw = ccols - P.tw + 1;
+    melf_result* res_dev = (melf_result*)d_results;
+    if (!res_dev) {
+        if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
+        res_dev = c->d_results;
+    }
+    for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
+        const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
+        if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
+        const uint8_t* base = (const uint8_t*)d_frames + (size_t)f0 * frame_stride;
+        MatchSrc ms;
+        ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = W * 3;
+        ms.x0 = x0; ms.y0 = y0; ms.rows = crows; ms.cols = ccols;
+        {
+            KernelTimer t(c, MELF_K_MATCH, st);
+            launch_match(ms, true, m, c->mg, c->d_tplT, nullptr, c->d_partials, nullptr, st);
+        }
+        DialsSrc ds;
+        ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = W * 3;
+        ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
+        {
+            KernelTimer t(c, MELF_K_DIALS, st);
+            launch_dials(ds, false, m, P, c->d_geom, c->d_rowmasks, c->d_partials, nparts, rw, res_dev + f0, st);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (out_host) {
+        HIP_TRY(hipMemcpyAsync(out_host, res_dev, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_process_batch(melf_ctx* c, const uint8_t* frames_host, int n, int H, int W, size_t frame_stride,
+                                  melf_result* out_host)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (n == 0) return MELF_SUCCESS;
+    if (!frames_host || !out_host || n < 0) return fail(MELF_ERR_INVALID, "bad argument");
+    if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * frame_stride;
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_in, frames_host, bytes, hipMemcpyHostToDevice, c->stream));
+    return melf_process_batch_dev(c, c->d_stage_in, n, H, W, frame_stride, nullptr, out_host, c->stream);
+}
+
+// ---------------------------------------------------------- stage entries ----
+extern "C" int melf_bgr2hls(melf_ctx* c, const uint8_t* src_host, int rows, int cols, size_t row_stride, uint8_t* dst_host)
+{
+    if (!c || !src_host || !dst_host || rows <= 0 || cols <= 0 || row_stride < (size_t)cols * 3)
+        return fail(MELF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)rows * row_stride, out_bytes = (size_t)rows * cols * 3;
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, in_bytes)) return rc;
+    if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, out_bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_in, src_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    {
+        KernelTimer t(c, MELF_K_HLS, c->stream);
+        launch_bgr2hls(c->d_stage_in, rows, cols, row_stride, c->P.hue_shift, c->d_stage_out, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dst_host, c->d_stage_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int n, int H, int W, void* d_masks,
+                                          void* stream_)
+{
+    if (!c || n < 0 || H <= 0 || W <= 0) return fail(MELF_ERR_INVALID, "bad argument");
+    if (n == 0) return MELF_SUCCESS;
+    if (!d_frames || !d_masks) return fail(MELF_ERR_INVALID, "NULL device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+    for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
+        const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
+        KernelTimer t(c, MELF_K_FUSED_MASK, st);
+        launch_fused_mask((const uint8_t*)d_frames + (size_t)f0 * H * W * 3, m, H, W, c->P.hue_shift, c->P.needle_lo,
+                          c->P.needle_hi, (uint8_t*)d_masks + (size_t)f0 * H * W, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_hls_inrange_close(melf_ctx* c, const uint8_t* frames_host, int n, int H, int W, uint8_t* masks_host)
+{
+    if (!c || !frames_host || !masks_host || n < 0 || H <= 0 || W <= 0) return fail(MELF_ERR_INVALID, "bad argument");
+    if (n == 0) return MELF_SUCCESS;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)n * H * W * 3, out_bytes = (size_t)n * H * W;
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, in_bytes)) return rc;
+    if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, out_bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_in, frames_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (int rc = melf_hls_inrange_close_dev(c, c->d_stage_in, n, H, W, c->d_stage_out, c->stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(masks_host, c->d_stage_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_match_ccoeff(melf_ctx* c, const uint8_t* images_host, int n, int rows, int cols, float* max_val,
+                                 int32_t* max_x, int32_t* max_y, float* result_map)
+{
+    if (!c || !images_host || n < 0) return fail(MELF_ERR_INVALID, "bad argument");
+    if (n == 0) return MELF_SUCCESS;
+    if (rows < c->P.th || cols < c->P.tw) return fail(MELF_ERR_INVALID, "image smaller than the template");
+    if (n > MAX_FRAMES_PER_LAUNCH) return fail(MELF_ERR_INVALID, "too many images for one stage call");
+    HIP_TRY(hipSetDevice(c->device));
+    const int rh = rows - c->P.th + 1, rw = cols - c->P.tw + 1;
+    const size_t in_bytes = (size_t)n * rows * cols;
+    const size_t map_bytes = result_map ? (size_t)n * rh * rw * sizeof(float) : 0;
+    const int nparts = match_parts(c->mg, rows, cols);
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, in_bytes)) return rc;
+    if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, map_bytes + 16)) return rc;
+    if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)n * nparts)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_in, images_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    MatchSrc ms;
+    ms.base = c->d_stage_in; ms.frame_stride = (size_t)rows * cols; ms.row_stride = cols;
+    ms.x0 = 0; ms.y0 = 0; ms.rows = rows; ms.cols = cols;
+    {
+        KernelTimer t(c, MELF_K_MATCH, c->stream);
+        launch_match(ms, false, n, c->mg, c->d_tplT, result_map ? (float*)c->d_stage_out : nullptr, c->d_partials,
+                     nullptr, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<MatchPartial> parts((size_t)n * nparts);
+    HIP_TRY(hipMemcpyAsync(parts.data(), c->d_partials, parts.size() * sizeof(MatchPartial), hipMemcpyDeviceToHost, c->stream));
+    if (result_map) HIP_TRY(hipMemcpyAsync(result_map, c->d_stage_out, map_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // fold the per-tile (max, first-argmax) pairs exactly as K3's prologue does on the device
+    for (int f = 0; f < n; ++f) {
+        float bv = 0.f;
+        int bi = INT32_MAX;
+        for (int k = 0; k < nparts; ++k) {
+            const MatchPartial& p = parts[(size_t)f * nparts + k];
+            if (p.idx != INT32_MAX && (bi == INT32_MAX || p.val > bv || (p.val == bv && p.idx < bi))) { bv = p.val; bi = p.idx; }
+        }
+        if (max_val) max_val[f] = bv;
+        if (max_x) max_x[f] = bi % rw;
+        if (max_y) max_y[f] = bi / rw;
+    }
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_read_dials(melf_ctx* c, const uint8_t* dials_hls_host, int n, melf_result* out_host)
+{
+    if (!c || !dials_hls_host || !out_host || n < 0) return fail(MELF_ERR_INVALID, "bad argument");
+    if (n == 0) return MELF_SUCCESS;
+    HIP_TRY(hipSetDevice(c->device));
+    const melf_params& P = c->P;
+    const size_t per = (size_t)P.th * P.tw * 3;
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, (size_t)n * per)) return rc;
+    if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_in, dials_hls_host, (size_t)n * per, hipMemcpyHostToDevice, c->stream));
+    DialsSrc ds;
+    ds.base = c->d_stage_in; ds.frame_stride = per; ds.row_stride = P.tw * 3;
+    ds.x0 = 0; ds.y0 = 0; ds.crop_rows = P.th; ds.crop_cols = P.tw;
+    {
+        KernelTimer t(c, MELF_K_DIALS, c->stream);
+        launch_dials(ds, true, n, P, c->d_geom, c->d_rowmasks, nullptr, 0, 1, c->d_results, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_results, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MELF_SUCCESS;
+}

@@ -1,0 +1,70 @@
+// Internal declarations shared by the translation units of libmeterelf_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/meterelf_hip.h"
+
+namespace melf {
+
+// ---- K2: template match -----------------------------------------------------
+// One partial (max, first-argmax) per workgroup tile of the correlation map.
+struct MatchPartial {
+    float val;
+    int32_t idx;  // y * rw + x in the frame's correlation map; INT32_MAX = empty
+};
+
+constexpr int MATCH_R = 11;           // output rows per lane
+constexpr int MATCH_WAVES = 4;        // waves per workgroup
+constexpr int MATCH_RBLK = MATCH_R * MATCH_WAVES;  // output rows per workgroup
+constexpr int MATCH_CBLK = 64;        // output cols per workgroup (one per lane)
+
+struct MatchGeom {
+    int th, tw;        // template rows, cols
+    int tw4;           // template row length in dwords (tw padded to 4)
+    int trows;         // padded template rows: th + 2*(MATCH_R-1)
+    uint32_t last_ones;  // byte mask (0x01 per valid byte) of the last template dword
+    int ldsw;          // LDS tile row width in dwords
+    int lds_rows;      // LDS tile rows: MATCH_RBLK + th - 1
+    double tmean;      // cv::mean(template) = sum * (1.0 / N)
+};
+
+// source description for K2: either packed single-channel u8 images or BGR frames
+struct MatchSrc {
+    const uint8_t* base;
+    size_t frame_stride;  // bytes between consecutive images/frames
+    int row_stride;       // bytes between rows
+    int x0, y0;           // origin of the searched image inside the frame (pixels)
+    int rows, cols;       // searched image size
+};
+
+void launch_match(const MatchSrc& src, bool from_bgr, int n, const MatchGeom& g, const uint32_t* d_tplT,
+                  float* d_result_map, MatchPartial* d_partials, int* nparts_out, hipStream_t stream);
+int match_parts(const MatchGeom& g, int rows, int cols);
+
+// ---- K3: per-dial reading ---------------------------------------------------
+struct DialGeom {
+    int32_t wx0, wy0;    // window origin in dials-crop coordinates
+    int32_t ws;          // window size (2R+5 <= 64)
+    int32_t core_x, core_y;  // int(cx), int(cy): centre of the 5x5 colour core
+};
+
+struct DialsSrc {
+    const uint8_t* base;   // BGR frames or packed HLS dials crops
+    size_t frame_stride;
+    int row_stride;        // bytes
+    int x0, y0;            // origin of the meter crop inside the frame (BGR mode)
+    int crop_rows, crop_cols;  // meter crop size (BGR mode): cvtColor image width for the tail rule
+};
+
+void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& P, const DialGeom* d_geom,
+                  const uint64_t* d_rowmasks /* [ndials][2][64] */, const MatchPartial* d_partials,
+                  int nparts, int rw, melf_result* d_results, hipStream_t stream);
+
+// ---- K1b / HLS --------------------------------------------------------------
+void launch_bgr2hls(const uint8_t* d_src, int rows, int cols, size_t row_stride, int hue_shift,
+                    uint8_t* d_dst, hipStream_t stream);
+void launch_fused_mask(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3],
+                       const int hi[3], uint8_t* d_masks, hipStream_t stream);
+
+}  // namespace melf
