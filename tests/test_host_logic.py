@@ -1,0 +1,215 @@
+"""CPU-side tests (-m "not gpu"): the C ABI loads and exports every symbol the
+header declares, struct layouts agree between C and ctypes, and the host logic
+(params loader, dial masks, blob, error conversion, API/CLI formatting) matches
+the oracle / the reference's goldens.  No GPU compute is called here."""
+import ctypes as C
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from meterelf_amd import _api, _engine, _hip, _main, _params, exceptions
+from meterelf_amd._types import HlsColor, Rect
+from oracle import pyoracle as po
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+HEADER = os.path.join(ROOT, 'include', 'meterelf_hip.h')
+
+
+def test_library_exports_every_declared_symbol():
+    with open(HEADER) as fp:
+        text = re.sub(r'/\*.*?\*/', '', fp.read(), flags=re.S)
+    declared = sorted(set(re.findall(r'\b(melf_[a-z0-9_]+)\s*\(', text)))
+    assert len(declared) >= 20
+    L = _hip.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(_hip.EXPORTS) == declared
+
+
+def test_struct_layout_matches_header(tmp_path):
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "meterelf_hip.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(melf_params), sizeof(melf_result),'
+                   'sizeof(melf_dial), offsetof(melf_params, match_threshold), offsetof(melf_params, dial),'
+                   'offsetof(melf_result, pos), offsetof(melf_result, value));return 0;}\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    exp = [C.sizeof(_hip.MelfParams), C.sizeof(_hip.MelfResult), C.sizeof(_hip.MelfDial),
+           _hip.MelfParams.match_threshold.offset, _hip.MelfParams.dial.offset,
+           _hip.MelfResult.pos.offset, _hip.MelfResult.value.offset]
+    assert got == exp
+    assert _hip.RESULT_DTYPE.itemsize == C.sizeof(_hip.MelfResult)
+
+
+@pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])
+def test_params_loader_and_masks_match_oracle(sd):
+    pfile = os.path.join(GOLDEN, sd, 'params.yml')
+    p = _params.load(pfile)
+    op = po.Params(pfile)
+    assert p.dial_names == op.names
+    assert p.dials_template_size == op.template_size
+    assert (p.meter_rect.top_left, p.meter_rect.bottom_right) == op.meter_rect
+    cp = p.to_c()
+    ocp = op.c_params()
+    assert (cp.th, cp.tw, cp.hue_shift, cp.ndials, cp.match_threshold) == (ocp.th, ocp.tw, ocp.hue_shift, ocp.ndials, ocp.match_threshold)
+    assert list(cp.name_order)[:4] == list(op.name_order())
+    for i in range(cp.ndials):
+        (a, b) = (cp.dial[i], ocp.dial[i])
+        assert (a.cx, a.cy, a.range_h, a.range_l, a.range_s, a.negative_momentum, a.angle_of_zero) == \
+               (b.cx, b.cy, b.range_h, b.range_l, b.range_s, b.negative_momentum, b.angle_of_zero)
+    assert list(cp.needle_lo) == [116, 35, 95] and list(cp.needle_hi) == [134, 125, 165]
+    assert np.array_equal(_hip.build_dial_masks(cp), op.masks())
+    # blob round trip
+    blob = _engine.make_blob(p)
+    back = _hip.blob_params(blob)
+    assert bytes(back) == bytes(cp)
+    assert np.array_equal(_engine.load_template(p), op.load_template())
+
+
+def test_dial_masks_random_geometries_match_oracle():
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        cp = _hip.MelfParams()
+        cp.abi_version = _hip.ABI_VERSION
+        (cp.th, cp.tw, cp.ndials) = (int(rng.integers(60, 130)), int(rng.integers(60, 200)), 3)
+        cent, diam, dist, thick = [], [], [], []
+        for d in range(3):
+            dl = cp.dial[d]
+            dl.diameter = int(rng.integers(4, 20))
+            dl.dist_from_center = int(rng.integers(0, 6))
+            dl.circle_thickness = int(rng.integers(1, 11))
+            r_out = int(np.rint(dl.diameter / 2.0)) + dl.dist_from_center + dl.circle_thickness
+            dl.cx = float(np.round(rng.uniform(r_out + 2, cp.tw - r_out - 3), 1))
+            dl.cy = float(np.round(rng.uniform(r_out + 2, cp.th - r_out - 3), 1))
+            if rng.random() < 0.3:
+                (dl.cx, dl.cy) = (float(int(dl.cx)) + 0.5, float(int(dl.cy)) + 0.5)  # half-to-even rounding
+            cent.append((dl.cx, dl.cy)); diam.append(dl.diameter); dist.append(dl.dist_from_center)
+            thick.append(dl.circle_thickness)
+        got = _hip.build_dial_masks(cp)
+        exp = np.zeros_like(got)
+        po.lib().orc_build_dial_masks(cp.th, cp.tw, 3, po._ptr(np.array(cent, np.float64)),
+                                      po._ptr(np.array(diam, np.int32)), po._ptr(np.array(dist, np.int32)),
+                                      po._ptr(np.array(thick, np.int32)), po._ptr(exp))
+        assert np.array_equal(got, exp)
+
+
+def test_load_errors(tmp_path):
+    with pytest.raises(_params.LoadError, match='Cannot load YAML data from'):
+        _params.load(str(tmp_path / 'missing.yml'))
+    bad = tmp_path / 'list.yml'
+    bad.write_text('- 1\n- 2\n')
+    with pytest.raises(_params.LoadError, match='Not a valid parameters file'):
+        _params.load(str(bad))
+    good = open(os.path.join(GOLDEN, 'sample-images1', 'params.yml')).read()
+    nofile = tmp_path / 'p.yml'
+    nofile.write_text(good)
+    with pytest.raises(_params.LoadError, match='File not found'):
+        _params.load(str(nofile))
+    wrong = tmp_path / 'w.yml'
+    wrong.write_text(good.replace('hue_shift: 128', 'hue_shift: "128"'))
+    (tmp_path / 'dials_gray.png').write_bytes(open(os.path.join(GOLDEN, 'sample-images1', 'dials_gray.png'), 'rb').read())
+    with pytest.raises(_params.LoadError, match='hue_shift is not int'):
+        _params.load(str(wrong))
+    wrong.write_text(good.replace('center: [37.3, 63.4]', 'center: [37, 63.4]'))
+    with pytest.raises(_params.LoadError, match='Item 0 in center is not float'):
+        _params.load(str(wrong))
+
+
+def test_hls_color_range_vectors():
+    import json
+    with open(os.path.join(GOLDEN, 'pure_fn_vectors.json')) as fp:
+        vec = json.load(fp)
+    for (c, g, lo, hi) in vec['get_range']:
+        assert HlsColor(*c).get_range(HlsColor(*g)) == (HlsColor(*lo), HlsColor(*hi))
+
+
+def test_exception_messages():
+    e = exceptions.DialsNotFoundError('f.jpg', extra_info={'match val': 17495704.0})
+    assert e.get_message() == 'Dials not found (match val = 17495704.0)'
+    assert str(e) == 'Dials not found from file: f.jpg (match val = 17495704.0)'
+    assert exceptions.NeedleContoursNotFoundError(extra_info={'dial': '0.01'}).get_message() == \
+        'Cannot find needle contours of a dial (dial = 0.01)'
+    assert exceptions.ImageLoadingError('x').get_message() == 'Unable to load image'
+    assert isinstance(e, ValueError) and isinstance(exceptions.ImageLoadingError(), IOError)
+
+
+def test_result_to_python_all_statuses():
+    names = ['0.0001', '0.001', '0.01', '0.1']
+    r = np.zeros(1, _hip.RESULT_DTYPE)[0]
+    r['pos'][:4] = [6.2306, 3.3, 5.1, 2.4]
+    r['value'] = 253.62306
+    (vals, err) = _engine.result_to_python(r, names, 'f')
+    assert err is None and vals == {'0.0001': 6.2306, '0.001': 3.3, '0.01': 5.1, '0.1': 2.4, 'value': 253.62306}
+    r['status'] = _hip.FRAME_DIALS_NOT_FOUND
+    r['match_val'] = 0.0
+    assert _engine.result_to_python(r, names, 'f')[1].get_message() == 'Dials not found (match val = 0.0)'
+    r['status'] = _hip.FRAME_NEEDLE_CONTOURS_NOT_FOUND
+    r['failed_dial'] = 2
+    assert _engine.result_to_python(r, names, 'f')[1].get_message() == 'Cannot find needle contours of a dial (dial = 0.01)'
+    r['status'] = _hip.FRAME_ANGLE_UNDETERMINED
+    r['unreadable_mask'] = 0b1010
+    assert _engine.result_to_python(r, names, 'f')[1].get_message() == \
+        'Cannot determine angle of a dial (unreadable dials = 0.001, 0.1)'
+
+
+def test_no_gpu_means_loud_failure():
+    if _hip.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    p = _params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml'))
+    with pytest.raises(_hip.HipError, match='no CPU fallback'):
+        _hip.Context(_engine.make_blob(p))
+
+
+def test_product_never_imports_the_oracle():
+    for f in glob.glob(os.path.join(ROOT, 'meterelf_amd', '**', '*'), recursive=True):
+        if f.endswith(('.py', '.hip', '.h', '.cpp', 'Makefile')):
+            assert 'oracle' not in open(f).read().lower().replace('the cpu oracle', ''), f
+
+
+@pytest.mark.parametrize('sd,count', [('sample-images1', 81), ('sample-images2', 223)])
+def test_cli_host_logic_against_golden_with_oracle_backend(sd, count, capsys, monkeypatch):
+    """API + CLI host logic (chunking, decode, error conversion, formatting) on CPU:
+    the GPU context is replaced -- in this test only -- by the oracle."""
+    monkeypatch.setattr(_api, 'MeterReader', helpers.OracleReader)
+    monkeypatch.setenv('METERELF_BATCH', '7')
+    files = sorted(glob.glob(os.path.join(GOLDEN, sd, '*.jpg')))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(GOLDEN, sd))
+    try:
+        _main.main(['meterelf', 'params.yml'] + [os.path.basename(f) for f in files] + ['nonexistent.jpg'])
+    finally:
+        os.chdir(cwd)
+    out = capsys.readouterr()
+    assert out.err == ''
+    lines = out.out.splitlines()
+    with open(os.path.join(GOLDEN, sd + '_stdout.txt')) as fp:
+        expected = fp.read().splitlines()
+    assert len(lines) == count + 1
+    assert lines[-1] == 'nonexistent.jpg: UNKNOWN Unable to load image'
+    diff = [(g, e) for (g, e) in zip(lines, expected) if g != e]
+    assert all('20180814021310-00-e02.jpg' in g for (g, _e) in diff) and len(diff) <= 1
+
+
+def test_cli_usage_message():
+    with pytest.raises(SystemExit) as e:
+        _main.main(['meterelf'])
+    assert str(e.value) == 'Usage: meterelf PARAMETERS_FILE [IMAGE_FILE...]'
+
+
+def test_debug_mode_reraises(monkeypatch):
+    from meterelf_amd import _debug
+    monkeypatch.setattr(_api, 'MeterReader', helpers.OracleReader)
+    monkeypatch.setattr(_debug, 'DEBUG', {'1'})
+    pfile = os.path.join(GOLDEN, 'sample-images1', 'params.yml')
+    f = os.path.join(GOLDEN, 'sample-images1', '20180814021309-01-e01.jpg')
+    with pytest.raises(exceptions.DialsNotFoundError) as e:
+        list(_api.get_meter_values(pfile, [f]))
+    assert e.value.get_message() == 'Dials not found (match val = 0.0)'  # reference tests/test_meterelf.py:164-167
