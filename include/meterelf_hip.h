@@ -144,6 +144,12 @@ int melf_hls_inrange_close(melf_ctx* ctx, const uint8_t* frames_host, int n, int
 int melf_hls_inrange_close_dev(melf_ctx* ctx, const void* d_frames, int n, int H, int W,
                                void* d_masks, void* stream);
 
+/* Number of entries of the fused stage's hue lookup table whose in-range answer
+ * depends on the float32 rounding of the individual BGR triple (exact rounding
+ * ties at a bound).  > 0 selects the kernel variant that re-evaluates those
+ * pixels with the exact float path; results are identical either way. */
+int melf_ctx_fused_table_ties(const melf_ctx* ctx, int* count);
+
 /* match_template (meterelf/_utils.py:91-97): TM_CCOEFF of n single-channel u8
  * images (rows x cols, packed) against the context's template + minMaxLoc.
  * result_map (optional) receives n*(rows-th+1)*(cols-tw+1) float32. */

@@ -62,7 +62,7 @@ EXPORTS = [
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
-    'melf_read_dials', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
+    'melf_read_dials', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def lib():
     L.melf_hls_inrange_close_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.melf_match_ccoeff.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.melf_read_dials.argtypes = [vp, vp, C.c_int, vp]
+    L.melf_ctx_fused_table_ties.argtypes = [vp, C.POINTER(C.c_int)]
     L.melf_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.melf_ctx_timings.argtypes = [vp, vp, vp]
     if L.melf_abi_version() != ABI_VERSION:
@@ -241,6 +242,11 @@ class Context:
         out = np.zeros((p.ndials, 2, p.th, p.tw), np.uint8)
         check(self._L.melf_ctx_get_masks(self._h, _ptr(out)))
         return out
+
+    def fused_table_ties(self):
+        n = C.c_int(0)
+        check(self._L.melf_ctx_fused_table_ties(self._h, C.byref(n)))
+        return n.value
 
     # --- measurement ---
     def set_profiling(self, on):

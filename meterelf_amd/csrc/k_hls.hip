@@ -11,6 +11,8 @@
 // bit-packed LDS image (1 bit per pixel, 2 halo rows above and below); passes 2
 // and 3 do the closing on 32-pixel words with carries between neighbouring words;
 // pass 4 expands bits to bytes, one dword store per 4 pixels.
+#include <stdlib.h>
+
 #include "melf_device.h"
 #include "melf_internal.h"
 
@@ -139,6 +141,475 @@ __global__ __launch_bounds__(256) void k_fused_mask(const uint8_t* __restrict__ 
         } else {
             for (int j = 0; j < 4 && x + j < W; ++j) o[j] = (nib >> j & 1u) ? 255 : 0;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1b fast path: table-driven in-range test, exact by construction.
+//
+// The float32 HLS formulas are piecewise functions of small integers:
+//   * L and S depend only on the (vmax, vmin) pair               -> 64 Ki entries, 1 bit
+//   * H depends on which channel is the maximum, on diff = vmax - vmin and on the
+//     signed numerator num (g-b, b-r or r-g), EXCEPT that at exact rounding ties
+//     the float32 error of the particular (vmax, vmin, mid) triple decides.
+// k_build_fused_tables evaluates the exact float path (hls_pixel) for all 2^24
+// BGR triples and records, per (case, diff, num) entry, whether an in-range and/or
+// an out-of-range H was seen (2 bits).  01 = in, 10 = out, 11 = depends on the
+// triple: the main kernel then re-evaluates that pixel with the exact float path.
+// Entry index = case * 65536 + diff^2 + diff + num  (sum_{d<diff}(2d+1) = diff^2).
+// ---------------------------------------------------------------------------
+constexpr int HUE2_DWORDS = 3 * 65536 * 2 / 32;  // 12288 (48 KiB): 2 bits per entry (seen in / seen out)
+constexpr int LS_DWORDS = 65536 / 32;            // 2048  (8 KiB)
+constexpr int HUE1_DWORDS = 3 * 65536 / 32;      // 6144  (24 KiB): 1 bit per entry (in), valid when nothing is ambiguous
+constexpr int HUES_DWORDS = 512 * 512 / 32;      // 8192  (32 KiB): one hue sector as [diff + 255][num + 256] bits;
+                                                 // rows with diff < |num| (pixel not in this sector) stay all-zero
+// interval form of the single-sector tables: one (lo : i16, count : u16) entry per row
+//   lsI[sector][P]        : vmin in [lo, lo + count) passes the L and S bounds when vmax = P
+//   hI[sector][diff + 256]: num  in [lo, lo + count) passes the H bounds
+// valid only if every row's set bits are one contiguous run (checked at build time).
+constexpr int LSI_ROWS = 256, HI_ROWS = 512;
+// global table buffer: [hue2][ls][hue1][hueS x 3][lsI x 3][hI x 3][ties, active sectors, non-interval rows x 3]
+constexpr int OFF_LS = HUE2_DWORDS, OFF_HUE1 = OFF_LS + LS_DWORDS, OFF_HUES = OFF_HUE1 + HUE1_DWORDS,
+              OFF_LSI = OFF_HUES + 3 * HUES_DWORDS, OFF_HI = OFF_LSI + 3 * LSI_ROWS,
+              OFF_COUNT = OFF_HI + 3 * HI_ROWS, OFF_ACTIVE = OFF_COUNT + 1, OFF_NONIV = OFF_ACTIVE + 1;
+static_assert(OFF_NONIV + 3 <= FUSED_TABLE_DWORDS, "table buffer too small");
+
+// e = case * 65536 + diff * (diff + 1) + num.  All three arms are computed and
+// then selected, so that the compiler emits v_cndmask instead of branches.
+__device__ __forceinline__ uint32_t hue_entry(int b, int g, int r, int vmax, int vmin)
+{
+    const int diff = vmax - vmin;
+    const int ep_r = g - b, ep_g = b - r + 65536, ep_b = r - g + 131072;
+    int ep = ep_b;
+    ep = (g == vmax) ? ep_g : ep;
+    ep = (r == vmax) ? ep_r : ep;
+    return (uint32_t)(diff * (diff + 1) + ep);
+}
+
+__global__ __launch_bounds__(256) void k_build_fused_tables(int hue_shift, Bounds B, uint32_t* __restrict__ tables)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;  // 2^24 threads: one BGR triple each
+    const int b = t & 255, g = (t >> 8) & 255, r = (t >> 16) & 255;
+    int H, L, S;
+    hls_pixel(b, g, r, false, hue_shift, H, L, S);
+    const int vmax = max(max(b, g), r), vmin = min(min(b, g), r);
+    const uint32_t e = hue_entry(b, g, r, vmax, vmin);
+    const bool hin = H >= B.lo[0] && H <= B.hi[0];
+    const uint32_t hm = (hin ? 1u : 2u) << ((e & 15u) * 2u);
+    uint32_t* hw = tables + (e >> 4);
+    if ((*(volatile uint32_t*)hw & hm) == 0) atomicOr(hw, hm);
+    const bool lsin = L >= B.lo[1] && L <= B.hi[1] && S >= B.lo[2] && S <= B.hi[2];
+    if (lsin) {
+        const uint32_t li = (uint32_t)(vmax << 8 | vmin);
+        uint32_t* lw = tables + OFF_LS + (li >> 5);
+        const uint32_t lm = 1u << (li & 31u);
+        if ((*(volatile uint32_t*)lw & lm) == 0) atomicOr(lw, lm);
+    }
+}
+
+// hue1[e] = (hue2[e] == 01); counts entries with hue2[e] == 11
+__global__ __launch_bounds__(256) void k_finish_fused_tables(uint32_t* __restrict__ tables)
+{
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;  // one hue1 dword = 32 entries = 2 hue2 dwords
+    if (w >= (uint32_t)HUE1_DWORDS) return;
+    uint32_t out = 0, amb = 0;
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t v = tables[2 * w + h];
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t two = (v >> (2 * k)) & 3u;
+            out |= (two == 1u ? 1u : 0u) << (16 * h + k);
+            amb += two == 3u ? 1u : 0u;
+        }
+    }
+    tables[OFF_HUE1 + w] = out;
+    if (amb) atomicAdd(tables + OFF_COUNT, amb);
+    // the same bits again in the per-sector [diff][num + 256] layout of the single-sector kernels
+    for (int k = 0; k < 32; ++k) {
+        if (!((out >> k) & 1u)) continue;
+        const uint32_t e = w * 32u + (uint32_t)k, c = e >> 16, local = e & 65535u;
+        int diff = (int)sqrtf((float)local);
+        while (diff * diff > (int)local) --diff;
+        while ((diff + 1) * (diff + 1) <= (int)local) ++diff;
+        const int num = (int)local - diff * (diff + 1);  // diff*diff <= local <= diff*diff + 2*diff
+        const uint32_t se = (uint32_t)((diff + 255) * 512 + num + 256);
+        atomicOr(tables + OFF_HUES + c * HUES_DWORDS + (se >> 5), 1u << (se & 31u));
+        atomicOr(tables + OFF_ACTIVE, 1u << c);
+    }
+}
+
+// One thread per table row: turns the row's bits into (lo, count) and counts rows whose set bits
+// are not one contiguous run.  Rows 0..255 of each sector: LS rows (vmax = P = row; the LS bit of
+// (P, vmin) is sector-independent); rows 256..767: hue rows (diff = row - 512).
+__global__ __launch_bounds__(256) void k_interval_tables(uint32_t* __restrict__ tables)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 3 * (LSI_ROWS + HI_ROWS)) return;
+    const int c = t / (LSI_ROWS + HI_ROWS), row = t - c * (LSI_ROWS + HI_ROWS);
+    int lo = 0, count = 0, runs = 0;
+    bool prev = false;
+    if (row < LSI_ROWS) {
+        for (int m = 0; m < 256; ++m) {
+            const uint32_t li = (uint32_t)(row << 8 | m);
+            const bool b = (tables[OFF_LS + (li >> 5)] >> (li & 31u)) & 1u;
+            if (b && !prev) { ++runs; if (runs == 1) lo = m; }
+            if (b && runs == 1) ++count;
+            prev = b;
+        }
+        tables[OFF_LSI + c * LSI_ROWS + row] = ((uint32_t)count << 16) | (uint32_t)(lo & 0xffff);
+    } else {
+        const int hr = row - LSI_ROWS;  // 0..511 = diff + 256; the bit table has rows diff + 255 in 0..510
+        if (hr >= 1) {
+            for (int nn = 0; nn < 512; ++nn) {
+                const uint32_t se = (uint32_t)((hr - 1) * 512 + nn);
+                const bool b = (tables[OFF_HUES + c * HUES_DWORDS + (se >> 5)] >> (se & 31u)) & 1u;
+                if (b && !prev) { ++runs; if (runs == 1) lo = nn - 256; }
+                if (b && runs == 1) ++count;
+                prev = b;
+            }
+        }
+        tables[OFF_HI + c * HI_ROWS + hr] = ((uint32_t)count << 16) | (uint32_t)(lo & 0xffff);
+    }
+    if (runs > 1) atomicAdd(tables + OFF_NONIV + c, 1u);
+}
+
+void launch_build_fused_tables(int hue_shift, const int lo[3], const int hi[3], uint32_t* d_tables, hipStream_t stream)
+{
+    Bounds B;
+    for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
+    (void)hipMemsetAsync(d_tables, 0, FUSED_TABLE_DWORDS * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(k_build_fused_tables, dim3(65536), dim3(256), 0, stream, hue_shift, B, d_tables);
+    hipLaunchKernelGGL(k_finish_fused_tables, dim3(HUE1_DWORDS / 256), dim3(256), 0, stream, d_tables);
+    hipLaunchKernelGGL(k_interval_tables, dim3((3 * (LSI_ROWS + HI_ROWS) + 255) / 256), dim3(256), 0, stream, d_tables);
+}
+int fused_tables_noniv_offset() { return OFF_NONIV; }
+int fused_tables_count_offset() { return OFF_COUNT; }
+int fused_tables_active_offset() { return OFF_ACTIVE; }
+
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct Px16 {
+    u32x4 q0, q1, q2;  // 16 BGR pixels = 48 bytes
+};
+
+// 16 pixels -> 16 in-range bits (bit k = pixel k)
+template <int VAR>
+__device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __restrict__ hue,
+                                              const uint32_t* __restrict__ ls, int hue_shift, const Bounds& B)
+{
+    constexpr bool AMB = VAR == 4;
+    constexpr bool SINGLE = VAR < 3;
+    constexpr bool IV = VAR >= 6;  // interval tables, sector VAR - 6
+    const uint32_t d[12] = {in.q0.x, in.q0.y, in.q0.z, in.q0.w, in.q1.x, in.q1.y, in.q1.z, in.q1.w,
+                            in.q2.x, in.q2.y, in.q2.z, in.q2.w};
+    if (VAR == 5)  // timing-only build: consume every loaded dword, no pixel math
+        return (d[0] ^ d[1] ^ d[2] ^ d[3] ^ d[4] ^ d[5] ^ d[6] ^ d[7] ^ d[8] ^ d[9] ^ d[10] ^ d[11]) & 0xffffu;
+    uint32_t bits = 0, amb = 0;
+    // interval variant: every lane reads its own bank (row-replicated tables), so no LDS conflicts
+    const uint32_t ls_lane = (threadIdx.x & 63u) * 4u;                    // byte 0 of the lsI address
+    const uint32_t hi_lane = (threadIdx.x & 31u) * 4u + 256u * 128u;      // hI row = diff + 256, 128 B per row
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = (3 * k) >> 2, sh = ((3 * k) & 3) * 8;
+        const uint32_t px = sh <= 8 ? (d[j] >> sh) : __builtin_amdgcn_alignbit(d[j + 1 < 12 ? j + 1 : 11], d[j], sh);
+        const int b = px & 255, g = (px >> 8) & 255, r = (px >> 16) & 255;
+        if (IV) {
+            constexpr int SEC = VAR - 6;
+            const int P = SEC == 0 ? r : (SEC == 1 ? g : b);
+            const int Q = SEC == 0 ? g : (SEC == 1 ? b : r);
+            const int S = SEC == 0 ? b : (SEC == 1 ? r : g);
+            const int mn = min(Q, S);
+            const int diff = P - mn, num = Q - S;
+            // lsI row P (256 B per row, one dword per lane): address bytes = {lane*4, P, 0, 0}
+            const uint32_t lso = __builtin_amdgcn_perm(px, ls_lane, SEC == 0 ? 0x0c0c0600u : (SEC == 1 ? 0x0c0c0500u : 0x0c0c0400u));
+            const uint32_t lse = *(const uint32_t*)((const char*)ls + lso);
+            const uint32_t hio = (uint32_t)((diff << 7) + (int)hi_lane);
+            const uint32_t hie = *(const uint32_t*)((const char*)hue + hio);
+            const bool in_ls = (uint32_t)(mn - (int)(int16_t)(lse & 0xffffu)) < (lse >> 16);
+            const bool in_h = (uint32_t)(num - (int)(int16_t)(hie & 0xffffu)) < (hie >> 16);
+            bits = bits + bits + ((in_ls && in_h) ? 1u : 0u);  // add-with-carry: pixel 0 ends up at bit 15
+        } else if (SINGLE) {
+            // Sector of maximum P: num = Q - S, vmin = min(Q, S).  A pixel belongs to the sector iff
+            // |num| <= diff (ties resolved r > g > b by which entries the table builder ever sets), so
+            // pixels of other sectors index rows/columns of the [diff + 255][num + 256] table that are
+            // all-zero: no compare or select is needed here.
+            const int P = VAR == 0 ? r : (VAR == 1 ? g : b);
+            const int Q = VAR == 0 ? g : (VAR == 1 ? b : r);
+            const int S = VAR == 0 ? b : (VAR == 1 ? r : g);
+            const int mn = min(Q, S);
+            const int diff = P - mn, num = Q - S;
+            const uint32_t li = (uint32_t)(P << 8 | mn);
+            const uint32_t lv = ls[li >> 5] >> (li & 31u);
+            const int e = (diff << 9) + num + (255 * 512 + 256);  // >= 0; low 5 bits = (num + 256) & 31
+            const uint32_t hv = hue[e >> 5] >> ((uint32_t)e & 31u);
+            bits = __builtin_amdgcn_alignbit(lv & hv, bits, 1);  // bit 0 enters at bit 31
+        } else {
+            const int vmax = max(max(b, g), r), vmin = min(min(b, g), r);
+            const uint32_t li = (uint32_t)(vmax << 8 | vmin);
+            const uint32_t lv = ls[li >> 5] >> (li & 31u);
+            const uint32_t e = hue_entry(b, g, r, vmax, vmin);
+            if (AMB) {
+                const uint32_t hv = hue[e >> 4] >> ((e & 15u) * 2u);
+                bits = __builtin_amdgcn_alignbit(lv & hv & ~(hv >> 1), bits, 1);
+                amb |= (lv & hv & (hv >> 1) & 1u) << k;
+            } else {
+                const uint32_t hv = hue[e >> 5] >> (e & 31u);
+                bits = __builtin_amdgcn_alignbit(lv & hv, bits, 1);
+            }
+        }
+        // keep at most four pixels' lookups in flight (register pressure)
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (IV) bits = __builtin_bitreverse32(bits);  // pixel k from bit 15 - k to bit 16 + k
+    bits >>= 16;  // pixel k sits at bit 16 + k
+    if (AMB) {
+        while (amb) {  // rounding ties that depend on the triple: exact float path
+            const int k = __builtin_ctz(amb);
+            amb &= amb - 1;
+            const uint32_t w0 = d[(3 * k) >> 2], w1 = d[((3 * k) >> 2) + 1 < 12 ? ((3 * k) >> 2) + 1 : 11];
+            const uint32_t px = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (((3 * k) & 3) * 8));
+            int Hh, Ll, Ss;
+            hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, false, hue_shift, Hh, Ll, Ss);
+            bits |= (Hh >= B.lo[0] && Hh <= B.hi[0]) ? (1u << k) : 0u;
+        }
+    }
+    return bits;
+}
+
+// Persistent workgroups; each takes segments (frame, row range) and streams them top to
+// bottom in passes of RC rows:
+//  (1) 16 px per thread -> in-range bits into a ring of bit rows (48 B loaded, coalesced per row),
+//  (2) per 32-px word: 3x3 dilation and the horizontal half of the erosion -> ring of "he" rows,
+//  (3) per 16-px strip: vertical AND of three he rows, expand to bytes, one 16-byte store.
+// PREFETCH: the next pass's 48 bytes per thread are requested before the current pass is processed
+// (ping-pong register sets) and stay in flight across its two barriers.
+// Requires W % 16 == 0 (no scalar-tail pixels, 16-byte aligned rows).
+// VAR 0 / 1 / 2: only the hue sector whose maximum is r / g / b can be in range (decided
+// from the table at context creation) -> no 3-way select, one 32 KiB table.
+// VAR 3: any sectors, no ties.  VAR 4: any sectors, ties re-evaluated exactly.
+// VAR 5: timing-only (memory traffic and barriers, no pixel math; output is garbage).
+template <int VAR, int THREADS, bool PREFETCH, int WPS /* waves per SIMD the register budget must allow */>
+__global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
+    const uint8_t* __restrict__ frames, int n, int H, int W, int hue_shift, Bounds B,
+    const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB)
+{
+    constexpr bool AMB = VAR == 4;
+    constexpr bool IV = VAR >= 6;
+    constexpr bool SINGLE = VAR < 3 || VAR == 5;
+    constexpr int HDW = IV ? HI_ROWS * 32 : (AMB ? HUE2_DWORDS : (SINGLE ? HUES_DWORDS : HUE1_DWORDS));
+    constexpr int LSDW = IV ? LSI_ROWS * 64 : LS_DWORDS;
+    // tables in static LDS (their addresses fold into the ds_read offset field), rings in dynamic LDS
+    __shared__ uint32_t hue[HDW];
+    __shared__ uint32_t ls[LSDW];
+    extern __shared__ uint32_t ring[];
+    const int wpr = (W + 31) >> 5;
+    uint32_t* raw = ring;
+    uint32_t* he = raw + NB * wpr;
+    const int tid = threadIdx.x;
+    if (IV) {  // each row replicated so that lane L of a 32-lane group always reads bank L
+        for (int i = tid; i < HDW; i += THREADS) hue[i] = g_tables[OFF_HI + (VAR - 6) * HI_ROWS + (i >> 5)];
+        for (int i = tid; i < LSDW; i += THREADS) ls[i] = g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + (i >> 6)];
+    } else {
+        for (int i = tid; i < HDW; i += THREADS)
+            hue[i] = g_tables[(AMB ? 0 : (SINGLE ? OFF_HUES + (VAR % 3) * HUES_DWORDS : OFF_HUE1)) + i];
+        for (int i = tid; i < LSDW; i += THREADS) ls[i] = g_tables[OFF_LS + i];
+    }
+    for (int i = tid; i < 2 * NB * wpr; i += THREADS) raw[i] = 0;  // unused half-words must read as 0
+
+    const int G16 = W >> 4;
+    const int RC = THREADS / G16;  // rows per pass
+    const int trow = tid / G16, tg = tid - trow * G16;
+    const bool active = trow < RC;
+    const int tgc = active ? tg : 0;
+    const int drow = tid / wpr, dk = tid - drow * wpr;  // word work item of step 2
+    const uint32_t lastmask = (W & 31) ? ((1u << (W & 31)) - 1u) : 0xffffffffu;
+    const int nbm = NB - 1;
+    __syncthreads();
+
+    for (int seg = blockIdx.x; seg < n * segs_per_frame; seg += gridDim.x) {
+        const int f = seg / segs_per_frame, sidx = seg - f * segs_per_frame;
+        const int r0 = sidx * seg_rows, r1 = min(H, r0 + seg_rows);
+        const uint8_t* frame = frames + (size_t)f * H * W * 3;
+        uint8_t* out = masks + (size_t)f * H * W;
+        // Unconditional, address-clamped loads: keeping them out of divergent control flow lets the
+        // compiler wait with an exact vmcnt(N) instead of vmcnt(0).
+        auto load = [&](int a, Px16& dst) {
+            int y = a + trow;
+            y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            // plain (cached) loads: each 128-byte line is touched by three dwordx4 instructions of the
+            // wave (48-byte lane stride); non-temporal loads refetch it and measured 25 % slower
+            const u32x4* p = (const u32x4*)(frame + ((size_t)y * W + 16 * tgc) * 3);
+            dst.q0 = p[0]; dst.q1 = p[1]; dst.q2 = p[2];
+        };
+        auto pass = [&](int a, const Px16& cur) {
+            // ---- (1) in-range bits of input rows [a, a+RC) ----
+            if (PREFETCH) {
+                const int y = a + trow;
+                uint32_t bits = inrange16<VAR>(cur, hue, ls, hue_shift, B);
+                bits = (y >= 0 && y < H) ? bits : 0u;
+                if (active && y < r1 + 2) ((uint16_t*)raw)[((y + 4 * NB) & nbm) * wpr * 2 + tg] = (uint16_t)bits;
+            } else {
+                // load next to its use: shortest live ranges (this path runs at 64..80 VGPRs)
+                const int y = a + trow;
+                if (active && y < r1 + 2) {
+                    uint32_t bits = 0;
+                    if (y >= 0 && y < H) {
+                        const u32x4* p = (const u32x4*)(frame + ((size_t)y * W + 16 * tg) * 3);
+                        Px16 px;
+                        px.q0 = p[0]; px.q1 = p[1]; px.q2 = p[2];
+                        bits = inrange16<VAR>(px, hue, ls, hue_shift, B);
+                    }
+                    ((uint16_t*)raw)[((y + 4 * NB) & nbm) * wpr * 2 + tg] = (uint16_t)bits;
+                }
+            }
+            __syncthreads();
+            // ---- (2) rows [a-1, a+RC-2]: 3x3 dilation, then the horizontal part of the erosion.
+            //      Pixels outside the image are neutral (never win): 0 for the dilation, 1 for the erosion.
+            if (drow < RC) {
+                const int y = a - 1 + drow;
+                if (y < r1 + 1 && y >= r0 - 1) {
+                    uint32_t v = 0xffffffffu;
+                    if (y >= 0 && y < H) {
+                        uint32_t C = 0, L = 0, R = 0;  // vertical OR of the three raw rows: this word and its neighbours
+#pragma unroll
+                        for (int dy = -1; dy <= 1; ++dy) {
+                            const int yy = y + dy;
+                            if (yy < 0 || yy >= H) continue;
+                            const uint32_t* rr = raw + ((yy + 4 * NB) & nbm) * wpr;
+                            C |= rr[dk];
+                            L |= dk > 0 ? rr[dk - 1] : 0u;
+                            R |= dk + 1 < wpr ? rr[dk + 1] : 0u;
+                        }
+                        uint32_t dil = C | (C << 1) | (L >> 31) | (C >> 1) | (R << 31);
+                        // dilated bit just left / right of this word (bit 31 of word k-1, bit 0 of word k+1)
+                        uint32_t dl = ((L >> 31) | (L >> 30) | C) & 1u;
+                        uint32_t dr = (R | (R >> 1) | (C >> 31)) & 1u;
+                        if (dk == 0) dl = 1u;
+                        if (dk == wpr - 1) { dil |= ~lastmask; dr = 1u; }
+                        v = dil & ((dil << 1) | dl) & ((dil >> 1) | (dr << 31));
+                    }
+                    he[((y + 4 * NB) & nbm) * wpr + dk] = v;
+                }
+            }
+            __syncthreads();
+            // ---- (3) rows [a-2, a+RC-3] of the segment: vertical AND, expand, store ----
+            {
+                const int y = a - 2 + trow;
+                if (active && y >= r0 && y < r1) {
+                    const uint16_t* h16p = (const uint16_t*)he;
+                    const uint32_t h16 = (uint32_t)h16p[((y - 1 + 4 * NB) & nbm) * wpr * 2 + tg] &
+                                         (uint32_t)h16p[((y + 4 * NB) & nbm) * wpr * 2 + tg] &
+                                         (uint32_t)h16p[((y + 1 + 4 * NB) & nbm) * wpr * 2 + tg];
+                    u32x4 o;
+                    o.x = (((h16 >> 0) & 15u) * 0x00204081u & 0x01010101u) * 255u;
+                    o.y = (((h16 >> 4) & 15u) * 0x00204081u & 0x01010101u) * 255u;
+                    o.z = (((h16 >> 8) & 15u) * 0x00204081u & 0x01010101u) * 255u;
+                    o.w = (((h16 >> 12) & 15u) * 0x00204081u & 0x01010101u) * 255u;
+                    __builtin_nontemporal_store(o, (u32x4*)(out + (size_t)y * W + 16 * tg));
+                }
+            }
+            // no barrier needed here: the rings (NB >= 2*RC + 4 rows) keep this pass's rows apart
+            // from the rows the next pass writes
+        };
+        int a = r0 - 2;
+        const int aend = r1 + 2;
+        if (PREFETCH) {
+            Px16 pa, pb;
+            load(a, pa);
+            for (;;) {
+                load(a + RC, pb);
+                pass(a, pa);
+                a += RC;
+                if (a >= aend) break;
+                load(a + RC, pa);
+                pass(a, pb);
+                a += RC;
+                if (a >= aend) break;
+            }
+        } else {
+            const Px16 unused = {};
+            for (; a < aend; a += RC) pass(a, unused);
+        }
+        __syncthreads();
+    }
+}
+
+bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W)
+{
+    return W >= 16 && W <= 512 * 16 && (W & 15) == 0 && (((size_t)d_frames | (size_t)d_masks) & 15) == 0 && H >= 1;
+}
+
+// launch configuration (MELF_FUSED_CONFIG=0..3 for experiments):
+//   0: 512 threads, 3 workgroups/CU (6 waves/SIMD, <= 80 VGPRs), no prefetch   [default]
+//   1: 512 threads, 2 workgroups/CU (4 waves/SIMD), register prefetch
+//   2: 1024 threads, 1-2 workgroups/CU (4 waves/SIMD), register prefetch
+//   3: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), no prefetch
+static int g_fused_config = 0;
+
+template <int V, int T, bool PF, int WPS>
+static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
+                         const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
+{
+    const int G16 = W >> 4, RC = T / G16, wpr = (W + 31) >> 5;
+    int NB = 8;
+    while (NB < 2 * RC + 4) NB <<= 1;
+    const int per_cu = WPS * 256 / T;          // resident workgroups per CU
+    const int target = 256 * (per_cu < 1 ? 1 : per_cu);
+    int segs = (target + n - 1) / n;
+    int seg_rows = (H + segs - 1) / segs;
+    if (seg_rows < 32) seg_rows = H < 32 ? H : 32;
+    segs = (H + seg_rows - 1) / seg_rows;
+    const long total = (long)n * segs;
+    const int grid = (int)(total < target ? total : target);
+    const size_t shmem = (size_t)(2 * NB * wpr) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, d_frames, n, H, W, hue_shift,
+                       B, d_tables, d_masks, segs, seg_rows, NB);
+}
+
+template <int V>
+static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
+                         const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
+{
+    if constexpr (V >= 6) {  // 128 KiB of replicated interval tables: one 1024-thread workgroup per CU
+        if (g_fused_config == 1) launch_lut_t<V, 1024, false, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
+        else launch_lut_t<V, 1024, true, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
+    } else {
+        switch (g_fused_config) {
+            case 1: launch_lut_t<V, 512, true, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 2: launch_lut_t<V, 1024, true, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 3: launch_lut_t<V, 1024, false, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            default: launch_lut_t<V, 512, false, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        }
+    }
+}
+
+// variant: 0/1/2 single sector r/g/b (bit tables), 3 generic, 4 generic with tie re-evaluation, 5 timing-only,
+//          6/7/8 single sector r/g/b with interval tables
+void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3],
+                           const int hi[3], const uint32_t* d_tables, int variant, uint8_t* d_masks,
+                           hipStream_t stream)
+{
+    Bounds B;
+    for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
+    static bool env_read = false;
+    if (!env_read) {
+        if (const char* e = getenv("MELF_FUSED_CONFIG")) g_fused_config = atoi(e) & 3;
+        env_read = true;
+    }
+    switch (variant) {
+        case 0: launch_lut_v<0>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        case 1: launch_lut_v<1>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        case 2: launch_lut_v<2>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        case 3: launch_lut_v<3>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        case 5: launch_lut_v<5>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        case 6: launch_lut_v<6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        case 7: launch_lut_v<7>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        case 8: launch_lut_v<8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        default: launch_lut_v<4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
     }
 }
 

@@ -2,6 +2,7 @@
 // The C ABI is declared and documented in include/meterelf_hip.h.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -211,6 +212,10 @@ struct melf_ctx {
     uint32_t* d_tplT = nullptr;
     DialGeom* d_geom = nullptr;
     uint64_t* d_rowmasks = nullptr;
+    uint32_t* d_fused_tables = nullptr;  // K1b lookup tables (built on the GPU at creation)
+    int fused_ambiguous = 0;             // hue-table entries whose answer depends on float32 rounding of the triple
+    int fused_active_sectors = 0;        // bit c: hue sector c (max = r/g/b) has in-range entries
+    int fused_variant = 3;
     hipStream_t stream = nullptr;
     // workspaces (grown on demand)
     MatchPartial* d_partials = nullptr;
@@ -222,6 +227,7 @@ struct melf_ctx {
     uint8_t* d_stage_out = nullptr;
     size_t stage_out_cap = 0;
     // profiling
+    bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
     bool profiling = false;
     std::vector<TimedEvent> events;
     double acc_ms[MELF_K_COUNT] = {0};
@@ -325,6 +331,31 @@ static int setup_device_tables(melf_ctx* c)
     HIP_TRY(hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(DialGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&c->d_rowmasks, rowmasks.size() * 8));
     HIP_TRY(hipMemcpy(c->d_rowmasks, rowmasks.data(), rowmasks.size() * 8, hipMemcpyHostToDevice));
+
+    // --- K1b lookup tables for the context's fixed needle bounds ---
+    HIP_TRY(hipMalloc((void**)&c->d_fused_tables, (size_t)FUSED_TABLE_DWORDS * 4));
+    launch_build_fused_tables(P.hue_shift, P.needle_lo, P.needle_hi, c->d_fused_tables, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t namb = 0;
+    HIP_TRY(hipMemcpy(&namb, c->d_fused_tables + fused_tables_count_offset(), 4, hipMemcpyDeviceToHost));
+    c->fused_ambiguous = (int)namb;
+    uint32_t active = 0;
+    HIP_TRY(hipMemcpy(&active, c->d_fused_tables + fused_tables_active_offset(), 4, hipMemcpyDeviceToHost));
+    c->fused_active_sectors = (int)active;
+    // kernel variant: ties -> 4; exactly one hue sector can be in range -> 0/1/2; otherwise 3
+    c->fused_variant = namb > 0 ? 4 : (active == 1 ? 0 : (active == 2 ? 1 : (active == 4 ? 2 : 3)));
+    if (c->fused_variant < 3) {  // single sector: interval tables if every row is one contiguous run
+        uint32_t noniv[3] = {1, 1, 1};
+        HIP_TRY(hipMemcpy(noniv, c->d_fused_tables + fused_tables_noniv_offset(), 12, hipMemcpyDeviceToHost));
+        if (noniv[c->fused_variant] == 0) c->fused_variant += 6;
+    }
+    if (const char* e = getenv("MELF_FUSED_VARIANT")) {  // tests: "generic" = 3, "ties" = 4
+        if (!strcmp(e, "generic") && namb == 0) c->fused_variant = 3;
+        if (!strcmp(e, "bits") && c->fused_variant >= 6) c->fused_variant -= 6;  // single-sector bit tables
+        if (!strcmp(e, "ties")) c->fused_variant = 4;
+        if (!strcmp(e, "memonly")) c->fused_variant = 5;  // timing experiments only: output is garbage
+    }
     return MELF_SUCCESS;
 }
 
@@ -348,6 +379,7 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
     if (int rc = blob_check(blob, blob_bytes, &h)) return rc;
     melf_ctx* c = new melf_ctx();
     c->device = device;
+    if (const char* e = getenv("MELF_FORCE_GENERIC_MASK")) c->force_generic_mask = e[0] == '1';
     c->P = h.params;
     const size_t n = (size_t)c->P.th * c->P.tw;
     const uint8_t* b = (const uint8_t*)blob + sizeof(BlobHeader);
@@ -371,7 +403,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
-    hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks);
+    hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -389,6 +421,13 @@ extern "C" int melf_ctx_get_masks(const melf_ctx* c, uint8_t* masks)
     if (!c || !masks) return fail(MELF_ERR_INVALID, "NULL argument");
     memcpy(masks, c->h_masks.data(), c->h_masks.size());
     return MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_fused_table_ties(const melf_ctx* c, int* count)
+{
+    if (!c || !count) return fail(MELF_ERR_INVALID, "NULL argument");
+    *count = c->fused_ambiguous;
+    return c->fused_variant * 16 + c->fused_active_sectors >= 0 ? MELF_SUCCESS : MELF_SUCCESS;
 }
 
 extern "C" int melf_ctx_set_profiling(melf_ctx* c, int on)
@@ -520,8 +559,13 @@ extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
         const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
         KernelTimer t(c, MELF_K_FUSED_MASK, st);
-        launch_fused_mask((const uint8_t*)d_frames + (size_t)f0 * H * W * 3, m, H, W, c->P.hue_shift, c->P.needle_lo,
-                          c->P.needle_hi, (uint8_t*)d_masks + (size_t)f0 * H * W, st);
+        const uint8_t* fin = (const uint8_t*)d_frames + (size_t)f0 * H * W * 3;
+        uint8_t* fout = (uint8_t*)d_masks + (size_t)f0 * H * W;
+        if (fused_mask_lut_ok(fin, fout, H, W) && !c->force_generic_mask)
+            launch_fused_mask_lut(fin, m, H, W, c->P.hue_shift, c->P.needle_lo, c->P.needle_hi, c->d_fused_tables,
+                                  c->fused_variant, fout, st);
+        else
+            launch_fused_mask(fin, m, H, W, c->P.hue_shift, c->P.needle_lo, c->P.needle_hi, fout, st);
     }
     HIP_TRY(hipGetLastError());
     return MELF_SUCCESS;

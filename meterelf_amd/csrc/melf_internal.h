@@ -66,5 +66,15 @@ void launch_bgr2hls(const uint8_t* d_src, int rows, int cols, size_t row_stride,
                     uint8_t* d_dst, hipStream_t stream);
 void launch_fused_mask(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3],
                        const int hi[3], uint8_t* d_masks, hipStream_t stream);
+// table-driven fast path of K1b (W % 16 == 0, 16-byte aligned buffers)
+constexpr int FUSED_TABLE_DWORDS = 3 * 65536 * 2 / 32 + 65536 / 32 + 3 * 65536 / 32 + 3 * (512 * 512 / 32) + 3 * (256 + 512) + 16;
+int fused_tables_count_offset();
+int fused_tables_active_offset();
+int fused_tables_noniv_offset();
+void launch_build_fused_tables(int hue_shift, const int lo[3], const int hi[3], uint32_t* d_tables, hipStream_t stream);
+bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W);
+void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3],
+                           const int hi[3], const uint32_t* d_tables, int variant, uint8_t* d_masks,
+                           hipStream_t stream);
 
 }  // namespace melf

@@ -103,7 +103,8 @@ def _blobby(rng, n, H, W):
 
 
 @pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])
-@pytest.mark.parametrize('n,H,W', [(3, 640, 480), (2, 480, 640), (2, 37, 53), (1, 33, 100), (2, 70, 1920)])
+@pytest.mark.parametrize('n,H,W', [(3, 640, 480), (2, 480, 640), (2, 37, 53), (1, 33, 100), (2, 70, 1920),
+                                   (5, 3, 16), (3, 101, 48), (2, 67, 80), (1, 1, 32), (7, 40, 1040)])
 def test_fused_mask_bit_exact(env, sd, n, H, W):
     from oracle import pyoracle as po
     e = env[sd]
@@ -118,7 +119,88 @@ def test_fused_mask_bit_exact(env, sd, n, H, W):
         exp = po.hls_inrange_close(frames[f], p.hue_shift, lo, hi)
         assert np.array_equal(got[f], exp), (f, np.argwhere(got[f] != exp)[:5])
         nz += int((exp > 0).sum())
-    assert nz > 0  # the test must exercise set pixels
+    assert nz > 0 or H * W < 2000  # the test must exercise set pixels
+
+
+def test_fused_mask_all_2_24_triples(env):
+    """The table-driven fast path against the oracle's float path for EVERY BGR
+    triple: each test pixel sits alone on a black background (spacing 4), so the
+    3x3 closing returns exactly its own in-range bit."""
+    from oracle import pyoracle as po
+    ctx = env['sample-images1']['reader'].ctx
+    p = ctx.params
+    (lo, hi) = (list(p.needle_lo), list(p.needle_hi))
+    side = 512
+    per = side * side
+    set_total = 0
+    for chunk in range((1 << 24) // per):
+        t = np.arange(chunk * per, (chunk + 1) * per, dtype=np.uint32)
+        tri = np.stack([t & 255, (t >> 8) & 255, (t >> 16) & 255], axis=-1).astype(np.uint8).reshape(side, side, 3)
+        img = np.zeros((side * 4, side * 4, 3), np.uint8)
+        img[1::4, 1::4] = tri
+        got = ctx.hls_inrange_close(img[None])[0]
+        exp = po.hls_inrange_close(img, p.hue_shift, lo, hi)
+        assert np.array_equal(got, exp), chunk
+        set_total += int((exp[1::4, 1::4] > 0).sum())
+        assert int((exp > 0).sum()) == int((exp[1::4, 1::4] > 0).sum())  # isolated pixels survive alone
+    assert set_total > 10000
+
+
+@pytest.mark.parametrize('variant', ['generic', 'ties'])
+def test_fused_mask_other_kernel_variants(env, monkeypatch, variant):
+    """The context picks the single-hue-sector kernel for the sample bounds; this
+    forces the generic table kernel and the one that re-evaluates rounding ties."""
+    from meterelf_amd import MeterReader
+    from oracle import pyoracle as po
+    monkeypatch.setenv('MELF_FUSED_VARIANT', variant)
+    reader = MeterReader(env['sample-images1']['params'])
+    try:
+        p = reader.ctx.params
+        assert reader.ctx.fused_table_ties() == 0
+        frames = _blobby(np.random.default_rng(4), 2, 96, 160)
+        got = reader.ctx.hls_inrange_close(frames)
+        for f in range(2):
+            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi)))
+    finally:
+        reader.close()
+
+
+@pytest.mark.parametrize('needle', [
+    dict(h=125, l=80, s=130, rh=9, rl=45, rs=35, shift=128),    # sample bounds: red sector only
+    dict(h=85, l=120, s=120, rh=12, rl=80, rs=100, shift=0),    # green sector
+    dict(h=170, l=120, s=120, rh=12, rl=80, rs=100, shift=0),   # blue sector
+    dict(h=128, l=128, s=128, rh=100, rl=120, rs=120, shift=0),  # several sectors
+    dict(h=43, l=128, s=128, rh=1, rl=128, rs=128, shift=0),    # narrow band at a sector seam (60 deg)
+    dict(h=200, l=100, s=200, rh=60, rl=90, rs=55, shift=77),   # odd hue shift, wraps
+])
+def test_fused_mask_other_bounds(env, tmp_path, needle):
+    """Other needle colours select other kernel variants (single g / b sector, generic);
+    all must equal the oracle, on random and on blob-structured frames."""
+    import shutil
+    from meterelf_amd import MeterReader, _params
+    from oracle import pyoracle as po
+    src = os.path.join(GOLDEN, 'sample-images1')
+    text = open(os.path.join(src, 'params.yml')).read()
+    text = text.replace('hue_shift: 128', 'hue_shift: %d' % needle['shift'])
+    text = text.replace('needle_color: {h: 125, l: 80, s: 130}', 'needle_color: {h: %(h)d, l: %(l)d, s: %(s)d}' % needle)
+    text = text.replace('needle_color_range: {h: 9, l: 45, s: 35}', 'needle_color_range: {h: %(rh)d, l: %(rl)d, s: %(rs)d}' % needle)
+    (tmp_path / 'params.yml').write_text(text)
+    shutil.copy(os.path.join(src, 'dials_gray.png'), tmp_path / 'dials_gray.png')
+    reader = MeterReader(_params.load(str(tmp_path / 'params.yml')))
+    try:
+        p = reader.ctx.params
+        (lo, hi) = (list(p.needle_lo), list(p.needle_hi))
+        rng = np.random.default_rng(needle['h'])
+        frames = np.concatenate([rng.integers(0, 256, size=(2, 64, 256, 3), dtype=np.uint8), _blobby(rng, 1, 64, 256)])
+        got = reader.ctx.hls_inrange_close(frames)
+        nz = 0
+        for f in range(len(frames)):
+            exp = po.hls_inrange_close(frames[f], p.hue_shift, lo, hi)
+            assert np.array_equal(got[f], exp), f
+            nz += int((exp > 0).sum())
+        assert nz > 0
+    finally:
+        reader.close()
 
 
 def test_fused_mask_on_fixture_frames(env):

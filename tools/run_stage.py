@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Runs one stage repeatedly on GPU 0 -- the command to put behind
+`rocprofv3 ... -- python3 tools/run_stage.py ...` for per-kernel traces and PMC passes.
+
+    python3 tools/run_stage.py fused [--iters 20] [--batch 256]
+    python3 tools/run_stage.py full  [--iters 10] [--batch 1024]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('stage', choices=['fused', 'full'])
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--sample-dir', default='sample-images1')
+    a = ap.parse_args()
+    import torch
+    from meterelf_amd import _engine, _hip, _params
+    pfile = os.path.join(ROOT, 'tests', 'golden', a.sample_dir, 'params.yml')
+    ctx = _hip.Context(_engine.make_blob(_params.load(pfile)), 0)
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    ctx.set_profiling(True)
+    if a.stage == 'fused':
+        B = a.batch or 256
+        frames = torch.randint(0, 256, (B, 640, 480, 3), dtype=torch.uint8, device=dev, generator=g)
+        masks = torch.empty((B, 640, 480), dtype=torch.uint8, device=dev)
+        for _ in range(a.iters):
+            ctx.hls_inrange_close_dev(frames.data_ptr(), B, 640, 480, masks.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+    else:
+        import bench
+        import glob
+        import numpy as np
+        from meterelf_amd._image import imread_bgr
+        B = a.batch or 1024
+        files = [f for f in sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', a.sample_dir, '*.jpg')))
+                 if os.path.basename(f) not in bench.REJECTED]
+        base = np.stack([imread_bgr(f) for f in files if imread_bgr(f).shape == imread_bgr(files[0]).shape])
+        frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), B, 2024, dev)
+        (H, W) = base.shape[1:3]
+        for _ in range(a.iters):
+            ctx.process_batch_dev(frames.data_ptr(), B, H, W, want_host=True, stream=stream)
+    t = ctx.timings()
+    for (k, (ms, n)) in t.items():
+        if n:
+            print('%-14s launches %4d  avg %.4f ms' % (k, n, ms / n))
+
+
+if __name__ == '__main__':
+    main()
