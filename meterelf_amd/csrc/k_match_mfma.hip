@@ -1,0 +1,373 @@
+// K2 on the matrix cores -- cv2.matchTemplate(L, template, TM_CCOEFF) + cv2.minMaxLoc
+// (reference: meterelf/_utils.py:91-97, called from meterelf/_image.py:57-66) for whole
+// batches: the exact integer cross-correlation as an i8 MFMA GEMM with FRAMES on the N
+// dimension.
+//
+//   D[m][n] += A[m][k] * B[k][n]      v_mfma_i32_32x32x32_i8
+//   m = output column x inside a 32-wide block xb, n = frame inside a group of 32 frames,
+//   k = image column inside a 32-wide block kb of image row y' = y + i
+//   A[m][k] = T'[i][32 d + k - m]   (Toeplitz expansion of template row i, d = kb - xb, zero outside)
+//   B[k][n] = L'_n[y'][32 kb + k]
+// with T' = T - 128 and L' = L - 128 as signed bytes.  The exact u8 correlation follows from
+//   sum T L = sum T' L' + 128 * winsum(L) + 128 * (sum T - 128 N)
+// and window sums come from two tiny exact passes (row sums, sliding column sums).
+// 188 useful of every 224 K columns are non-zero (84 % dense); accumulators stay in registers
+// over the whole 119 x 224 K loop, so there is no scatter and no partial-sum traffic.
+//
+// One wave owns R = 5 consecutive output rows x 64 output columns x 32 frames (160 accumulator
+// registers).  At template row i it needs image rows y0+i .. y0+i+4: a sliding window of six
+// register row-buffers (5 live + 1 incoming, rotated by a 6-way unroll), so every image row
+// is fetched once per wave, straight from L2 in B-fragment order (lane * 16 bytes).
+//
+// The operand / result lane maps were verified with exact integer data
+// (tools/ubench/mfma_i8_layout.hip): A lane l = A[l & 31][16 (l >> 5) + j],
+// B lane l = B[16 (l >> 5) + j][l & 31], D lane l reg r = D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+#include <limits.h>
+
+#include "melf_device.h"
+#include "melf_internal.h"
+
+namespace melf {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// k_prep_lplane: searched image ->
+//   Lg[group][row][kb][h][n][16] : L' = L - 128 (int8) in MFMA B-fragment order (a row is
+//                                  NKB KiB: 32 frames x 32*NKB image columns), zero beyond the
+//                                  image / beyond the batch;
+//   R[group][row][x][n]          : row-window sums sum_{j < tw} L[row][x + j] (u16), x < 64.
+// One workgroup (256 threads) per (group, row); thread = (frame n = t / 8, block kb = t % 8)
+// converts 32 pixels, keeps a 32-element running sum, and an 8-lane scan turns the per-block
+// totals into the row's inclusive prefix sums (int16, in LDS); the window sums are then two
+// LDS reads each.  The 16-byte fragment pieces go through LDS so that the row leaves with
+// coalesced 16-byte stores.
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+
+template <bool FROM_BGR>
+__global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw,
+                                                     int8_t* __restrict__ Lg, uint16_t* __restrict__ R)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[8 * 2 * 32 * 4];  // [kb][h][n][16 B]
+    __shared__ int16_t pre[32][256 + 8];                                    // inclusive prefix of L' per frame
+    const int y = blockIdx.x, grp = blockIdx.y;
+    const int t = threadIdx.x, n = t >> 3, kb = t & 7;
+    const int f = grp * 32 + n;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 32 output bytes (L' = 0 <=> pad)
+    const bool live = kb < nkb && f < nframes && y < src.rows;  // uniform per wave except the ragged batch tail
+    if (live) {
+        const uint8_t* prow = src.base + (size_t)f * src.frame_stride + (size_t)(src.y0 + y) * src.row_stride;
+        const int xbeg = kb * 32;
+        const int npx = min(32, src.cols - xbeg);  // < 32 only in the last block: masked below, not branched on
+        if (FROM_BGR) {
+            const size_t o = (size_t)(src.x0 + xbeg) * 3;
+            const uint8_t* p = prow + o;
+            const int mis = (int)((size_t)p & 3);
+            // 25 aligned dwords cover the 96 bytes of 32 pixels at any byte alignment; the window may
+            // reach past the crop (never used: masked) but must stay inside the frame buffer
+            if ((size_t)(src.y0 + y) * src.row_stride + o + 100 <= src.frame_stride) {
+                const uint32_t* q = (const uint32_t*)(p - mis);
+                uint32_t d[25];
+#pragma unroll
+                for (int i = 0; i < 25; ++i) d[i] = q[i];
+                uint32_t a[24];
+#pragma unroll
+                for (int i = 0; i < 24; ++i) a[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], (uint32_t)mis * 8u);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const int j = (3 * k) >> 2, sh = ((3 * k) & 3) * 8;
+                    const uint32_t px = sh <= 8 ? (a[j] >> sh) : __builtin_amdgcn_alignbit(a[j + 1 < 24 ? j + 1 : 23], a[j], sh);
+                    const int L = hls_lightness(px & 255, (px >> 8) & 255, (px >> 16) & 255);
+                    const uint32_t v = k < npx ? (uint32_t)((L - 128) & 255) : 0u;
+                    w[k >> 2] |= v << ((k & 3) * 8);
+                }
+            } else {  // last bytes of the frame buffer: byte loads
+                for (int k = 0; k < npx; ++k) {
+                    const int L = hls_lightness(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+                    w[k >> 2] |= (uint32_t)((L - 128) & 255) << ((k & 3) * 8);
+                }
+            }
+        } else {
+            const uint8_t* p = prow + src.x0 + xbeg;
+            for (int k = 0; k < npx; ++k) w[k >> 2] |= (uint32_t)(((int)p[k] - 128) & 255) << ((k & 3) * 8);
+        }
+    }
+    // fragment-order image of the row
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
+        *(u32x4m*)(tile + ((kb * 2 + h) * 32 + n) * 4) = v;
+    }
+    // inclusive prefix sums of L' along the row: 32 local sums, then a scan over the frame's 8 lanes
+    int loc[32];
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        run += (int)(int8_t)((w[k >> 2] >> ((k & 3) * 8)) & 255u);
+        loc[k] = run;
+    }
+    int off = run;  // inclusive scan of block totals over lanes with equal t >> 3
+#pragma unroll
+    for (int dlt = 1; dlt < 8; dlt <<= 1) {
+        const int o2 = __shfl_up(off, dlt, 8);
+        if (kb >= dlt) off += o2;
+    }
+    off -= run;  // exclusive
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) {
+        const uint32_t two = (uint32_t)((loc[k] + off) & 0xffff) | ((uint32_t)((loc[k + 1] + off) & 0xffff) << 16);
+        *(uint32_t*)&pre[n][kb * 32 + k] = two;
+    }
+    __syncthreads();
+    const int row_dwords = nkb * 256;
+    u32x4m* out = (u32x4m*)(Lg + ((size_t)grp * rows_pad + y) * (size_t)nkb * 1024);
+    for (int i = t; i < row_dwords / 4; i += 256) out[i] = *(const u32x4m*)(tile + i * 4);
+    // window sums: R[x] = P[x + tw - 1] - P[x - 1] + 128 tw   (P = inclusive prefix of L - 128)
+    if (y < src.rows) {
+        uint16_t* ro = R + (((size_t)grp * src.rows + y) * 64) * 32;
+        const int bias = tw * 128;
+        for (int e = t; e < 64 * 32; e += 256) {
+            const int x = e >> 5, nn = e & 31;
+            const int hi = (int)pre[nn][x + tw - 1], lo = x > 0 ? (int)pre[nn][x - 1] : 0;
+            ro[e] = (uint16_t)(hi - lo + bias);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_colsum: ws[g][y][x][n] = sum_{i < th} R[g][y + i][x][n]  (u32), exact.
+// One workgroup (128 threads) per 128 (x, n) columns of a group: the 128 x `rows` tile of R is
+// fetched with coalesced, deeply pipelined loads into LDS, then every thread slides down its
+// own column.  grid = (16, groups).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_colsum(const uint16_t* __restrict__ R, int rows, int th, int rh,
+                                                uint32_t* __restrict__ ws)
+{
+    extern __shared__ uint16_t col[];  // [rows][128]
+    const int t = threadIdx.x, grp = blockIdx.y, c0 = blockIdx.x * 128;
+    const uint16_t* r = R + (size_t)grp * rows * 2048 + c0 + t;
+    for (int y = 0; y < rows; ++y) col[y * 128 + t] = r[(size_t)y * 2048];
+    __syncthreads();
+    uint32_t* o = ws + (size_t)grp * rh * 2048 + c0 + t;
+    uint32_t s = 0;
+    for (int y = 0; y < th - 1; ++y) s += col[y * 128 + t];
+    for (int y = 0; y < rh; ++y) {
+        s += col[(y + th - 1) * 128 + t];
+        o[(size_t)y * 2048] = s;
+        s -= col[y * 128 + t];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_match_mfma
+// ---------------------------------------------------------------------------
+struct MfmaGeom {
+    int rh, rw;          // correlation map size
+    int rows_pad;        // rows per group in Lg
+    int th_pad;          // template rows padded to a multiple of 6 (zero rows)
+    int nframes;
+    int nparts;          // row blocks per frame = partials per frame
+    int k1;              // 128 * (sum T - 128 * th * tw)
+    double tmean;
+};
+
+__device__ inline bool better_m(float v, int i, float bv, int bi)
+{
+    return i != INT_MAX && (bi == INT_MAX || v > bv || (v == bv && i < bi));
+}
+
+template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */>
+__global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
+                                                      const uint32_t* __restrict__ ws, MfmaGeom g,
+                                                      float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+{
+    constexpr int NKB = ND + NXB - 1;
+    constexpr int NBUF = R + PD;   // image-row register buffers: R live + PD in flight
+    constexpr int NA = PD + 1;     // template-fragment sets: 1 live + PD in flight
+    const int lane = threadIdx.x;
+    // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so
+    // ids with equal (id % 8) share an L2.  Give each XCD whole frame groups (they share Lg rows).
+    const int nblk = gridDim.x;
+    const int id = blockIdx.x;
+    const int per = nblk / 8, rem = nblk % 8, xcd = id & 7, sub = id >> 3;
+    const int vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + sub;
+    const int grp = vid / g.nparts, rblk = vid - grp * g.nparts;
+    const int y0 = rblk * R;
+
+    const i32x4* Lrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + y0) * (size_t)NKB * 1024) + lane;
+    const i32x4* Ap = (const i32x4*)Atab + lane;
+    constexpr int ROWV = NKB * 64;  // i32x4 per image row
+
+    i32x16 acc[R][NXB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][xb][e] = 0;
+
+    // prologue: image rows y0 .. y0+R+PD-2 and template rows 0 .. PD-1
+    i32x4 buf[NBUF][NKB];
+#pragma unroll
+    for (int r = 0; r < NBUF - 1; ++r)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) buf[r][kb] = Lrow[r * ROWV + kb * 64];
+    i32x4 a[NA][ND];
+#pragma unroll
+    for (int q = 0; q < NA - 1; ++q)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) a[q][d] = Ap[((size_t)q * ND + d) * 64];
+
+    // Both rotations have period lcm(NBUF, NA); the loop body covers one period and th_pad is a
+    // multiple of it (the template table is zero-padded), so every register index is a constant.
+    constexpr int PERIOD = NBUF * NA / (NBUF % NA == 0 ? NA : (NA % 2 == 0 && NBUF % 2 == 0 ? 2 : 1));
+    for (int i0 = 0; i0 < g.th_pad; i0 += PERIOD) {
+#pragma unroll
+        for (int s = 0; s < PERIOD; ++s) {
+            const int i = i0 + s;
+            // image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+                buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
+            // template fragments of step i + PD (the table carries PD extra all-zero rows)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
+            // Pin the schedule: the loads above stay in flight while the MFMAs below run on operands
+            // fetched PD steps earlier.  Without the fences hipcc sinks each load next to its first
+            // use and waits vmcnt(0) every ten MFMAs (measured: 26 % MFMA utilisation).
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int xb = 0; xb < NXB; ++xb)
+                        acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
+                                                                           acc[r][xb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: exact u8 correlation, OpenCV's float post-pass, first-max reduction ----
+    const int n = lane & 31, hh = lane >> 5;
+    const int f = grp * 32 + n;
+    float bestv = 0.f;
+    int besti = INT_MAX;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int y = y0 + r;
+        if (y >= g.rh) continue;
+#pragma unroll
+        for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (x >= g.rw || f >= g.nframes) continue;
+                const uint32_t wsv = ws[(((size_t)grp * g.rh + y) * 64 + x) * 32 + n];
+                const int64_t cc = (int64_t)acc[r][xb][e] + (int64_t)128 * wsv + g.k1;
+                double num = (double)cc;
+                num -= (double)wsv * g.tmean;
+                const float v = (float)num;
+                const int idx = y * g.rw + x;
+                if (result_map) result_map[(size_t)f * g.rh * g.rw + idx] = v;
+                if (better_m(v, idx, bestv, besti)) { bestv = v; besti = idx; }
+            }
+    }
+    {
+        const float ov = __shfl_xor(bestv, 32, 64);
+        const int oi = __shfl_xor(besti, 32, 64);
+        if (better_m(ov, oi, bestv, besti)) { bestv = ov; besti = oi; }
+    }
+    if (lane < 32 && f < g.nframes) {
+        MatchPartial p;
+        p.val = bestv;
+        p.idx = besti;
+        partials[(size_t)f * g.nparts + rblk] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+constexpr int MM_ND = 7, MM_R = 5, MM_PD = 1;
+constexpr int MM_NBUF = MM_R + MM_PD, MM_NA = MM_PD + 1;
+constexpr int MM_PERIOD = MM_NBUF * MM_NA / (MM_NBUF % MM_NA == 0 ? MM_NA : (MM_NA % 2 == 0 && MM_NBUF % 2 == 0 ? 2 : 1));
+static int mm_th_pad(int th) { return (th + MM_PERIOD - 1) / MM_PERIOD * MM_PERIOD; }
+
+bool mfma_match_ok(int th, int tw, int rows, int cols)
+{
+    const int rh = rows - th + 1, rw = cols - tw + 1;
+    const int nd = (tw + 31 + 31) / 32;  // Toeplitz blocks per template row
+    return rh >= 1 && rw >= 1 && rw <= 64 && nd == MM_ND && cols <= 32 * (MM_ND + (rw > 32 ? 2 : 1) - 1);
+}
+
+MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
+{
+    MfmaPlan p;
+    p.rh = rows - th + 1;
+    p.rw = cols - tw + 1;
+    p.nxb = p.rw > 32 ? 2 : 1;
+    p.nkb = MM_ND + p.nxb - 1;
+    p.th_pad = mm_th_pad(th);
+    p.nparts = (p.rh + MM_R - 1) / MM_R;
+    p.rows_pad = p.nparts * MM_R + p.th_pad + MM_PD;   // last row touched: y0 + (th_pad - 1) + R + PD - 1 (prefetched, unused)
+    p.groups = (nframes + 31) / 32;
+    p.lg_bytes = (size_t)p.groups * p.rows_pad * p.nkb * 1024;
+    p.r_bytes = (size_t)p.groups * rows * 64 * 32 * sizeof(uint16_t);
+    p.ws_bytes = (size_t)p.groups * p.rh * 64 * 32 * sizeof(uint32_t);
+    return p;
+}
+
+size_t mfma_atab_bytes(int th)
+{
+    return (size_t)(mm_th_pad(th) + MM_PD) * MM_ND * 1024;
+}
+
+// Atab[i][d][lane][j] = T'[i][32 d + 16 (lane >> 5) + j - (lane & 31)], zero outside the template
+void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab)
+{
+    const int th_pad = mm_th_pad(th);
+    for (int i = 0; i < th_pad + MM_PD; ++i)
+        for (int d = 0; d < MM_ND; ++d)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 16; ++j) {
+                    const int col = 32 * d + 16 * (l >> 5) + j - (l & 31);
+                    int8_t v = 0;
+                    if (i < th && col >= 0 && col < tw) v = (int8_t)((int)templ[(size_t)i * tw + col] - 128);
+                    atab[(((size_t)i * MM_ND + d) * 64 + l) * 16 + j] = v;
+                }
+}
+
+void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
+                      uint16_t* d_r, uint32_t* d_ws, hipStream_t stream)
+{
+    dim3 grid(p.rows_pad, p.groups), block(256);
+    if (from_bgr) hipLaunchKernelGGL(k_prep_lplane<true>, grid, block, 0, stream, src, n, p.nkb, p.rows_pad, tw, d_lg, d_r);
+    else hipLaunchKernelGGL(k_prep_lplane<false>, grid, block, 0, stream, src, n, p.nkb, p.rows_pad, tw, d_lg, d_r);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_colsum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_colsum, dim3(16, p.groups), dim3(128), (size_t)src.rows * 128 * sizeof(uint16_t), stream, d_r,
+                       src.rows, th, p.rh, d_ws);
+}
+
+void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
+                       const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
+                       hipStream_t stream)
+{
+    MfmaGeom g;
+    g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
+    g.k1 = (int)(128 * (tsum - 128L * th * tw));
+    g.tmean = tmean;
+    dim3 grid(p.nparts * p.groups), block(64);
+    if (p.nxb == 2)
+        hipLaunchKernelGGL((k_match_mfma<MM_ND, 2, MM_R, MM_PD>), grid, block, 0, stream, d_lg, d_atab, d_ws, g, d_result_map, d_partials);
+    else
+        hipLaunchKernelGGL((k_match_mfma<MM_ND, 1, MM_R, MM_PD>), grid, block, 0, stream, d_lg, d_atab, d_ws, g, d_result_map, d_partials);
+}
+
+}  // namespace melf

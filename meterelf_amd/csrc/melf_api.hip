@@ -212,6 +212,12 @@ struct melf_ctx {
     uint32_t* d_tplT = nullptr;
     DialGeom* d_geom = nullptr;
     uint64_t* d_rowmasks = nullptr;
+    int8_t* d_atab = nullptr;            // Toeplitz template fragments of the MFMA match (NULL: template shape unsupported)
+    long tsum = 0;
+    bool use_mfma = true;                // MELF_MATCH=dot4 forces the VALU kernel
+    int8_t* d_lg = nullptr; size_t lg_cap = 0;
+    uint16_t* d_rsum = nullptr; size_t rsum_cap = 0;
+    uint32_t* d_wsum = nullptr; size_t wsum_cap = 0;
     uint32_t* d_fused_tables = nullptr;  // K1b lookup tables (built on the GPU at creation)
     int fused_ambiguous = 0;             // hue-table entries whose answer depends on float32 rounding of the triple
     int fused_active_sectors = 0;        // bit c: hue sector c (max = r/g/b) has in-range entries
@@ -285,6 +291,14 @@ static int setup_device_tables(melf_ctx* c)
     long tsum = 0;
     for (size_t i = 0; i < (size_t)th * tw; ++i) tsum += c->h_templ[i];
     g.tmean = (double)tsum * (1.0 / ((double)th * tw));
+    c->tsum = tsum;
+    if ((tw + 62) / 32 == 7) {  // the MFMA kernel is instantiated for 7 Toeplitz blocks per template row (tw 162..193)
+        std::vector<int8_t> atab(mfma_atab_bytes(th));
+        mfma_build_atab(c->h_templ.data(), th, tw, atab.data());
+        HIP_TRY(hipMalloc((void**)&c->d_atab, atab.size()));
+        HIP_TRY(hipMemcpy(c->d_atab, atab.data(), atab.size(), hipMemcpyHostToDevice));
+    }
+    if (const char* e = getenv("MELF_MATCH")) c->use_mfma = strcmp(e, "dot4") != 0;
     std::vector<uint32_t> tplT((size_t)g.tw4 * g.trows, 0u);
     for (int i = 0; i < th; ++i)
         for (int jj = 0; jj < g.tw4; ++jj) {
@@ -403,6 +417,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
+    hipFree(c->d_atab); hipFree(c->d_lg); hipFree(c->d_rsum); hipFree(c->d_wsum);
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -480,7 +495,7 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
     const int crows = y1 - y0, ccols = x1 - x0;
     if (x0 < 0 || y0 < 0 || crows < P.th || ccols < P.tw)
         return fail(MELF_ERR_INVALID, "meter_rect crop is smaller than the dials template (cv2.matchTemplate would assert)");
-    const int nparts = match_parts(c->mg, crows, ccols);
+    const bool mfma = c->use_mfma && c->d_atab && mfma_match_ok(P.th, P.tw, crows, ccols);
     const int rw = ccols - P.tw + 1;
     melf_result* res_dev = (melf_result*)d_results;
     if (!res_dev) {
@@ -489,12 +504,30 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
     }
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
         const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
-        if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
         const uint8_t* base = (const uint8_t*)d_frames + (size_t)f0 * frame_stride;
         MatchSrc ms;
         ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = W * 3;
         ms.x0 = x0; ms.y0 = y0; ms.rows = crows; ms.cols = ccols;
-        {
+        int nparts = 0;
+        if (mfma) {
+            const MfmaPlan pl = mfma_plan(P.th, P.tw, crows, ccols, m);
+            nparts = pl.nparts;
+            if (int rc = grow(&c->d_lg, &c->lg_cap, pl.lg_bytes)) return rc;
+            if (int rc = grow(&c->d_rsum, &c->rsum_cap, pl.r_bytes / sizeof(uint16_t))) return rc;
+            if (int rc = grow(&c->d_wsum, &c->wsum_cap, pl.ws_bytes / sizeof(uint32_t))) return rc;
+            if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
+            {
+                KernelTimer t(c, MELF_K_LPLANE, st);
+                launch_mfma_prep(ms, true, m, pl, P.th, P.tw, c->d_lg, c->d_rsum, c->d_wsum, st);
+            }
+            {
+                KernelTimer t(c, MELF_K_MATCH, st);
+                launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg, c->d_wsum, nullptr,
+                                  c->d_partials, st);
+            }
+        } else {
+            nparts = match_parts(c->mg, crows, ccols);
+            if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
             KernelTimer t(c, MELF_K_MATCH, st);
             launch_match(ms, true, m, c->mg, c->d_tplT, nullptr, c->d_partials, nullptr, st);
         }
@@ -597,7 +630,10 @@ extern "C" int melf_match_ccoeff(melf_ctx* c, const uint8_t* images_host, int n,
     const int rh = rows - c->P.th + 1, rw = cols - c->P.tw + 1;
     const size_t in_bytes = (size_t)n * rows * cols;
     const size_t map_bytes = result_map ? (size_t)n * rh * rw * sizeof(float) : 0;
-    const int nparts = match_parts(c->mg, rows, cols);
+    const bool mfma = c->use_mfma && c->d_atab && mfma_match_ok(c->P.th, c->P.tw, rows, cols);
+    MfmaPlan pl = {};
+    if (mfma) pl = mfma_plan(c->P.th, c->P.tw, rows, cols, n);
+    const int nparts = mfma ? pl.nparts : match_parts(c->mg, rows, cols);
     if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, in_bytes)) return rc;
     if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, map_bytes + 16)) return rc;
     if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)n * nparts)) return rc;
@@ -605,7 +641,18 @@ extern "C" int melf_match_ccoeff(melf_ctx* c, const uint8_t* images_host, int n,
     MatchSrc ms;
     ms.base = c->d_stage_in; ms.frame_stride = (size_t)rows * cols; ms.row_stride = cols;
     ms.x0 = 0; ms.y0 = 0; ms.rows = rows; ms.cols = cols;
-    {
+    if (mfma) {
+        if (int rc = grow(&c->d_lg, &c->lg_cap, pl.lg_bytes)) return rc;
+        if (int rc = grow(&c->d_rsum, &c->rsum_cap, pl.r_bytes / sizeof(uint16_t))) return rc;
+        if (int rc = grow(&c->d_wsum, &c->wsum_cap, pl.ws_bytes / sizeof(uint32_t))) return rc;
+        {
+            KernelTimer t(c, MELF_K_LPLANE, c->stream);
+            launch_mfma_prep(ms, false, n, pl, c->P.th, c->P.tw, c->d_lg, c->d_rsum, c->d_wsum, c->stream);
+        }
+        KernelTimer t(c, MELF_K_MATCH, c->stream);
+        launch_mfma_match(n, pl, c->P.th, c->P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg, c->d_wsum,
+                          result_map ? (float*)c->d_stage_out : nullptr, c->d_partials, c->stream);
+    } else {
         KernelTimer t(c, MELF_K_MATCH, c->stream);
         launch_match(ms, false, n, c->mg, c->d_tplT, result_map ? (float*)c->d_stage_out : nullptr, c->d_partials,
                      nullptr, c->stream);

@@ -42,6 +42,21 @@ void launch_match(const MatchSrc& src, bool from_bgr, int n, const MatchGeom& g,
                   float* d_result_map, MatchPartial* d_partials, int* nparts_out, hipStream_t stream);
 int match_parts(const MatchGeom& g, int rows, int cols);
 
+// ---- K2 on the matrix cores (k_match_mfma.hip) --------------------------------
+struct MfmaPlan {
+    int rh, rw, nxb, nkb, th_pad, nparts, rows_pad, groups;
+    size_t lg_bytes, r_bytes, ws_bytes;
+};
+bool mfma_match_ok(int th, int tw, int rows, int cols);
+MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes);
+size_t mfma_atab_bytes(int th);
+void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab);
+void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
+                      uint16_t* d_r, uint32_t* d_ws, hipStream_t stream);
+void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
+                       const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
+                       hipStream_t stream);
+
 // ---- K3: per-dial reading ---------------------------------------------------
 struct DialGeom {
     int32_t wx0, wy0;    // window origin in dials-crop coordinates

@@ -371,6 +371,49 @@ def test_full_path_records_match_oracle(env, sd):
         _compare_records([recs[i]], [o], tag=os.path.basename(e['files'][i]))
 
 
+@pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])
+def test_match_paths_agree_dot4_vs_mfma(env, sd, monkeypatch):
+    """The VALU (v_dot4) kernel and the MFMA kernel are two formulations of the same exact
+    integer correlation: identical float32 maps, and both identical to the oracle."""
+    from meterelf_amd import MeterReader
+    from oracle import pyoracle as po
+    e = env[sd]
+    op = e['oparams']
+    tpl = op.load_template()
+    rng = np.random.default_rng(21)
+    (rows, cols) = (250, 250) if sd == 'sample-images1' else (135, 220)
+    imgs = rng.integers(0, 256, size=(35, rows, cols), dtype=np.uint8)   # 35 frames: a full and a ragged group of 32
+    imgs[3] = 255
+    imgs[4] = 0
+    (_mv, _mx, _my, map_mfma) = e['reader'].ctx.match_ccoeff(imgs, want_map=True)
+    monkeypatch.setenv('MELF_MATCH', 'dot4')
+    r2 = MeterReader(e['params'])
+    try:
+        (mv2, mx2, my2, map_dot4) = r2.ctx.match_ccoeff(imgs, want_map=True)
+    finally:
+        r2.close()
+    assert np.array_equal(map_mfma, map_dot4)
+    for i in (0, 3, 4, 34):
+        (ev, ex, ey, emap) = po.match_ccoeff(imgs[i], tpl, want_map=True)
+        assert np.array_equal(map_dot4[i], emap)
+        assert (float(mv2[i]), int(mx2[i]), int(my2[i])) == (ev, ex, ey)
+
+
+@pytest.mark.parametrize('sd,seed', [('sample-images1', 7), ('sample-images2', 8)])
+def test_full_path_dot4_kernel(env, sd, seed, monkeypatch):
+    """Whole path with the VALU match kernel forced (the default is the MFMA kernel)."""
+    from meterelf_amd import MeterReader
+    from oracle import pyoracle as po
+    e = env[sd]
+    monkeypatch.setenv('MELF_MATCH', 'dot4')
+    reader = MeterReader(e['params'])
+    try:
+        frames = synth_frames(_good(e['files']), 12, seed)
+        _compare_records(reader.read_frames(frames), po.process_frames(frames, e['oparams']), tag=sd)
+    finally:
+        reader.close()
+
+
 def synth_frames(files, n, seed, shift=8, sigma=2.0):
     """BASELINE config 3/4 synthesis: fixture (i mod K)
     circularly shifted by (dx, dy) in [-shift, shift]^2 plus N(0, sigma^2) noise."""
