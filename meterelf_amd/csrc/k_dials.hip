@@ -202,19 +202,40 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
     const int lol = max(cl - D.range_l, 0), hil = min(cl + D.range_l, 255);
     const int los = max(cs - D.range_s, 0), his = min(cs + D.range_s, 255);
 
-    // inRange over the window (get_mask_by_color, _utils.py:113-119): row masks via ballot
+    // inRange over the window (get_mask_by_color, _utils.py:113-119): row masks via ballot.
+    // Phase 1 requests every window pixel of this lane's column (lane = column, one packed VGPR per
+    // window row) so that all the loads are in flight together; phase 2 converts and tests.
+    const int Xl = wx0 + lane;
+    const bool colvalid = lane < ws && Xl >= 0 && Xl < P.tw;
+    const bool tail = !FROM_HLS && hls_scalar_tail(mx + Xl, src.crop_cols);
     uint64_t m0 = 0, V = 0;
-    for (int y = 0; y < ws; ++y) {
-        const int X = wx0 + lane, Y = wy0 + y;
-        const bool valid = lane < ws && X >= 0 && X < P.tw && Y >= 0 && Y < P.th;
-        bool in = false;
-        if (valid) {
-            int H, L, S;
-            fetch(X, Y, H, L, S);
-            in = H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his;
+    for (int yc = 0; yc < ws; yc += 16) {
+        uint32_t pxv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int Y = wy0 + yc + k;
+            pxv[k] = 0;
+            if (yc + k < ws && colvalid && Y >= 0 && Y < P.th) {
+                const uint8_t* p = FROM_HLS ? frame + ((size_t)Y * P.tw + Xl) * 3
+                                            : frame + (size_t)(src.y0 + my + Y) * src.row_stride + (size_t)(src.x0 + mx + Xl) * 3;
+                pxv[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+            }
         }
-        const uint64_t b = __ballot(in), vb = __ballot(valid);
-        if (lane == y) { m0 = b; V = vb; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int y = yc + k, Y = wy0 + y;
+            const bool valid = y < ws && colvalid && Y >= 0 && Y < P.th;
+            bool in = false;
+            if (valid) {
+                int H, L, S;
+                const uint32_t px = pxv[k];
+                if (FROM_HLS) { H = px & 255; L = (px >> 8) & 255; S = (px >> 16) & 255; }
+                else hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, tail, P.hue_shift, H, L, S);
+                in = H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his;
+            }
+            const uint64_t b = __ballot(in), vb = __ballot(valid);
+            if (lane == y) { m0 = b; V = vb; }
+        }
     }
 
     // dilate then erode, 3x3, pixels outside the dials crop never win (_reading.py:128-130)

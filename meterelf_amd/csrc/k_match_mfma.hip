@@ -208,45 +208,57 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][xb][e] = 0;
 
-    // prologue: image rows y0 .. y0+R+PD-2 and template rows 0 .. PD-1
-    i32x4 buf[NBUF][NKB];
-#pragma unroll
-    for (int r = 0; r < NBUF - 1; ++r)
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) buf[r][kb] = Lrow[r * ROWV + kb * 64];
-    i32x4 a[NA][ND];
-#pragma unroll
-    for (int q = 0; q < NA - 1; ++q)
-#pragma unroll
-        for (int d = 0; d < ND; ++d) a[q][d] = Ap[((size_t)q * ND + d) * 64];
-
-    // Both rotations have period lcm(NBUF, NA); the loop body covers one period and th_pad is a
-    // multiple of it (the template table is zero-padded), so every register index is a constant.
+    // Both register rotations have period lcm(NBUF, NA); the loop body covers one period, so every
+    // register index is a constant.  th_pad is a multiple of the period (zero template rows).
     constexpr int PERIOD = NBUF * NA / (NBUF % NA == 0 ? NA : (NA % 2 == 0 && NBUF % 2 == 0 ? 2 : 1));
-    for (int i0 = 0; i0 < g.th_pad; i0 += PERIOD) {
+    // The sum over template rows may run in any order: every wave walks the rows cyclically from
+    // its own start so that, at any moment, all row blocks of a frame group are reading (nearly) the
+    // same image rows -- one L2 miss serves the whole group instead of every wave streaming its own
+    // 1 MiB through L2 at a different offset.  Block rblk is PERIOD template rows "late" per block
+    // while its output rows are only R lower, so neighbouring blocks are PERIOD - R image rows apart.
+    const int istart = (g.th_pad - (rblk * PERIOD) % g.th_pad) % g.th_pad;
+    i32x4 buf[NBUF][NKB];
+    i32x4 a[NA][ND];
+    for (int phase = 0; phase < 2; ++phase) {
+        const int ibeg = phase == 0 ? istart : 0, iend = phase == 0 ? g.th_pad : istart;
+        if (ibeg >= iend) continue;
+        // (re-)prime: image rows y0+ibeg .. y0+ibeg+R+PD-2 and template rows ibeg .. ibeg+PD-1
 #pragma unroll
-        for (int s = 0; s < PERIOD; ++s) {
-            const int i = i0 + s;
-            // image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD
+        for (int r = 0; r < NBUF - 1; ++r)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
-                buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
-            // template fragments of step i + PD (the table carries PD extra all-zero rows)
+                buf[r][kb] = Lrow[(size_t)(ibeg + r) * ROWV + kb * 64];
 #pragma unroll
-            for (int d = 0; d < ND; ++d) a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
-            // Pin the schedule: the loads above stay in flight while the MFMAs below run on operands
-            // fetched PD steps earlier.  Without the fences hipcc sinks each load next to its first
-            // use and waits vmcnt(0) every ten MFMAs (measured: 26 % MFMA utilisation).
-            __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < NA - 1; ++q)
 #pragma unroll
-            for (int d = 0; d < ND; ++d)
+            for (int d = 0; d < ND; ++d) a[q][d] = Ap[((size_t)(ibeg + q) * ND + d) * 64];
+        for (int i0 = ibeg; i0 < iend; i0 += PERIOD) {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+            for (int s = 0; s < PERIOD; ++s) {
+                const int i = i0 + s;
+                // Loads for later steps are spread over this step's MFMA sub-blocks (one image-row
+                // fragment and one template fragment per ten MFMAs) and pinned there with
+                // sched_barrier: they stay in flight for a whole step while the matrix pipe never
+                // waits for a burst of load issue.  (Left to itself hipcc sinks each load next to its
+                // first use and waits vmcnt(0) every ten MFMAs: 26 % MFMA utilisation.)
 #pragma unroll
-                    for (int xb = 0; xb < NXB; ++xb)
-                        acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
-                                                                           acc[r][xb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int d = 0; d < ND; ++d) {
+                    // image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD
+#pragma unroll
+                    for (int kb = d; kb < (d == ND - 1 ? NKB : d + 1); ++kb)
+                        buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
+                    // template fragments of step i + PD (the table carries PD extra all-zero rows)
+                    a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int xb = 0; xb < NXB; ++xb)
+                            acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
+                                                                               acc[r][xb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
 
