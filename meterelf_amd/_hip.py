@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libmeterelf_hip.so')
+LIB_PATH = os.environ.get('MELF_LIB_PATH') or os.path.join(_PKG, 'libmeterelf_hip.so')  # override: A/B builds
 
 MAX_DIALS = 8
 ABI_VERSION = 1
