@@ -443,6 +443,67 @@ def test_full_path_synthetic_batch(env, sd, seed):
     assert sum(1 for o in ores if o.status == 0) >= 40
 
 
+def test_1080p_six_dials(env, tmp_path):
+    """BASELINE config 5 shape: 1920x1080 frames, meter_rect inside the frame, six dials.
+    The reference cannot compute `value` for != 4 dials (assert in _reading.py:166): the record
+    carries the six positions only.  Oracle parity on positions / match / statuses."""
+    import shutil
+    import yaml
+    from meterelf_amd import MeterReader, _params
+    from meterelf_amd._image import imread_bgr
+    from oracle import pyoracle as po
+    src = os.path.join(GOLDEN, 'sample-images1')
+    with open(os.path.join(src, 'params.yml')) as fp:
+        data = yaml.safe_load(fp)
+    data['meter_rect'] = {'top_left': [1210, 420], 'bottom_right': [1460, 670]}
+    extra = []
+    for (k, nd) in enumerate(data['needle_data'][:2]):
+        nd2 = dict(nd)
+        nd2['name'] = '1.%d' % k
+        nd2['center'] = [nd['center'][0] + 0.4, nd['center'][1] - 0.3]
+        extra.append(nd2)
+    data['needle_data'] = data['needle_data'] + extra
+    with open(tmp_path / 'params.yml', 'w') as fp:
+        yaml.safe_dump(data, fp)
+    shutil.copy(os.path.join(src, 'dials_gray.png'), tmp_path / 'dials_gray.png')
+    params = _params.load(str(tmp_path / 'params.yml'))
+    op = po.Params(str(tmp_path / 'params.yml'))
+    assert len(params.dial_names) == 6
+    rng = np.random.default_rng(1080)
+    files = _good(env['sample-images1']['files'])[:5]
+    frames = rng.integers(0, 256, size=(len(files), 1080, 1920, 3), dtype=np.uint8)
+    for (i, f) in enumerate(files):
+        crop = imread_bgr(f)[160:410, 50:300]
+        frames[i, 420:670, 1210:1460] = crop
+    reader = MeterReader(params)
+    try:
+        recs = reader.read_frames(frames)
+        ores = po.process_frames(frames, op)
+        for i in range(len(files)):
+            (r, o) = (recs[i], ores[i])
+            assert int(r['status']) == o.status == 0
+            assert (int(r['match_x']), int(r['match_y']), float(r['match_val'])) == (o.match_x, o.match_y, o.match_val)
+            assert np.allclose(r['pos'][:6], list(o.pos)[:6], rtol=0, atol=POS_TOL)
+        # the fused full-frame stage at 1080p
+        got = reader.ctx.hls_inrange_close(frames[:2])
+        p = reader.ctx.params
+        for f in range(2):
+            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi)))
+    finally:
+        reader.close()
+
+
+def test_large_and_ragged_batches(env):
+    """Batch sizes around the 32-frame MFMA group and a batch of 70 (two groups + 6)."""
+    from oracle import pyoracle as po
+    e = env['sample-images2']
+    frames = synth_frames(_good(e['files']), 70, 31)
+    ores = po.process_frames(frames, e['oparams'])
+    for n in (1, 31, 32, 33, 70):
+        recs = e['reader'].read_frames(frames[:n])
+        _compare_records(recs, [ores[i] for i in range(n)], tag='n=%d' % n)
+
+
 def test_edge_cases(env):
     from meterelf_amd import _hip
     e = env['sample-images1']

@@ -213,3 +213,21 @@ def test_debug_mode_reraises(monkeypatch):
     with pytest.raises(exceptions.DialsNotFoundError) as e:
         list(_api.get_meter_values(pfile, [f]))
     assert e.value.get_message() == 'Dials not found (match val = 0.0)'  # reference tests/test_meterelf.py:164-167
+
+
+def test_debug_mode_stdout_suffix(monkeypatch, capsys):
+    """reference tests/test_meterelf.py:170-188: in DEBUG mode the line carries repr(meter_values)."""
+    import json
+    from meterelf_amd import _debug
+    monkeypatch.setattr(_api, 'MeterReader', helpers.OracleReader)
+    monkeypatch.setattr(_debug, 'DEBUG', {'1'})
+    f = os.path.join(GOLDEN, 'sample-images1', '20180814215230-01-e136.jpg')
+    _main.main(['meterelf', os.path.join(GOLDEN, 'sample-images1', 'params.yml'), f])
+    out = capsys.readouterr()
+    basic = f + ': 253.623'
+    assert out.out.startswith(basic) and out.err == ''
+    data = json.loads(out.out[len(basic):].replace("'", '"').strip())
+    assert set(data) == {'0.0001', '0.001', '0.01', '0.1', 'value'}
+    assert abs(data['0.0001'] - 6.23) < 0.005 and abs(data['0.001'] - 3.3) < 0.05
+    assert abs(data['0.01'] - 5.1) < 0.05 and abs(data['0.1'] - 2.4) < 0.05
+    assert abs(data['value'] - 253.62306) < 0.000005
