@@ -161,6 +161,20 @@ int melf_match_ccoeff(melf_ctx* ctx, const uint8_t* images_host, int n, int rows
  * (meterelf/_reading.py:28-111, :118-182). */
 int melf_read_dials(melf_ctx* ctx, const uint8_t* dials_hls_host, int n, melf_result* out_host);
 
+/* ---- calibration stages (reference: meterelf/_calibration.py, offline) ------ */
+
+/* get_average_meter_image (meterelf/_calibration.py:60-63 with _image.py:34-44 and
+ * _utils.py:64-88): the meter_rect crop of every frame is translated so that its dial match
+ * (match_x[i], match_y[i]) lands at (align_x, align_y), the float64 running mean is taken in the
+ * reference's operation order and denormalised to u8.  out_crop: crop_rows x crop_cols x 3. */
+int melf_aligned_average(melf_ctx* ctx, const uint8_t* frames_host, int n, int H, int W, size_t frame_stride,
+                         const int32_t* match_x, const int32_t* match_y, int align_x, int align_y,
+                         uint8_t* out_crop_host);
+
+/* cv2.inRange on a packed 3-channel u8 image (get_mask_by_color, meterelf/_utils.py:113-119). */
+int melf_inrange(melf_ctx* ctx, const uint8_t* img_host, int rows, int cols, const int32_t lo[3],
+                 const int32_t hi[3], uint8_t* mask_host);
+
 /* ---- measurement ---------------------------------------------------------
  * With profiling on, every kernel launched by a *_dev entry point is bracketed
  * by hipEvents on its stream; melf_ctx_timings drains them (synchronising) and

@@ -62,7 +62,7 @@ EXPORTS = [
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
-    'melf_read_dials', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
+    'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
 ]
 
 _lib = None
@@ -100,6 +100,8 @@ def lib():
     L.melf_hls_inrange_close_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.melf_match_ccoeff.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.melf_read_dials.argtypes = [vp, vp, C.c_int, vp]
+    L.melf_aligned_average.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_int, vp]
+    L.melf_inrange.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.melf_ctx_fused_table_ties.argtypes = [vp, C.POINTER(C.c_int)]
     L.melf_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.melf_ctx_timings.argtypes = [vp, vp, vp]
@@ -241,6 +243,28 @@ class Context:
         p = self.params
         out = np.zeros((p.ndials, 2, p.th, p.tw), np.uint8)
         check(self._L.melf_ctx_get_masks(self._h, _ptr(out)))
+        return out
+
+    # --- calibration stages ---
+    def aligned_average(self, frames, match_x, match_y, align_x, align_y):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        (n, H, W, _) = frames.shape
+        p = self.params
+        (rows, cols) = (min(p.rect_y1, H) - min(p.rect_y0, H), min(p.rect_x1, W) - min(p.rect_x0, W))
+        mx = np.ascontiguousarray(match_x, dtype=np.int32)
+        my = np.ascontiguousarray(match_y, dtype=np.int32)
+        out = np.empty((rows, cols, 3), np.uint8)
+        check(self._L.melf_aligned_average(self._h, _ptr(frames), n, H, W, H * W * 3, _ptr(mx), _ptr(my),
+                                           int(align_x), int(align_y), _ptr(out)))
+        return out
+
+    def inrange(self, img, lo, hi):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        (rows, cols, _) = img.shape
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        out = np.empty((rows, cols), np.uint8)
+        check(self._L.melf_inrange(self._h, _ptr(img), rows, cols, _ptr(lo), _ptr(hi), _ptr(out)))
         return out
 
     def fused_table_ties(self):

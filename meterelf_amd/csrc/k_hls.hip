@@ -625,3 +625,66 @@ void launch_fused_mask(const uint8_t* d_frames, int n, int H, int W, int hue_shi
 }
 
 }  // namespace melf
+
+// ---------------------------------------------------------------------------
+// Calibration stage kernels (reference: meterelf/_calibration.py:60-84, _image.py:34-44,
+// _utils.py:64-88, 113-119).  Offline path: correctness first.
+// ---------------------------------------------------------------------------
+namespace melf {
+
+// get_average_meter_image: every frame's meter crop is translated so that its dial match lands
+// at (ax, ay) (cv2.warpAffine with an integer translation = exact shift, zero border), the
+// float64 running mean is updated in the reference's operation order
+//     p = p * ((k - 1) / k) + (img / 255.0) / k,  k = 2, 3, ...
+// and the result is denormalised with (p * 255.0 + 0.5).astype(uint8).
+__global__ __launch_bounds__(256) void k_aligned_average(const uint8_t* __restrict__ frames, int n, size_t frame_stride,
+                                                         int row_stride, int x0, int y0, int rows, int cols,
+                                                         const int32_t* __restrict__ mx, const int32_t* __restrict__ my,
+                                                         int ax, int ay, uint8_t* __restrict__ out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * cols * 3) return;
+    const int c = t % 3, x = (t / 3) % cols, y = t / (3 * cols);
+    double p = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int sx = x - (ax - mx[i]), sy = y - (ay - my[i]);
+        double v = 0.0;
+        if (sx >= 0 && sx < cols && sy >= 0 && sy < rows)
+            v = (double)frames[(size_t)i * frame_stride + (size_t)(y0 + sy) * row_stride + (size_t)(x0 + sx) * 3 + c];
+        const double nv = v / 255.0;
+        if (i == 0) {
+            p = nv;
+        } else {
+            const double k = (double)(i + 1);
+            p = p * ((double)i / k) + nv / k;
+        }
+    }
+    out[t] = (uint8_t)(int)(p * 255.0 + 0.5);
+}
+
+void launch_aligned_average(const uint8_t* d_frames, int n, size_t frame_stride, int row_stride, int x0, int y0, int rows,
+                            int cols, const int32_t* d_mx, const int32_t* d_my, int ax, int ay, uint8_t* d_out,
+                            hipStream_t stream)
+{
+    const int total = rows * cols * 3;
+    hipLaunchKernelGGL(k_aligned_average, dim3((total + 255) / 256), dim3(256), 0, stream, d_frames, n, frame_stride,
+                       row_stride, x0, y0, rows, cols, d_mx, d_my, ax, ay, d_out);
+}
+
+// cv2.inRange on a packed 3-channel u8 image (get_mask_by_color, meterelf/_utils.py:113-119)
+__global__ __launch_bounds__(256) void k_inrange3(const uint8_t* __restrict__ img, int npx, Bounds B, uint8_t* __restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx) return;
+    const uint8_t* v = img + (size_t)p * 3;
+    out[p] = (v[0] >= B.lo[0] && v[0] <= B.hi[0] && v[1] >= B.lo[1] && v[1] <= B.hi[1] && v[2] >= B.lo[2] && v[2] <= B.hi[2]) ? 255 : 0;
+}
+
+void launch_inrange3(const uint8_t* d_img, int npx, const int lo[3], const int hi[3], uint8_t* d_out, hipStream_t stream)
+{
+    Bounds B;
+    for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
+    hipLaunchKernelGGL(k_inrange3, dim3((npx + 255) / 256), dim3(256), 0, stream, d_img, npx, B, d_out);
+}
+
+}  // namespace melf

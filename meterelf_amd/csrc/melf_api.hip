@@ -699,3 +699,49 @@ extern "C" int melf_read_dials(melf_ctx* c, const uint8_t* dials_hls_host, int n
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MELF_SUCCESS;
 }
+
+// ------------------------------------------------------- calibration stages ----
+extern "C" int melf_aligned_average(melf_ctx* c, const uint8_t* frames_host, int n, int H, int W, size_t frame_stride,
+                                    const int32_t* match_x, const int32_t* match_y, int align_x, int align_y,
+                                    uint8_t* out_crop_host)
+{
+    if (!c || !frames_host || !match_x || !match_y || !out_crop_host || n < 1 || H <= 0 || W <= 0)
+        return fail(MELF_ERR_INVALID, "bad argument");
+    if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
+    HIP_TRY(hipSetDevice(c->device));
+    const melf_params& P = c->P;
+    const int x0 = P.rect_x0 < W ? P.rect_x0 : W, x1 = P.rect_x1 < W ? P.rect_x1 : W;
+    const int y0 = P.rect_y0 < H ? P.rect_y0 : H, y1 = P.rect_y1 < H ? P.rect_y1 : H;
+    const int rows = y1 - y0, cols = x1 - x0;
+    if (x0 < 0 || y0 < 0 || rows < 1 || cols < 1) return fail(MELF_ERR_INVALID, "empty meter_rect crop");
+    const size_t in_bytes = (size_t)n * frame_stride, out_bytes = (size_t)rows * cols * 3;
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, in_bytes)) return rc;
+    if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, out_bytes + (size_t)n * 8 + 64)) return rc;
+    int32_t* d_mx = (int32_t*)(c->d_stage_out + ((out_bytes + 15) & ~(size_t)15));
+    int32_t* d_my = d_mx + n;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_in, frames_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_mx, match_x, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_my, match_y, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    launch_aligned_average(c->d_stage_in, n, frame_stride, W * 3, x0, y0, rows, cols, d_mx, d_my, align_x, align_y,
+                           c->d_stage_out, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_crop_host, c->d_stage_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_inrange(melf_ctx* c, const uint8_t* img_host, int rows, int cols, const int32_t lo[3],
+                            const int32_t hi[3], uint8_t* mask_host)
+{
+    if (!c || !img_host || !lo || !hi || !mask_host || rows < 1 || cols < 1) return fail(MELF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)rows * cols;
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, npx * 3)) return rc;
+    if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, npx)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_in, img_host, npx * 3, hipMemcpyHostToDevice, c->stream));
+    launch_inrange3(c->d_stage_in, (int)npx, lo, hi, c->d_stage_out, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mask_host, c->d_stage_out, npx, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MELF_SUCCESS;
+}

@@ -92,4 +92,10 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
                            const int hi[3], const uint32_t* d_tables, int variant, uint8_t* d_masks,
                            hipStream_t stream);
 
+// ---- calibration stage kernels ------------------------------------------------
+void launch_aligned_average(const uint8_t* d_frames, int n, size_t frame_stride, int row_stride, int x0, int y0, int rows,
+                            int cols, const int32_t* d_mx, const int32_t* d_my, int ax, int ay, uint8_t* d_out,
+                            hipStream_t stream);
+void launch_inrange3(const uint8_t* d_img, int npx, const int lo[3], const int hi[3], uint8_t* d_out, hipStream_t stream);
+
 }  // namespace melf

@@ -377,8 +377,20 @@ typedef struct {
  * border starts at a 0->1 transition whose last marked border pixel on the row
  * (lnbd) is not a positively marked one; traced pixels are marked +2, or -2
  * when the border leaves them to the right.  Returns number of contours. */
+static int find_external_contours_pts(const uint8_t* bin, int rows, int cols, contour_rec* out, int max_out,
+                                      int32_t* pts, int max_pts, int32_t* counts);
+
 static int find_external_contours(const uint8_t* bin, int rows, int cols, contour_rec* out, int max_out)
 {
+    return find_external_contours_pts(bin, rows, cols, out, max_out, NULL, 0, NULL);
+}
+
+/* pts (optional): x,y pairs of every contour in discovery order, coordinates of the original
+ * image; counts[k] = number of points of contour k */
+static int find_external_contours_pts(const uint8_t* bin, int rows, int cols, contour_rec* out, int max_out,
+                                      int32_t* pts, int max_pts, int32_t* counts)
+{
+    int npts_total = 0;
     int W = cols + 2, Hh = rows + 2;
     int8_t* img = (int8_t*)calloc((size_t)W * Hh, 1);
     for (int y = 0; y < rows; ++y)
@@ -406,6 +418,7 @@ static int find_external_contours(const uint8_t* bin, int rows, int cols, contou
                 if (s == s_end) {
                     img[i0] = (int8_t)(2 | -128);
                     npts = 1;
+                    if (pts && npts_total < max_pts) { pts[2 * npts_total] = x - 1; pts[2 * npts_total + 1] = y - 1; ++npts_total; }
                 } else {
                     i3 = i0;
                     for (;;) {
@@ -423,6 +436,7 @@ static int find_external_contours(const uint8_t* bin, int rows, int cols, contou
                         if (npts > 0) a00 += (double)qx * py - (double)qy * px;
                         qx = px; qy = py;
                         ++npts;
+                        if (pts && npts_total < max_pts) { pts[2 * npts_total] = px - 1; pts[2 * npts_total + 1] = py - 1; ++npts_total; }
                         px += CDX[s]; py += CDY[s];
                         if (i4 == i0 && i3 == i1) break;
                         i3 = i4;
@@ -434,6 +448,7 @@ static int find_external_contours(const uint8_t* bin, int rows, int cols, contou
                 if (n < max_out) {
                     out[n].area = fabs(a00 * 0.5);
                     out[n].start = (y - 1) * cols + (x - 1);
+                    if (counts) counts[n] = (int32_t)npts;
                 }
                 ++n;
                 p = img[y * W + x];
@@ -495,6 +510,18 @@ static void fill_external_contour(const uint8_t* bin, int rows, int cols, int st
     free(outside);
     free(stack);
     free(comp);
+}
+
+/* cv2.findContours(img, RETR_EXTERNAL, CHAIN_APPROX_NONE): all contours with their points, in
+ * discovery (raster) order -- cv2 returns the list reversed.  Used by the calibration restatement
+ * (reference: meterelf/_calibration.py:47-48). */
+ORC_API int orc_external_contours(const uint8_t* bin, int rows, int cols, int32_t* pts, int max_pts,
+                                  int32_t* counts, int max_contours)
+{
+    contour_rec* recs = (contour_rec*)malloc(sizeof(contour_rec) * (size_t)(max_contours > 0 ? max_contours : 1));
+    int n = find_external_contours_pts(bin, rows, cols, recs, max_contours, pts, max_pts, counts);
+    free(recs);
+    return n;
 }
 
 /* exported for unit tests of the contour semantics */
