@@ -398,22 +398,38 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     constexpr int HDW = IV ? HI_ROWS * 32 : (AMB ? HUE2_DWORDS : (SINGLE ? HUES_DWORDS : HUE1_DWORDS));
     constexpr int LSDW = IV ? LSI_ROWS * 64 : LS_DWORDS;
     // tables in static LDS (their addresses fold into the ds_read offset field), rings in dynamic LDS
-    __shared__ uint32_t hue[HDW];
-    __shared__ uint32_t ls[LSDW];
+    __shared__ __attribute__((aligned(16))) uint32_t hue[HDW];
+    __shared__ __attribute__((aligned(16))) uint32_t ls[LSDW];
     extern __shared__ uint32_t ring[];
     const int wpr = (W + 31) >> 5;
     uint32_t* raw = ring;
     uint32_t* he = raw + NB * wpr;
     const int tid = threadIdx.x;
-    if (IV) {  // each row replicated so that lane L of a 32-lane group always reads bank L
-        for (int i = tid; i < HDW; i += THREADS) hue[i] = g_tables[OFF_HI + (VAR - 6) * HI_ROWS + (i >> 5)];
-        for (int i = tid; i < LSDW; i += THREADS) ls[i] = g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + (i >> 6)];
-    } else {
-        for (int i = tid; i < HDW; i += THREADS)
-            hue[i] = g_tables[(AMB ? 0 : (SINGLE ? OFF_HUES + (VAR % 3) * HUES_DWORDS : OFF_HUE1)) + i];
-        for (int i = tid; i < LSDW; i += THREADS) ls[i] = g_tables[OFF_LS + i];
-    }
-    for (int i = tid; i < 2 * NB * wpr; i += THREADS) raw[i] = 0;  // unused half-words must read as 0
+    // Table fill, run once per workgroup AFTER the first frame loads have been issued (see below).
+    auto fill_tables = [&]() {
+        if (IV) {
+            // each (lo, count) row replicated so that lane L of a 32-lane group always reads bank L:
+            // one global load per row, then 16-byte LDS stores
+            for (int r = tid; r < HI_ROWS; r += THREADS) {
+                const uint32_t v = g_tables[OFF_HI + (VAR - 6) * HI_ROWS + r];
+                const u32x4 v4 = {v, v, v, v};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *(u32x4*)(hue + r * 32 + q * 4) = v4;
+            }
+            for (int r = tid; r < LSI_ROWS; r += THREADS) {
+                const uint32_t v = g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + r];
+                const u32x4 v4 = {v, v, v, v};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) *(u32x4*)(ls + r * 64 + q * 4) = v4;
+            }
+        } else {
+            for (int i = tid; i < HDW; i += THREADS)
+                hue[i] = g_tables[(AMB ? 0 : (SINGLE ? OFF_HUES + (VAR % 3) * HUES_DWORDS : OFF_HUE1)) + i];
+            for (int i = tid; i < LSDW; i += THREADS) ls[i] = g_tables[OFF_LS + i];
+        }
+        for (int i = tid; i < 2 * NB * wpr; i += THREADS) raw[i] = 0;  // unused half-words must read as 0
+    };
+    bool tables_ready = false;
 
     const int G16 = W >> 4;
     const int RC = THREADS / G16;  // rows per pass
@@ -423,7 +439,6 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const int drow = tid / wpr, dk = tid - drow * wpr;  // word work item of step 2
     const uint32_t lastmask = (W & 31) ? ((1u << (W & 31)) - 1u) : 0xffffffffu;
     const int nbm = NB - 1;
-    __syncthreads();
 
     for (int seg = blockIdx.x; seg < n * segs_per_frame; seg += gridDim.x) {
         const int f = seg / segs_per_frame, sidx = seg - f * segs_per_frame;
@@ -515,6 +530,11 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
         if (PREFETCH) {
             Px16 pa, pb;
             load(a, pa);
+            if (!tables_ready) {  // the frame loads above are already in flight while LDS is filled
+                fill_tables();
+                tables_ready = true;
+                __syncthreads();
+            }
             for (;;) {
                 load(a + RC, pb);
                 pass(a, pa);
@@ -526,6 +546,11 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                 if (a >= aend) break;
             }
         } else {
+            if (!tables_ready) {
+                fill_tables();
+                tables_ready = true;
+                __syncthreads();
+            }
             const Px16 unused = {};
             for (; a < aend; a += RC) pass(a, unused);
         }

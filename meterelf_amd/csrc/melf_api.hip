@@ -215,9 +215,17 @@ struct melf_ctx {
     int8_t* d_atab = nullptr;            // Toeplitz template fragments of the MFMA match (NULL: template shape unsupported)
     long tsum = 0;
     bool use_mfma = true;                // MELF_MATCH=dot4 forces the VALU kernel
-    int8_t* d_lg = nullptr; size_t lg_cap = 0;
-    uint16_t* d_rsum = nullptr; size_t rsum_cap = 0;
-    uint32_t* d_wsum = nullptr; size_t wsum_cap = 0;
+    // two pipeline lanes: a batch is split in halves that run on separate streams, so that one
+    // half's VALU-bound kernels (prep, dials) overlap the other half's matrix-core-bound match
+    static const int NLANES = 2;
+    int lanes = 1;                       // MELF_LANES=2 enables the split (measured slower on MI355X: the two
+                                         // half-batch match kernels do not overlap usefully; kept for experiments)
+    hipStream_t lane_stream[NLANES] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {nullptr, nullptr};
+    int8_t* d_lg[NLANES] = {nullptr, nullptr}; size_t lg_cap[NLANES] = {0, 0};
+    uint16_t* d_rsum[NLANES] = {nullptr, nullptr}; size_t rsum_cap[NLANES] = {0, 0};
+    uint32_t* d_wsum[NLANES] = {nullptr, nullptr}; size_t wsum_cap[NLANES] = {0, 0};
+    MatchPartial* d_lpart[NLANES] = {nullptr, nullptr}; size_t lpart_cap[NLANES] = {0, 0};
     uint32_t* d_fused_tables = nullptr;  // K1b lookup tables (built on the GPU at creation)
     int fused_ambiguous = 0;             // hue-table entries whose answer depends on float32 rounding of the triple
     int fused_active_sectors = 0;        // bit c: hue sector c (max = r/g/b) has in-range entries
@@ -402,6 +410,13 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
     int rc = MELF_SUCCESS;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(MELF_ERR_HIP, "hipStreamCreate failed");
+    for (int l = 0; l < melf_ctx::NLANES && !rc; ++l)
+        if (hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join[l], hipEventDisableTiming) != hipSuccess)
+            rc = fail(MELF_ERR_HIP, "hipStreamCreate failed");
+    if (!rc && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess)
+        rc = fail(MELF_ERR_HIP, "hipEventCreate failed");
+    if (const char* e = getenv("MELF_LANES")) c->lanes = atoi(e) == 2 ? 2 : 1;
     if (!rc) rc = setup_device_tables(c);
     if (rc) {
         melf_ctx_destroy(c);
@@ -417,7 +432,13 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
-    hipFree(c->d_atab); hipFree(c->d_lg); hipFree(c->d_rsum); hipFree(c->d_wsum);
+    hipFree(c->d_atab);
+    for (int l = 0; l < melf_ctx::NLANES; ++l) {
+        hipFree(c->d_lg[l]); hipFree(c->d_rsum[l]); hipFree(c->d_wsum[l]); hipFree(c->d_lpart[l]);
+        if (c->lane_stream[l]) hipStreamDestroy(c->lane_stream[l]);
+        if (c->ev_join[l]) hipEventDestroy(c->ev_join[l]);
+    }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -502,43 +523,67 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
         if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
         res_dev = c->d_results;
     }
+    // work list: chunks of at most MAX_FRAMES_PER_LAUNCH frames, each split over the pipeline lanes
+    // at a multiple of 32 frames (the MFMA group size)
+    const bool split = mfma && c->lanes > 1 && n >= 128;
+    if (split) {
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        for (int l = 0; l < melf_ctx::NLANES; ++l) HIP_TRY(hipStreamWaitEvent(c->lane_stream[l], c->ev_fork, 0));
+    }
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
-        const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
-        const uint8_t* base = (const uint8_t*)d_frames + (size_t)f0 * frame_stride;
-        MatchSrc ms;
-        ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = W * 3;
-        ms.x0 = x0; ms.y0 = y0; ms.rows = crows; ms.cols = ccols;
-        int nparts = 0;
-        if (mfma) {
-            const MfmaPlan pl = mfma_plan(P.th, P.tw, crows, ccols, m);
-            nparts = pl.nparts;
-            if (int rc = grow(&c->d_lg, &c->lg_cap, pl.lg_bytes)) return rc;
-            if (int rc = grow(&c->d_rsum, &c->rsum_cap, pl.r_bytes / sizeof(uint16_t))) return rc;
-            if (int rc = grow(&c->d_wsum, &c->wsum_cap, pl.ws_bytes / sizeof(uint32_t))) return rc;
-            if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
-            {
-                KernelTimer t(c, MELF_K_LPLANE, st);
-                launch_mfma_prep(ms, true, m, pl, P.th, P.tw, c->d_lg, c->d_rsum, c->d_wsum, st);
+        const int mtot = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
+        const int nl = split ? melf_ctx::NLANES : 1;
+        const int per = split ? ((mtot / nl + 31) / 32) * 32 : mtot;
+        for (int l = 0; l < nl; ++l) {
+            const int g0 = f0 + l * per;
+            const int m = l == nl - 1 ? f0 + mtot - g0 : per;
+            if (m <= 0) continue;
+            hipStream_t ls = split ? c->lane_stream[l] : st;
+            const uint8_t* base = (const uint8_t*)d_frames + (size_t)g0 * frame_stride;
+            MatchSrc ms;
+            ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = W * 3;
+            ms.x0 = x0; ms.y0 = y0; ms.rows = crows; ms.cols = ccols;
+            int nparts = 0;
+            MatchPartial* parts = nullptr;
+            if (mfma) {
+                const MfmaPlan pl = mfma_plan(P.th, P.tw, crows, ccols, m);
+                nparts = pl.nparts;
+                if (int rc = grow(&c->d_lg[l], &c->lg_cap[l], pl.lg_bytes)) return rc;
+                if (int rc = grow(&c->d_rsum[l], &c->rsum_cap[l], pl.r_bytes / sizeof(uint16_t))) return rc;
+                if (int rc = grow(&c->d_wsum[l], &c->wsum_cap[l], pl.ws_bytes / sizeof(uint32_t))) return rc;
+                if (int rc = grow(&c->d_lpart[l], &c->lpart_cap[l], (size_t)m * nparts)) return rc;
+                parts = c->d_lpart[l];
+                {
+                    KernelTimer t(c, MELF_K_LPLANE, ls);
+                    launch_mfma_prep(ms, true, m, pl, P.th, P.tw, c->d_lg[l], c->d_rsum[l], c->d_wsum[l], ls);
+                }
+                {
+                    KernelTimer t(c, MELF_K_MATCH, ls);
+                    launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[l], c->d_wsum[l],
+                                      nullptr, parts, ls);
+                }
+            } else {
+                nparts = match_parts(c->mg, crows, ccols);
+                if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
+                parts = c->d_partials;
+                KernelTimer t(c, MELF_K_MATCH, ls);
+                launch_match(ms, true, m, c->mg, c->d_tplT, nullptr, parts, nullptr, ls);
             }
+            DialsSrc ds;
+            ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = W * 3;
+            ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
             {
-                KernelTimer t(c, MELF_K_MATCH, st);
-                launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg, c->d_wsum, nullptr,
-                                  c->d_partials, st);
+                KernelTimer t(c, MELF_K_DIALS, ls);
+                launch_dials(ds, false, m, P, c->d_geom, c->d_rowmasks, parts, nparts, rw, res_dev + g0, ls);
             }
-        } else {
-            nparts = match_parts(c->mg, crows, ccols);
-            if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
-            KernelTimer t(c, MELF_K_MATCH, st);
-            launch_match(ms, true, m, c->mg, c->d_tplT, nullptr, c->d_partials, nullptr, st);
+            HIP_TRY(hipGetLastError());
         }
-        DialsSrc ds;
-        ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = W * 3;
-        ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
-        {
-            KernelTimer t(c, MELF_K_DIALS, st);
-            launch_dials(ds, false, m, P, c->d_geom, c->d_rowmasks, c->d_partials, nparts, rw, res_dev + f0, st);
+    }
+    if (split) {
+        for (int l = 0; l < melf_ctx::NLANES; ++l) {
+            HIP_TRY(hipEventRecord(c->ev_join[l], c->lane_stream[l]));
+            HIP_TRY(hipStreamWaitEvent(st, c->ev_join[l], 0));
         }
-        HIP_TRY(hipGetLastError());
     }
     if (out_host) {
         HIP_TRY(hipMemcpyAsync(out_host, res_dev, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, st));
@@ -642,15 +687,15 @@ extern "C" int melf_match_ccoeff(melf_ctx* c, const uint8_t* images_host, int n,
     ms.base = c->d_stage_in; ms.frame_stride = (size_t)rows * cols; ms.row_stride = cols;
     ms.x0 = 0; ms.y0 = 0; ms.rows = rows; ms.cols = cols;
     if (mfma) {
-        if (int rc = grow(&c->d_lg, &c->lg_cap, pl.lg_bytes)) return rc;
-        if (int rc = grow(&c->d_rsum, &c->rsum_cap, pl.r_bytes / sizeof(uint16_t))) return rc;
-        if (int rc = grow(&c->d_wsum, &c->wsum_cap, pl.ws_bytes / sizeof(uint32_t))) return rc;
+        if (int rc = grow(&c->d_lg[0], &c->lg_cap[0], pl.lg_bytes)) return rc;
+        if (int rc = grow(&c->d_rsum[0], &c->rsum_cap[0], pl.r_bytes / sizeof(uint16_t))) return rc;
+        if (int rc = grow(&c->d_wsum[0], &c->wsum_cap[0], pl.ws_bytes / sizeof(uint32_t))) return rc;
         {
             KernelTimer t(c, MELF_K_LPLANE, c->stream);
-            launch_mfma_prep(ms, false, n, pl, c->P.th, c->P.tw, c->d_lg, c->d_rsum, c->d_wsum, c->stream);
+            launch_mfma_prep(ms, false, n, pl, c->P.th, c->P.tw, c->d_lg[0], c->d_rsum[0], c->d_wsum[0], c->stream);
         }
         KernelTimer t(c, MELF_K_MATCH, c->stream);
-        launch_mfma_match(n, pl, c->P.th, c->P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg, c->d_wsum,
+        launch_mfma_match(n, pl, c->P.th, c->P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[0], c->d_wsum[0],
                           result_map ? (float*)c->d_stage_out : nullptr, c->d_partials, c->stream);
     } else {
         KernelTimer t(c, MELF_K_MATCH, c->stream);
