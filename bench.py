@@ -80,7 +80,7 @@ def main():
 
     pfile = os.path.join(GOLDEN, args.sample_dir, 'params.yml')
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:   # launched by torch.distributed.run (also with one rank)
         from meterelf_amd import _dist
         dist = _dist.init_process_group('nccl')
         (blob, names) = (None, None)
