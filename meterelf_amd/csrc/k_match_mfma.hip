@@ -169,6 +169,8 @@ struct MfmaGeom {
     int th_pad;          // template rows padded to a multiple of 6 (zero rows)
     int nframes;
     int nparts;          // row blocks per frame = partials per frame
+    int na;              // balanced layout: blocks 0..na-1 own 4 full rows each, then pairs of 5-row blocks
+                         // that share their middle row (one 32-column block of it each); na < 0: uniform R rows
     int k1;              // 128 * (sum T - 128 * th * tw)
     double tmean;
 };
@@ -178,23 +180,22 @@ __device__ inline bool better_m(float v, int i, float bv, int bi)
     return i != INT_MAX && (bi == INT_MAX || v > bv || (v == bv && i < bi));
 }
 
-template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */>
-__global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
-                                                      const uint32_t* __restrict__ ws, MfmaGeom g,
-                                                      float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+// One wave's whole job.  MFIRST / MLAST: which 32-column blocks (bit xb) the first / last of the R
+// rows computes -- the balanced layout gives two neighbouring waves one column block each of a
+// shared row, so that every wave carries 8 or 9 half-row units instead of 10.
+template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST>
+__device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
+                                           const uint32_t* __restrict__ ws, const MfmaGeom& g,
+                                           float* __restrict__ result_map, MatchPartial* __restrict__ partials,
+                                           int grp, int rblk, int y0)
 {
+    auto on = [](int r, int xb) -> bool {
+        return r == 0 ? ((MFIRST >> xb) & 1) : (r == R - 1 ? ((MLAST >> xb) & 1) : true);
+    };
     constexpr int NKB = ND + NXB - 1;
     constexpr int NBUF = R + PD;   // image-row register buffers: R live + PD in flight
     constexpr int NA = PD + 1;     // template-fragment sets: 1 live + PD in flight
     const int lane = threadIdx.x;
-    // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so
-    // ids with equal (id % 8) share an L2.  Give each XCD whole frame groups (they share Lg rows).
-    const int nblk = gridDim.x;
-    const int id = blockIdx.x;
-    const int per = nblk / 8, rem = nblk % 8, xcd = id & 7, sub = id >> 3;
-    const int vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + sub;
-    const int grp = vid / g.nparts, rblk = vid - grp * g.nparts;
-    const int y0 = rblk * R;
 
     const i32x4* Lrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + y0) * (size_t)NKB * 1024) + lane;
     const i32x4* Ap = (const i32x4*)Atab + lane;
@@ -216,7 +217,9 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
     // same image rows -- one L2 miss serves the whole group instead of every wave streaming its own
     // 1 MiB through L2 at a different offset.  Block rblk is PERIOD template rows "late" per block
     // while its output rows are only R lower, so neighbouring blocks are PERIOD - R image rows apart.
-    const int istart = (g.th_pad - (rblk * PERIOD) % g.th_pad) % g.th_pad;
+    // start so that image row y0 + i is roughly the same for every block at any moment (rounded to the
+    // rotation period)
+    const int istart = (((g.th_pad - y0 % g.th_pad) % g.th_pad) / PERIOD) * PERIOD;
     i32x4 buf[NBUF][NKB];
     i32x4 a[NA][ND];
     for (int phase = 0; phase < 2; ++phase) {
@@ -254,8 +257,9 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
                     for (int r = 0; r < R; ++r)
 #pragma unroll
                         for (int xb = 0; xb < NXB; ++xb)
-                            acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
-                                                                               acc[r][xb], 0, 0, 0);
+                            if (on(r, xb))
+                                acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
+                                                                                   acc[r][xb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
         for (int xb = 0; xb < NXB; ++xb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (!on(r, xb)) continue;
                 const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 if (x >= g.rw || f >= g.nframes) continue;
                 const uint32_t wsv = ws[(((size_t)grp * g.rh + y) * 64 + x) * 32 + n];
@@ -300,13 +305,42 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
     }
 }
 
+
+template <int ND, int NXB, int R, int PD>
+__global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
+                                                      const uint32_t* __restrict__ ws, MfmaGeom g,
+                                                      float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+{
+    // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so
+    // ids with equal (id % 8) share an L2.  Give each XCD whole frame groups (they share Lg rows).
+    const int nblk = gridDim.x;
+    const int id = blockIdx.x;
+    const int per = nblk / 8, rem = nblk % 8, xcd = id & 7, sub = id >> 3;
+    const int vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + sub;
+    const int grp = vid / g.nparts, rblk = vid - grp * g.nparts;
+    if (NXB == 2 && g.na >= 0) {
+        // balanced layout: 8 or 9 half-row units per wave (see MfmaGeom::na)
+        if (rblk < g.na) {
+            match_wave<ND, 2, 4, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, 4 * rblk);
+        } else {
+            const int q = rblk - g.na, base = 4 * g.na + 9 * (q >> 1);
+            if ((q & 1) == 0) match_wave<ND, 2, 5, PD, 3, 1>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
+            else match_wave<ND, 2, 5, PD, 2, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + 4);
+        }
+    } else {
+        match_wave<ND, NXB, R, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * R);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 constexpr int MM_ND = 7, MM_R = 5, MM_PD = 1;
 constexpr int MM_NBUF = MM_R + MM_PD, MM_NA = MM_PD + 1;
 constexpr int MM_PERIOD = MM_NBUF * MM_NA / (MM_NBUF % MM_NA == 0 ? MM_NA : (MM_NA % 2 == 0 && MM_NBUF % 2 == 0 ? 2 : 1));
-static int mm_th_pad(int th) { return (th + MM_PERIOD - 1) / MM_PERIOD * MM_PERIOD; }
+// th_pad: multiple of every wave type's rotation period (R = 5: lcm(6, 2) = 6; R = 4: lcm(5, 2) = 10)
+static int mm_th_pad(int th) { return (th + 29) / 30 * 30; }
+static_assert(MM_PD == 1 && MM_R == 5 && 30 % MM_PERIOD == 0, "th_pad rule assumes PD = 1, R in {4, 5}");
 
 bool mfma_match_ok(int th, int tw, int rows, int cols)
 {
@@ -324,8 +358,26 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
     p.nkb = MM_ND + p.nxb - 1;
     p.th_pad = mm_th_pad(th);
     p.nparts = (p.rh + MM_R - 1) / MM_R;
-    p.rows_pad = p.nparts * MM_R + p.th_pad + MM_PD;   // last row touched: y0 + (th_pad - 1) + R + PD - 1 (prefetched, unused)
+    p.na = -1;
+    int rows_cov = p.nparts * MM_R;
     p.groups = (nframes + 31) / 32;
+    if (p.nxb == 2) {
+        // Balanced layout: na blocks of 4 full rows + np pairs of 5-row blocks sharing a row (9 rows per
+        // pair), 4 na + 9 np >= rh.  Take the fewest pairs for which all blocks of the batch run at once
+        // (one wave per SIMD, 1024 SIMDs); with none needed the uniform 4-row layout is already balanced.
+        const int simds = 1024;
+        int best_np = -1, best_na = 0;
+        for (int np = 0; 9 * np <= p.rh + 8; ++np) {
+            const int rest = p.rh - 9 * np;
+            const int na = rest > 0 ? (rest + 3) / 4 : 0;
+            if ((long)(na + 2 * np) * p.groups <= simds) { best_np = np; best_na = na; break; }
+        }
+        if (best_np < 0) { best_np = 0; best_na = (p.rh + 3) / 4; }  // more blocks than SIMDs anyway
+        p.na = best_na;
+        p.nparts = best_na + 2 * best_np;
+        rows_cov = 4 * best_na + 9 * best_np;
+    }
+    p.rows_pad = rows_cov + p.th_pad + MM_PD + 1;   // last row touched: y0 + (th_pad - 1) + R + PD - 1 (prefetched, unused)
     p.lg_bytes = (size_t)p.groups * p.rows_pad * p.nkb * 1024;
     p.r_bytes = (size_t)p.groups * rows * 64 * 32 * sizeof(uint16_t);
     p.ws_bytes = (size_t)p.groups * p.rh * 64 * 32 * sizeof(uint32_t);
@@ -373,6 +425,7 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
 {
     MfmaGeom g;
     g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
+    g.na = p.na;
     g.k1 = (int)(128 * (tsum - 128L * th * tw));
     g.tmean = tmean;
     dim3 grid(p.nparts * p.groups), block(64);
