@@ -170,7 +170,8 @@ struct MfmaGeom {
     int nframes;
     int nparts;          // row blocks per frame = partials per frame
     int na;              // balanced layout: blocks 0..na-1 own 4 full rows each, then pairs of 5-row blocks
-                         // that share their middle row (one 32-column block of it each); na < 0: uniform R rows
+                         // that share their middle row (one 32-column block of it each); na < 0: uniform rows
+    int ur;              // uniform layout: rows per wave (5 or 2)
     int k1;              // 128 * (sum T - 128 * th * tw)
     double tmean;
 };
@@ -327,6 +328,8 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
             if ((q & 1) == 0) match_wave<ND, 2, 5, PD, 3, 1>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
             else match_wave<ND, 2, 5, PD, 2, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + 4);
         }
+    } else if (g.ur == 2) {  // small maps: more, lighter waves
+        match_wave<ND, NXB, 2, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * 2);
     } else {
         match_wave<ND, NXB, R, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * R);
     }
@@ -377,6 +380,14 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
         p.nparts = best_na + 2 * best_np;
         rows_cov = 4 * best_na + 9 * best_np;
     }
+    p.ur = MM_R;
+    if ((long)p.nparts * p.groups * 2 <= 1024) {
+        // few waves (small correlation map or small batch): 2 rows per wave doubles the waves in flight
+        p.na = -1;
+        p.ur = 2;
+        p.nparts = (p.rh + 1) / 2;
+        rows_cov = p.nparts * 2;
+    }
     p.rows_pad = rows_cov + p.th_pad + MM_PD + 1;   // last row touched: y0 + (th_pad - 1) + R + PD - 1 (prefetched, unused)
     p.lg_bytes = (size_t)p.groups * p.rows_pad * p.nkb * 1024;
     p.r_bytes = (size_t)p.groups * rows * 64 * 32 * sizeof(uint16_t);
@@ -426,6 +437,7 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
     MfmaGeom g;
     g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
     g.na = p.na;
+    g.ur = p.ur;
     g.k1 = (int)(128 * (tsum - 128L * th * tw));
     g.tmean = tmean;
     dim3 grid(p.nparts * p.groups), block(64);

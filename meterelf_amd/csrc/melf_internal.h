@@ -44,7 +44,7 @@ int match_parts(const MatchGeom& g, int rows, int cols);
 
 // ---- K2 on the matrix cores (k_match_mfma.hip) --------------------------------
 struct MfmaPlan {
-    int rh, rw, nxb, nkb, th_pad, nparts, rows_pad, groups, na;
+    int rh, rw, nxb, nkb, th_pad, nparts, rows_pad, groups, na, ur;
     size_t lg_bytes, r_bytes, ws_bytes;
 };
 bool mfma_match_ok(int th, int tw, int rows, int cols);
