@@ -244,8 +244,9 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
     const uint64_t he = dil & ((dil << 1) | 1ull) & ((dil >> 1) | (1ull << 63));
     const uint64_t mde = he & row_up(he, lane, ~0ull) & row_down(he, lane, ~0ull) & V;
 
-    const uint64_t disk = rowmasks[((size_t)d * 2 + 0) * 64 + lane];
-    const uint64_t annulus = rowmasks[((size_t)d * 2 + 1) * 64 + lane];
+    const uint64_t disk = rowmasks[((size_t)d * 3 + 0) * 64 + lane];
+    const uint64_t annulus = rowmasks[((size_t)d * 3 + 1) * 64 + lane];
+    const uint64_t outside0 = rowmasks[((size_t)d * 3 + 2) * 64 + lane];  // truly outside the disk (no pockets)
     const uint64_t M = mde & disk;
 
     int status = 0;  // 0 ok, 1 no contours, 2 unreadable
@@ -253,9 +254,10 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
     if (__ballot(M != 0) == 0) {
         status = 1;  // NeedleContoursNotFoundError (_reading.py:137-138)
     } else {
-        // pixels of ~M that are 4-connected to the outside of the disk
+        // pixels of ~M that are 4-connected to the outside of the disk.  The seed is host-computed:
+        // unfilled pockets inside the reference's disk mask (thin rings) are not outside.
         const uint64_t freeb = ~M;
-        uint64_t o = ~disk;
+        uint64_t o = outside0;
         for (;;) {
             const uint64_t n = o | ((((o << 1) | (o >> 1)) | row_up(o, lane, ~0ull) | row_down(o, lane, ~0ull)) & freeb);
             const bool ch2 = n != o;
@@ -290,9 +292,10 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
             if (area2 > best2) { best2 = area2; bestF = s; }
             rem &= ~s;
         }
-        // contourArea > 100: filled contour, else the whole closed mask (_reading.py:141-148);
-        // both are used only through `& dial.mask` / `& dial.circle_mask`.
-        const uint64_t N = best2 > 200 ? bestF : M;
+        // contourArea > 100: filled contour, else the whole closed mask (_reading.py:141-148); both are
+        // used only through `& dial.mask` / `& dial.circle_mask` (:150, :51) -- the filled contour can
+        // cover pocket pixels that the disk mask lacks.
+        const uint64_t N = (best2 > 200 ? bestF : M) & disk;
         const uint64_t outer = N & annulus;
 
         // momentum vector (_reading.py:32-41)

@@ -322,7 +322,10 @@ static int setup_device_tables(melf_ctx* c)
 
     // --- K3 windows and row bit masks ---
     std::vector<DialGeom> geom(P.ndials);
-    std::vector<uint64_t> rowmasks((size_t)P.ndials * 2 * 64, 0);
+    // planes per dial: 0 = `mask` (disk), 1 = `circle_mask` (annulus), 2 = window pixels that are
+    // 4-connected to the window border through non-disk pixels (the disk mask of a thin ring can have
+    // unfilled pockets: they are NOT outside)
+    std::vector<uint64_t> rowmasks((size_t)P.ndials * 3 * 64, 0);
     const size_t n = (size_t)th * tw;
     for (int d = 0; d < P.ndials; ++d) {
         const melf_dial& D = P.dial[d];
@@ -344,8 +347,24 @@ static int setup_device_tables(melf_ctx* c)
                     // the kernel needs a 2-px margin around the disk inside its window
                     if (wy < 2 || wy >= G.ws - 2 || wx < 2 || wx >= G.ws - 2)
                         return fail(MELF_ERR_TOO_LARGE, "dial mask leaks outside its window (clipped circle?)");
-                    rowmasks[((size_t)d * 2 + pl) * 64 + wy] |= 1ull << wx;
+                    rowmasks[((size_t)d * 3 + pl) * 64 + wy] |= 1ull << wx;
                 }
+        {   // plane 2: flood the complement of the disk from the 64 x 64 window border
+            const uint64_t* dk = &rowmasks[((size_t)d * 3 + 0) * 64];
+            uint64_t* outp = &rowmasks[((size_t)d * 3 + 2) * 64];
+            for (int y = 0; y < 64; ++y) outp[y] = (y == 0 || y == 63) ? ~dk[y] : ((1ull | (1ull << 63)) & ~dk[y]);
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int y = 0; y < 64; ++y) {
+                    const uint64_t o = outp[y];
+                    uint64_t nb = (o << 1) | (o >> 1);
+                    if (y > 0) nb |= outp[y - 1];
+                    if (y < 63) nb |= outp[y + 1];
+                    const uint64_t n2 = o | (nb & ~dk[y]);
+                    if (n2 != o) { outp[y] = n2; changed = true; }
+                }
+            }
+        }
         if (G.core_x - 2 < G.wx0 || G.core_x + 2 >= G.wx0 + G.ws || G.core_y - 2 < G.wy0 || G.core_y + 2 >= G.wy0 + G.ws)
             return fail(MELF_ERR_INVALID, "dial colour core outside the dial window");
     }

@@ -73,7 +73,7 @@ struct DialsSrc {
 };
 
 void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& P, const DialGeom* d_geom,
-                  const uint64_t* d_rowmasks /* [ndials][2][64] */, const MatchPartial* d_partials,
+                  const uint64_t* d_rowmasks /* [ndials][3][64] */, const MatchPartial* d_partials,
                   int nparts, int rw, melf_result* d_results, hipStream_t stream);
 
 // ---- K1b / HLS --------------------------------------------------------------

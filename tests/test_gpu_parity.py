@@ -443,6 +443,81 @@ def test_full_path_synthetic_batch(env, sd, seed):
     assert sum(1 for o in ores if o.status == 0) >= 40
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3, 4])
+def test_read_dials_random_geometries(env, tmp_path, seed):
+    """Random params.yml dial geometries (centres incl. half-integer ones, diameters, ring
+    thickness, colour ranges, momentum sign, zero angle, 3..6 dials) on noisy blob crops:
+    the per-dial kernel's windows / bit masks / flood fills against the oracle."""
+    import shutil
+    import yaml
+    from meterelf_amd import MeterReader, _params
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(seed)
+    src = os.path.join(GOLDEN, 'sample-images1')
+    with open(os.path.join(src, 'params.yml')) as fp:
+        data = yaml.safe_load(fp)
+    ndials = int(rng.integers(3, 7))
+    needles = []
+    for k in range(ndials):
+        diameter = int(rng.integers(6, 20))
+        dist = int(rng.integers(1, 6))
+        thick = int(rng.integers(3, 11))
+        r_out = int(np.rint(diameter / 2.0)) + dist + thick
+        cx = float(rng.integers(r_out + 3, 188 - r_out - 3)) + float(rng.choice([0.0, 0.3, 0.5, 0.9]))
+        cy = float(rng.integers(r_out + 3, 119 - r_out - 3)) + float(rng.choice([0.0, 0.4, 0.5, 0.7]))
+        needles.append({
+            'name': 'd%d' % k, 'color_range': {'h': int(rng.integers(5, 40)), 'l': int(rng.integers(20, 90)),
+                                               's': int(rng.integers(20, 120))},
+            'dist_from_center': dist, 'circle_thickness': thick, 'angle_of_zero': float(rng.uniform(-20, 20)),
+            'center': [cx, cy], 'diameter': diameter, 'negative_momentum': bool(rng.integers(0, 2))})
+    data['needle_data'] = needles
+    with open(tmp_path / 'params.yml', 'w') as fp:
+        yaml.safe_dump(data, fp)
+    shutil.copy(os.path.join(src, 'dials_gray.png'), tmp_path / 'dials_gray.png')
+    params = _params.load(str(tmp_path / 'params.yml'))
+    op = po.Params(str(tmp_path / 'params.yml'))
+    assert np.array_equal(_hip_masks(params), op.masks())
+    crops = []
+    for k in range(24):
+        base = rng.integers(30, 220, size=3)
+        c = np.clip(base[None, None, :] + rng.integers(-35, 35, size=(119, 188, 3)), 0, 255).astype(np.uint8)
+        for nd in needles:  # a needle-like streak of a distinct colour through every dial
+            (cx, cy) = nd['center']
+            ang = rng.uniform(0, 2 * np.pi)
+            col = rng.integers(0, 256, size=3)
+            for t in np.linspace(0, 26, 80):
+                for w in (-1, 0, 1):
+                    (x, y) = (int(cx + t * np.cos(ang) + w * np.sin(ang)), int(cy + t * np.sin(ang) - w * np.cos(ang)))
+                    if 0 <= x < 188 and 0 <= y < 119:
+                        c[y, x] = np.clip(col + rng.integers(-6, 6, size=3), 0, 255)
+        crops.append(c)
+    crops = np.stack(crops)
+    reader = MeterReader(params)
+    try:
+        recs = reader.ctx.read_dials(crops)
+    finally:
+        reader.close()
+    statuses = set()
+    for i in range(len(crops)):
+        o = po.read_dials(crops[i], op)
+        statuses.add(o.status)
+        assert int(recs[i]['status']) == o.status, (i, int(recs[i]['status']), o.status)
+        if o.status == 0:
+            assert np.allclose(recs[i]['pos'][:ndials], list(o.pos)[:ndials], rtol=0, atol=POS_TOL), i
+            if ndials == 4:
+                assert abs(float(recs[i]['value']) - o.value) < 1e-8
+        elif o.status == 2:
+            assert int(recs[i]['failed_dial']) == o.failed_dial
+        elif o.status == 3:
+            assert int(recs[i]['unreadable_mask']) == o.unreadable_mask
+    assert 0 in statuses
+
+
+def _hip_masks(params):
+    from meterelf_amd import _hip
+    return _hip.build_dial_masks(params.to_c())
+
+
 def test_1080p_six_dials(env, tmp_path):
     """BASELINE config 5 shape: 1920x1080 frames, meter_rect inside the frame, six dials.
     The reference cannot compute `value` for != 4 dials (assert in _reading.py:166): the record
