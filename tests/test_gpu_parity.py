@@ -513,6 +513,47 @@ def test_read_dials_random_geometries(env, tmp_path, seed):
     assert 0 in statuses
 
 
+@pytest.mark.parametrize('tw,th,kind', [(188, 119, 'random'), (188, 119, 'extreme'), (170, 100, 'random'), (150, 90, 'random'), (64, 40, 'random')])
+def test_match_other_templates(tmp_path, tw, th, kind):
+    """Other templates: random and 0/255-extreme content (limits of the T-128 / L-128 int8 trick) at
+    the MFMA kernel's width class, and other widths that take the generic v_dot4 kernel."""
+    import shutil
+    import yaml
+    from PIL import Image
+    from meterelf_amd import MeterReader, _params
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(tw * 1000 + th + len(kind))
+    src = os.path.join(GOLDEN, 'sample-images1')
+    with open(os.path.join(src, 'params.yml')) as fp:
+        data = yaml.safe_load(fp)
+    data['dials_template_size'] = [tw, th]
+    for nd in data['needle_data']:   # keep the dial windows inside the smaller templates
+        nd['center'] = [min(nd['center'][0], tw - 26.0), min(nd['center'][1], th - 26.0)]
+        nd['center'] = [max(nd['center'][0], 26.0), max(nd['center'][1], 26.0)]
+    with open(tmp_path / 'params.yml', 'w') as fp:
+        yaml.safe_dump(data, fp)
+    if kind == 'extreme':
+        tpl = rng.choice(np.array([0, 255], np.uint8), size=(th, tw))
+    else:
+        tpl = rng.integers(0, 256, size=(th, tw), dtype=np.uint8)
+    Image.fromarray(tpl, 'L').save(tmp_path / 'dials_gray.png')
+    params = _params.load(str(tmp_path / 'params.yml'))
+    imgs = rng.integers(0, 256, size=(5, 250, 250), dtype=np.uint8)
+    imgs[1] = 255
+    imgs[2] = rng.choice(np.array([0, 255], np.uint8), size=(250, 250))
+    imgs[3, 40:40 + th, 30:30 + tw] = tpl   # an exact occurrence of the template
+    reader = MeterReader(params)
+    try:
+        (mv, mx, my, rmap) = reader.ctx.match_ccoeff(imgs, want_map=True)
+    finally:
+        reader.close()
+    for i in range(len(imgs)):
+        (ev, ex, ey, emap) = po.match_ccoeff(imgs[i], tpl, want_map=True)
+        assert np.array_equal(rmap[i], emap), i
+        assert (float(mv[i]), int(mx[i]), int(my[i])) == (ev, ex, ey), i
+    assert (int(mx[3]), int(my[3])) == (30, 40)
+
+
 def _hip_masks(params):
     from meterelf_amd import _hip
     return _hip.build_dial_masks(params.to_c())
