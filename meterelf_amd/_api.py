@@ -5,9 +5,12 @@
 Lazy, yields in input order, per-image ImageProcessingError becomes the `error`
 field (re-raised only when DEBUG is set).  Unlike the reference's one-at-a-time
 loop, files are decoded and sent to the GPU in chunks (METERELF_BATCH, default
-64), so up to one chunk is read ahead of the consumer.
+64), so up to one chunk is read ahead of the consumer; the JPEG decode of a chunk
+(host work, cv2.imread in the reference) runs on a small thread pool
+(METERELF_DECODE_THREADS, default min(8, cpu count); Pillow releases the GIL).
 """
 import os
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional
 
 from . import _debug, _params
@@ -40,6 +43,15 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
     if _debug.DEBUG:
         batch = 1  # DEBUG re-raises at the failing file, before any later file is touched
     reader: Optional[MeterReader] = None
+    nthreads = max(1, int(os.getenv('METERELF_DECODE_THREADS', str(min(8, os.cpu_count() or 1)))))
+    pool = ThreadPoolExecutor(max_workers=nthreads) if (nthreads > 1 and batch > 1) else None
+
+    def _decode(filename: str):
+        try:
+            return ImageFile(filename, params).get_frame()
+        except ImageProcessingError as e:
+            return e
+
     try:
         for chunk in _chunks(filenames, batch):
             if reader is None:
@@ -47,13 +59,15 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
             assert len(reader.dial_names) == 4  # meterelf/_reading.py:166
             errors: Dict[int, ImageProcessingError] = {}
             frames, where = [], []
-            for (i, filename) in enumerate(chunk):
-                try:
-                    frames.append(ImageFile(filename, params).get_frame())
+            decoded = list(pool.map(_decode, chunk)) if pool is not None else [_decode(f) for f in chunk]
+            for (i, item) in enumerate(decoded):
+                if isinstance(item, ImageProcessingError):
+                    errors[i] = item
+                    if _debug.DEBUG:
+                        raise item
+                else:
+                    frames.append(item)
                     where.append(i)
-                except ImageProcessingError as e:
-                    errors[i] = e
-                    _debug.reraise_if_debug_on()
             records = reader.read_many(frames) if frames else []
             by_index = dict(zip(where, records))
             for (i, filename) in enumerate(chunk):
@@ -65,5 +79,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                         raise error
                 yield MeterImageData(filename, meter_values.get('value'), error, meter_values)
     finally:
+        if pool is not None:
+            pool.shutdown(wait=False)
         if reader is not None:
             reader.close()
