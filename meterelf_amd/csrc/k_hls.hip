@@ -286,6 +286,7 @@ int fused_tables_count_offset() { return OFF_COUNT; }
 int fused_tables_active_offset() { return OFF_ACTIVE; }
 
 
+constexpr int FUSED_MAX_RC = 256;  // rows per pass (bounds the LDS rings of very narrow images)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct Px16 {
     u32x4 q0, q1, q2;  // 16 BGR pixels = 48 bytes
@@ -313,20 +314,28 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
         const uint32_t px = sh <= 8 ? (d[j] >> sh) : __builtin_amdgcn_alignbit(d[j + 1 < 12 ? j + 1 : 11], d[j], sh);
         const int b = px & 255, g = (px >> 8) & 255, r = (px >> 16) & 255;
         if (IV) {
+            // Bytes are taken straight from the loaded dwords (SDWA byte selects), no per-pixel extraction.
             constexpr int SEC = VAR - 6;
-            const int P = SEC == 0 ? r : (SEC == 1 ? g : b);
-            const int Q = SEC == 0 ? g : (SEC == 1 ? b : r);
-            const int S = SEC == 0 ? b : (SEC == 1 ? r : g);
-            const int mn = min(Q, S);
-            const int diff = P - mn, num = Q - S;
+            const int iP = 3 * k + (SEC == 0 ? 2 : (SEC == 1 ? 1 : 0));
+            const int iQ = 3 * k + (SEC == 0 ? 1 : (SEC == 1 ? 0 : 2));
+            const int iS = 3 * k + (SEC == 0 ? 0 : (SEC == 1 ? 2 : 1));
+            const uint32_t P = (d[iP >> 2] >> ((iP & 3) * 8)) & 255u;
+            const uint32_t Q = (d[iQ >> 2] >> ((iQ & 3) * 8)) & 255u;
+            const uint32_t S = (d[iS >> 2] >> ((iS & 3) * 8)) & 255u;
+            const uint32_t mn = min(Q, S);
+            const int diff = (int)P - (int)mn;
             // lsI row P (256 B per row, one dword per lane): address bytes = {lane*4, P, 0, 0}
-            const uint32_t lso = __builtin_amdgcn_perm(px, ls_lane, SEC == 0 ? 0x0c0c0600u : (SEC == 1 ? 0x0c0c0500u : 0x0c0c0400u));
+            const uint32_t lso = __builtin_amdgcn_perm(d[iP >> 2], ls_lane, 0x0c0c0000u | ((4u + (iP & 3)) << 8));
             const uint32_t lse = *(const uint32_t*)((const char*)ls + lso);
             const uint32_t hio = (uint32_t)((diff << 7) + (int)hi_lane);
             const uint32_t hie = *(const uint32_t*)((const char*)hue + hio);
-            const bool in_ls = (uint32_t)(mn - (int)(int16_t)(lse & 0xffffu)) < (lse >> 16);
-            const bool in_h = (uint32_t)(num - (int)(int16_t)(hie & 0xffffu)) < (hie >> 16);
-            bits = bits + bits + ((in_ls && in_h) ? 1u : 0u);  // add-with-carry: pixel 0 ends up at bit 15
+            // compares straight into lane masks (v_cmp -> SGPR pair), combined on the scalar unit
+            const uint64_t m_ls = __builtin_amdgcn_uicmp((uint32_t)((int)mn - (int)(int16_t)(lse & 0xffffu)), lse >> 16, 36 /* ult */);
+            const uint64_t m_h = __builtin_amdgcn_uicmp((uint32_t)((int)Q - ((int)S + (int)(int16_t)(hie & 0xffffu))), hie >> 16, 36);
+            // bits = 2 * bits + in (one add-with-carry on the lane mask): pixel 0 ends up at bit 15
+            const uint64_t m = m_ls & m_h;
+            uint64_t cout;
+            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits), "=s"(cout) : "s"(m));
         } else if (SINGLE) {
             // Sector of maximum P: num = Q - S, vmin = min(Q, S).  A pixel belongs to the sector iff
             // |num| <= diff (ties resolved r > g > b by which entries the table builder ever sets), so
@@ -400,6 +409,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     // tables in static LDS (their addresses fold into the ds_read offset field), rings in dynamic LDS
     __shared__ __attribute__((aligned(16))) uint32_t hue[HDW];
     __shared__ __attribute__((aligned(16))) uint32_t ls[LSDW];
+    __shared__ uint32_t expand4[16];  // 4 mask bits -> 4 mask bytes
     extern __shared__ uint32_t ring[];
     const int wpr = (W + 31) >> 5;
     uint32_t* raw = ring;
@@ -428,11 +438,12 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             for (int i = tid; i < LSDW; i += THREADS) ls[i] = g_tables[OFF_LS + i];
         }
         for (int i = tid; i < 2 * NB * wpr; i += THREADS) raw[i] = 0;  // unused half-words must read as 0
+        if (tid < 16) expand4[tid] = ((uint32_t)tid * 0x00204081u & 0x01010101u) * 255u;
     };
     bool tables_ready = false;
 
     const int G16 = W >> 4;
-    const int RC = THREADS / G16;  // rows per pass
+    const int RC = min(THREADS / G16, FUSED_MAX_RC);  // rows per pass
     const int trow = tid / G16, tg = tid - trow * G16;
     const bool active = trow < RC;
     const int tgc = active ? tg : 0;
@@ -452,7 +463,8 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             y = y < 0 ? 0 : (y >= H ? H - 1 : y);
             // plain (cached) loads: each 128-byte line is touched by three dwordx4 instructions of the
             // wave (48-byte lane stride); non-temporal loads refetch it and measured 25 % slower
-            const u32x4* p = (const u32x4*)(frame + ((size_t)y * W + 16 * tgc) * 3);
+            // 32-bit offsets from a uniform base (full-rate 24-bit multiplies; a frame is < 4 GiB)
+            const u32x4* p = (const u32x4*)(frame + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tgc) * 3u);
             dst.q0 = p[0]; dst.q1 = p[1]; dst.q2 = p[2];
         };
         auto pass = [&](int a, const Px16& cur) {
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                 const int y = a + trow;
                 uint32_t bits = inrange16<VAR>(cur, hue, ls, hue_shift, B);
                 bits = (y >= 0 && y < H) ? bits : 0u;
-                if (active && y < r1 + 2) ((uint16_t*)raw)[((y + 4 * NB) & nbm) * wpr * 2 + tg] = (uint16_t)bits;
+                if (active && y < r1 + 2) ((uint16_t*)raw)[__umul24((y + 4 * NB) & nbm, wpr * 2) + tg] = (uint16_t)bits;
             } else {
                 // load next to its use: shortest live ranges (this path runs at 64..80 VGPRs)
                 const int y = a + trow;
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                         for (int dy = -1; dy <= 1; ++dy) {
                             const int yy = y + dy;
                             if (yy < 0 || yy >= H) continue;
-                            const uint32_t* rr = raw + ((yy + 4 * NB) & nbm) * wpr;
+                            const uint32_t* rr = raw + __umul24((yy + 4 * NB) & nbm, wpr);
                             C |= rr[dk];
                             L |= dk > 0 ? rr[dk - 1] : 0u;
                             R |= dk + 1 < wpr ? rr[dk + 1] : 0u;
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                         if (dk == wpr - 1) { dil |= ~lastmask; dr = 1u; }
                         v = dil & ((dil << 1) | dl) & ((dil >> 1) | (dr << 31));
                     }
-                    he[((y + 4 * NB) & nbm) * wpr + dk] = v;
+                    he[__umul24((y + 4 * NB) & nbm, wpr) + dk] = v;
                 }
             }
             __syncthreads();
@@ -511,15 +523,15 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                 const int y = a - 2 + trow;
                 if (active && y >= r0 && y < r1) {
                     const uint16_t* h16p = (const uint16_t*)he;
-                    const uint32_t h16 = (uint32_t)h16p[((y - 1 + 4 * NB) & nbm) * wpr * 2 + tg] &
-                                         (uint32_t)h16p[((y + 4 * NB) & nbm) * wpr * 2 + tg] &
-                                         (uint32_t)h16p[((y + 1 + 4 * NB) & nbm) * wpr * 2 + tg];
-                    u32x4 o;
-                    o.x = (((h16 >> 0) & 15u) * 0x00204081u & 0x01010101u) * 255u;
-                    o.y = (((h16 >> 4) & 15u) * 0x00204081u & 0x01010101u) * 255u;
-                    o.z = (((h16 >> 8) & 15u) * 0x00204081u & 0x01010101u) * 255u;
-                    o.w = (((h16 >> 12) & 15u) * 0x00204081u & 0x01010101u) * 255u;
-                    __builtin_nontemporal_store(o, (u32x4*)(out + (size_t)y * W + 16 * tg));
+                    const uint32_t h16 = (uint32_t)h16p[__umul24((y - 1 + 4 * NB) & nbm, wpr * 2) + tg] &
+                                         (uint32_t)h16p[__umul24((y + 4 * NB) & nbm, wpr * 2) + tg] &
+                                         (uint32_t)h16p[__umul24((y + 1 + 4 * NB) & nbm, wpr * 2) + tg];
+                    u32x4 o;  // 16 bits -> 16 bytes through the 16-entry LDS table (broadcast reads)
+                    o.x = *(const uint32_t*)((const char*)expand4 + ((h16 << 2) & 0x3cu));
+                    o.y = *(const uint32_t*)((const char*)expand4 + ((h16 >> 2) & 0x3cu));
+                    o.z = *(const uint32_t*)((const char*)expand4 + ((h16 >> 6) & 0x3cu));
+                    o.w = *(const uint32_t*)((const char*)expand4 + ((h16 >> 10) & 0x3cu));
+                    __builtin_nontemporal_store(o, (u32x4*)(out + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tg)));
                 }
             }
             // no barrier needed here: the rings (NB >= 2*RC + 4 rows) keep this pass's rows apart
@@ -574,7 +586,7 @@ template <int V, int T, bool PF, int WPS>
 static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
                          const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
-    const int G16 = W >> 4, RC = T / G16, wpr = (W + 31) >> 5;
+    const int G16 = W >> 4, RC = T / G16 < FUSED_MAX_RC ? T / G16 : FUSED_MAX_RC, wpr = (W + 31) >> 5;
     int NB = 8;
     while (NB < 2 * RC + 4) NB <<= 1;
     const int per_cu = WPS * 256 / T;          // resident workgroups per CU
