@@ -305,9 +305,15 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
     if (VAR == 5)  // timing-only build: consume every loaded dword, no pixel math
         return (d[0] ^ d[1] ^ d[2] ^ d[3] ^ d[4] ^ d[5] ^ d[6] ^ d[7] ^ d[8] ^ d[9] ^ d[10] ^ d[11]) & 0xffffu;
     uint32_t bits = 0, amb = 0;
-    // interval variant: every lane reads its own bank (row-replicated tables), so no LDS conflicts
-    const uint32_t ls_lane = (threadIdx.x & 63u) * 4u;                    // byte 0 of the lsI address
-    const uint32_t hi_lane = (threadIdx.x & 31u) * 4u + 256u * 128u;      // hI row = diff + 256, 128 B per row
+    // Interval variant: one 64 KiB-aligned block of 256 rows x 256 B; bytes 0..127 of row r hold hI row r
+    // once per lane of a 32-lane group, bytes 128..255 lsI row r likewise, so every lane reads its own
+    // bank (no LDS conflicts).  A table address is the byte vector {lane * 4 (+128), row, base >> 16, 0}:
+    // one v_perm / one SDWA subtract into byte 1 builds it.
+    typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
+    const uint32_t ls_lane = (uint32_t)(uintptr_t)ls + (threadIdx.x & 31u) * 4u;
+    uint32_t haddr[4];  // four hue addresses in flight
+#pragma unroll
+    for (int q = 0; q < 4; ++q) haddr[q] = (uint32_t)(uintptr_t)hue + (threadIdx.x & 31u) * 4u;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int j = (3 * k) >> 2, sh = ((3 * k) & 3) * 8;
@@ -323,12 +329,18 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
             const uint32_t Q = (d[iQ >> 2] >> ((iQ & 3) * 8)) & 255u;
             const uint32_t S = (d[iS >> 2] >> ((iS & 3) * 8)) & 255u;
             const uint32_t mn = min(Q, S);
-            const int diff = (int)P - (int)mn;
-            // lsI row P (256 B per row, one dword per lane): address bytes = {lane*4, P, 0, 0}
-            const uint32_t lso = __builtin_amdgcn_perm(d[iP >> 2], ls_lane, 0x0c0c0000u | ((4u + (iP & 3)) << 8));
-            const uint32_t lse = *(const uint32_t*)((const char*)ls + lso);
-            const uint32_t hio = (uint32_t)((diff << 7) + (int)hi_lane);
-            const uint32_t hie = *(const uint32_t*)((const char*)hue + hio);
+            // lsI row P: address bytes {lane*4, P, base, 0}
+            const uint32_t lso = __builtin_amdgcn_perm(d[iP >> 2], ls_lane, 0x0c020000u | ((4u + (iP & 3)) << 8));
+            const uint32_t lse = *(lds_u32)lso;
+            // hI row (P - mn) & 255, written into byte 1 of the address register.  Negative differences
+            // alias onto real rows, which is harmless: then mn > P and no lsI row P holds a minimum above P.
+            switch (iP & 3) {
+                case 0: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
+                case 1: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
+                case 2: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
+                default: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
+            }
+            const uint32_t hie = *(lds_u32)haddr[k & 3];
             // compares straight into lane masks (v_cmp -> SGPR pair), combined on the scalar unit
             const uint64_t m_ls = __builtin_amdgcn_uicmp((uint32_t)((int)mn - (int)(int16_t)(lse & 0xffffu)), lse >> 16, 36 /* ult */);
             const uint64_t m_h = __builtin_amdgcn_uicmp((uint32_t)((int)Q - ((int)S + (int)(int16_t)(hie & 0xffffu))), hie >> 16, 36);
@@ -396,19 +408,21 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
 // from the table at context creation) -> no 3-way select, one 32 KiB table.
 // VAR 3: any sectors, no ties.  VAR 4: any sectors, ties re-evaluated exactly.
 // VAR 5: timing-only (memory traffic and barriers, no pixel math; output is garbage).
-template <int VAR, int THREADS, bool PREFETCH, int WPS /* waves per SIMD the register budget must allow */>
+template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */>
 __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const uint8_t* __restrict__ frames, int n, int H, int W, int hue_shift, Bounds B,
     const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB)
 {
+    constexpr bool PREFETCH = PD > 0;
     constexpr bool AMB = VAR == 4;
     constexpr bool IV = VAR >= 6;
     constexpr bool SINGLE = VAR < 3 || VAR == 5;
-    constexpr int HDW = IV ? HI_ROWS * 32 : (AMB ? HUE2_DWORDS : (SINGLE ? HUES_DWORDS : HUE1_DWORDS));
-    constexpr int LSDW = IV ? LSI_ROWS * 64 : LS_DWORDS;
+    constexpr int HDW = IV ? 256 * 64 /* both interval tables, interleaved by row */ : (AMB ? HUE2_DWORDS : (SINGLE ? HUES_DWORDS : HUE1_DWORDS));
+    constexpr int LSDW = IV ? 4 /* lives inside hue[] */ : LS_DWORDS;
     // tables in static LDS (their addresses fold into the ds_read offset field), rings in dynamic LDS
-    __shared__ __attribute__((aligned(16))) uint32_t hue[HDW];
-    __shared__ __attribute__((aligned(16))) uint32_t ls[LSDW];
+    __shared__ __attribute__((aligned(IV ? 65536 : 16))) uint32_t hue[HDW];
+    __shared__ __attribute__((aligned(16))) uint32_t ls_own[LSDW];
+    uint32_t* const ls = IV ? hue + 32 : ls_own;
     __shared__ uint32_t expand4[16];  // 4 mask bits -> 4 mask bytes
     extern __shared__ uint32_t ring[];
     const int wpr = (W + 31) >> 5;
@@ -420,17 +434,15 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
         if (IV) {
             // each (lo, count) row replicated so that lane L of a 32-lane group always reads bank L:
             // one global load per row, then 16-byte LDS stores
-            for (int r = tid; r < HI_ROWS; r += THREADS) {
-                const uint32_t v = g_tables[OFF_HI + (VAR - 6) * HI_ROWS + r];
-                const u32x4 v4 = {v, v, v, v};
+            for (int r = tid; r < 256; r += THREADS) {  // hI rows diff = 0..255 (table rows diff + 256), lsI rows P
+                const uint32_t vh = g_tables[OFF_HI + (VAR - 6) * HI_ROWS + 256 + r];
+                const uint32_t vl = g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + r];
+                const u32x4 h4 = {vh, vh, vh, vh}, l4 = {vl, vl, vl, vl};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) *(u32x4*)(hue + r * 32 + q * 4) = v4;
-            }
-            for (int r = tid; r < LSI_ROWS; r += THREADS) {
-                const uint32_t v = g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + r];
-                const u32x4 v4 = {v, v, v, v};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) *(u32x4*)(ls + r * 64 + q * 4) = v4;
+                for (int q = 0; q < 8; ++q) {
+                    *(u32x4*)(hue + r * 64 + q * 4) = h4;
+                    *(u32x4*)(hue + r * 64 + 32 + q * 4) = l4;
+                }
             }
         } else {
             for (int i = tid; i < HDW; i += THREADS)
@@ -519,6 +531,11 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             }
             __syncthreads();
             // ---- (3) rows [a-2, a+RC-3] of the segment: vertical AND, expand, store ----
+            // gfx9 counts loads and stores in the same vmcnt and the compiler treats them as completing
+            // out of order, so a wait for the prefetched pixels issued AFTER this pass's store would also
+            // wait for the store's write-ack (a full memory round trip per pass).  Waiting here, just
+            // before the store is issued, costs nothing: the only store in flight is one pass old.
+            if (PD > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (PD - 1)));  // vmcnt(3*(PD-1)), others untouched
             {
                 const int y = a - 2 + trow;
                 if (active && y >= r0 && y < r1) {
@@ -540,22 +557,27 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
         int a = r0 - 2;
         const int aend = r1 + 2;
         if (PREFETCH) {
-            Px16 pa, pb;
-            load(a, pa);
+            // PD + 1 rotating register sets: the loads of the next PD passes are in flight while the
+            // current pass is processed (all indices are compile-time after unrolling)
+            Px16 pbuf[PD + 1];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) load(a + q * RC, pbuf[q]);
             if (!tables_ready) {  // the frame loads above are already in flight while LDS is filled
                 fill_tables();
                 tables_ready = true;
                 __syncthreads();
             }
-            for (;;) {
-                load(a + RC, pb);
-                pass(a, pa);
-                a += RC;
-                if (a >= aend) break;
-                load(a + RC, pa);
-                pass(a, pb);
-                a += RC;
-                if (a >= aend) break;
+            // same explicit wait as before each store (see pass()): the loop body then never waits on
+            // a load that is younger than a store
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (PD - 1)));
+            for (bool more = true; more;) {
+#pragma unroll
+                for (int q = 0; q <= PD; ++q) {
+                    load(a + PD * RC, pbuf[(q + PD) % (PD + 1)]);
+                    pass(a, pbuf[q]);
+                    a += RC;
+                    if (a >= aend) { more = false; break; }
+                }
             }
         } else {
             if (!tables_ready) {
@@ -582,7 +604,7 @@ bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W)
 //   3: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), no prefetch
 static int g_fused_config = 0;
 
-template <int V, int T, bool PF, int WPS>
+template <int V, int T, int PF, int WPS>
 static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
                          const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
@@ -611,15 +633,19 @@ template <int V>
 static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
                          const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
-    if constexpr (V >= 6) {  // 128 KiB of replicated interval tables: one 1024-thread workgroup per CU
-        if (g_fused_config == 1) launch_lut_t<V, 1024, false, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
-        else launch_lut_t<V, 1024, true, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
+    if constexpr (V >= 5) {  // interval tables (64 KiB per workgroup); 5: timing-only twin of the same launch shapes
+        switch (g_fused_config) {
+            case 1: launch_lut_t<V, 1024, 0, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 3: launch_lut_t<V, 1024, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            default: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+        }
     } else {
         switch (g_fused_config) {
-            case 1: launch_lut_t<V, 512, true, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 2: launch_lut_t<V, 1024, true, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 3: launch_lut_t<V, 1024, false, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            default: launch_lut_t<V, 512, false, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 1: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 3: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            default: launch_lut_t<V, 512, 0, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         }
     }
 }

@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--sample-dir', default='sample-images1')
+    ap.add_argument('--hw', default='480x640', help='fused stage: frame rows x columns')
     a = ap.parse_args()
     import torch
     from meterelf_amd import _engine, _hip, _params
@@ -31,10 +32,16 @@ def main():
     ctx.set_profiling(True)
     if a.stage == 'fused':
         B = a.batch or 256
-        frames = torch.randint(0, 256, (B, 640, 480, 3), dtype=torch.uint8, device=dev, generator=g)
-        masks = torch.empty((B, 640, 480), dtype=torch.uint8, device=dev)
+        (H, W) = (int(v) for v in a.hw.split('x'))
+        frames = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=dev, generator=g)
+        masks = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        ctx.set_profiling(False)
+        for _ in range(10):  # untimed warm-up launches
+            ctx.hls_inrange_close_dev(frames.data_ptr(), B, H, W, masks.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        ctx.set_profiling(True)
         for _ in range(a.iters):
-            ctx.hls_inrange_close_dev(frames.data_ptr(), B, 640, 480, masks.data_ptr(), stream=stream)
+            ctx.hls_inrange_close_dev(frames.data_ptr(), B, H, W, masks.data_ptr(), stream=stream)
         torch.cuda.synchronize()
     else:
         import bench
