@@ -635,7 +635,7 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
 {
     if constexpr (V >= 5) {  // interval tables (64 KiB per workgroup); 5: timing-only twin of the same launch shapes
         switch (g_fused_config) {
-            case 1: launch_lut_t<V, 1024, 0, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 1: launch_lut_t<V, 512, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 3: launch_lut_t<V, 1024, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             default: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
