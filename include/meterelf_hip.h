@@ -30,7 +30,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 #define MELF_MAX_DIALS 8
-#define MELF_ABI_VERSION 1
+#define MELF_ABI_VERSION 2
 
 /* API status codes (negative) */
 enum {
@@ -175,11 +175,34 @@ int melf_aligned_average(melf_ctx* ctx, const uint8_t* frames_host, int n, int H
 int melf_inrange(melf_ctx* ctx, const uint8_t* img_host, int rows, int cols, const int32_t lo[3],
                  const int32_t hi[3], uint8_t* mask_host);
 
+/* ---- JPEG decode (reference: cv2.imread in ImageFile.get_bgr_image, meterelf/_image.py:46-51) ----
+ * Baseline sequential 8-bit Huffman JPEGs (one interleaved scan; YCbCr 4:2:0 / 4:2:2 / 4:4:4 or
+ * greyscale; restart intervals allowed) are decoded on the GPU to the bytes libjpeg produces with its
+ * defaults (ISLOW IDCT, fancy upsampling), i.e. what cv2.imread returns: H x W x 3 BGR u8.
+ * Per-file status: 0 decoded, 1 valid JPEG outside that subset (decode it on the host instead),
+ * 2 unreadable / corrupt, 3 its size is not H x W.  Frames with a non-zero status are zero-filled. */
+enum { MELF_JPEG_OK = 0, MELF_JPEG_UNSUPPORTED = 1, MELF_JPEG_CORRUPT = 2, MELF_JPEG_SIZE_MISMATCH = 3 };
+
+/* Header check only (no GPU, no context): image size and whether the GPU decoder handles the file. */
+int melf_jpeg_probe(const uint8_t* data, size_t size, int32_t* H, int32_t* W, int32_t* supported);
+
+/* Decodes n files of H x W pixels.  out: n*H*W*3 bytes, on the host (out_on_device = 0) or in HBM.
+ * Synchronises the context's stream. */
+int melf_jpeg_decode_batch(melf_ctx* ctx, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                           void* out, int out_on_device, int32_t* status);
+
+/* get_meter_value for n JPEG files (meterelf/_api.py:22-33 with _image.py:46-51): decode on the GPU
+ * straight into HBM, then the same path as melf_process_batch.  Records of files whose status is
+ * non-zero are meaningless. */
+int melf_jpeg_process_batch(melf_ctx* ctx, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                            melf_result* out_host, int32_t* status);
+
 /* ---- measurement ---------------------------------------------------------
  * With profiling on, every kernel launched by a *_dev entry point is bracketed
  * by hipEvents on its stream; melf_ctx_timings drains them (synchronising) and
  * returns per-kernel accumulated milliseconds and launch counts. */
-enum { MELF_K_LPLANE = 0, MELF_K_MATCH = 1, MELF_K_DIALS = 2, MELF_K_FUSED_MASK = 3, MELF_K_HLS = 4, MELF_K_COUNT = 5 };
+enum { MELF_K_LPLANE = 0, MELF_K_MATCH = 1, MELF_K_DIALS = 2, MELF_K_FUSED_MASK = 3, MELF_K_HLS = 4,
+       MELF_K_JPEG_HUFF = 5, MELF_K_JPEG_IDCT = 6, MELF_K_JPEG_COLOR = 7, MELF_K_COUNT = 8 };
 int melf_ctx_set_profiling(melf_ctx* ctx, int on);
 int melf_ctx_timings(melf_ctx* ctx, double ms[MELF_K_COUNT], int64_t launches[MELF_K_COUNT]);
 const char* melf_kernel_name(int k);

@@ -12,14 +12,15 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MELF_LIB_PATH') or os.path.join(_PKG, 'libmeterelf_hip.so')  # override: A/B builds
 
 MAX_DIALS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FRAME_OK = 0
 FRAME_DIALS_NOT_FOUND = 1
 FRAME_NEEDLE_CONTOURS_NOT_FOUND = 2
 FRAME_ANGLE_UNDETERMINED = 3
 
-K_LPLANE, K_MATCH, K_DIALS, K_FUSED_MASK, K_HLS, K_COUNT = 0, 1, 2, 3, 4, 5
+K_LPLANE, K_MATCH, K_DIALS, K_FUSED_MASK, K_HLS, K_JPEG_HUFF, K_JPEG_IDCT, K_JPEG_COLOR, K_COUNT = range(9)
+JPEG_OK, JPEG_UNSUPPORTED, JPEG_CORRUPT, JPEG_SIZE_MISMATCH = 0, 1, 2, 3
 
 
 class MelfDial(C.Structure):
@@ -63,6 +64,7 @@ EXPORTS = [
     'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
+    'melf_jpeg_probe', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
 ]
 
 _lib = None
@@ -105,6 +107,10 @@ def lib():
     L.melf_ctx_fused_table_ties.argtypes = [vp, C.POINTER(C.c_int)]
     L.melf_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.melf_ctx_timings.argtypes = [vp, vp, vp]
+    i32p = C.POINTER(C.c_int32)
+    L.melf_jpeg_probe.argtypes = [vp, C.c_size_t, i32p, i32p, i32p]
+    L.melf_jpeg_decode_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.melf_jpeg_process_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     if L.melf_abi_version() != ABI_VERSION:
         raise HipError('libmeterelf_hip.so ABI version mismatch')
     _lib = L
@@ -124,6 +130,30 @@ def device_count():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def jpeg_probe(data):
+    """(H, W, supported, reason) of a JPEG file's bytes; header parse only, no GPU."""
+    L = lib()
+    H, W, ok = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    buf = (C.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, np.ndarray) else None
+    p = C.cast(buf, C.c_void_p) if buf is not None else _ptr(data)
+    check(L.melf_jpeg_probe(p, len(data), C.byref(H), C.byref(W), C.byref(ok)))
+    return H.value, W.value, bool(ok.value), L.melf_last_error().decode()
+
+
+def _file_table(files):
+    """list of bytes objects -> (pointer array, size array, keep-alive)"""
+    n = len(files)
+    ptrs = (C.c_void_p * n)()
+    sizes = (C.c_size_t * n)()
+    keep = []
+    for (i, f) in enumerate(files):
+        b = bytes(f) if not isinstance(f, bytes) else f
+        keep.append(b)
+        ptrs[i] = C.cast(C.c_char_p(b), C.c_void_p)
+        sizes[i] = len(b)
+    return ptrs, sizes, keep
 
 
 def pack_blob(cparams, template):
@@ -273,6 +303,35 @@ class Context:
         return n.value
 
     # --- measurement ---
+    def jpeg_decode(self, files, H, W):
+        """cv2.imread for a batch of JPEG files' bytes: (frames n x H x W x 3 BGR u8, status n)."""
+        n = len(files)
+        out = np.zeros((n, H, W, 3), np.uint8)
+        status = np.zeros(n, np.int32)
+        if n:
+            (ptrs, sizes, keep) = _file_table(files)
+            check(self._L.melf_jpeg_decode_batch(self._h, ptrs, sizes, n, H, W, _ptr(out), 0, _ptr(status)))
+        return out, status
+
+    def jpeg_decode_dev(self, files, H, W, d_frames_ptr):
+        """Same, into device memory (n*H*W*3 bytes at d_frames_ptr); returns the status array."""
+        n = len(files)
+        status = np.zeros(n, np.int32)
+        if n:
+            (ptrs, sizes, keep) = _file_table(files)
+            check(self._L.melf_jpeg_decode_batch(self._h, ptrs, sizes, n, H, W, C.c_void_p(d_frames_ptr), 1, _ptr(status)))
+        return status
+
+    def jpeg_process_batch(self, files, H, W):
+        """JPEG bytes -> (result records, decode status); decode and reading both on the GPU."""
+        n = len(files)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        status = np.zeros(n, np.int32)
+        if n:
+            (ptrs, sizes, keep) = _file_table(files)
+            check(self._L.melf_jpeg_process_batch(self._h, ptrs, sizes, n, H, W, _ptr(out), _ptr(status)))
+        return out, status
+
     def set_profiling(self, on):
         check(self._L.melf_ctx_set_profiling(self._h, 1 if on else 0))
 

@@ -325,7 +325,6 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
             const int iP = 3 * k + (SEC == 0 ? 2 : (SEC == 1 ? 1 : 0));
             const int iQ = 3 * k + (SEC == 0 ? 1 : (SEC == 1 ? 0 : 2));
             const int iS = 3 * k + (SEC == 0 ? 0 : (SEC == 1 ? 2 : 1));
-            const uint32_t P = (d[iP >> 2] >> ((iP & 3) * 8)) & 255u;
             const uint32_t Q = (d[iQ >> 2] >> ((iQ & 3) * 8)) & 255u;
             const uint32_t S = (d[iS >> 2] >> ((iS & 3) * 8)) & 255u;
             const uint32_t mn = min(Q, S);

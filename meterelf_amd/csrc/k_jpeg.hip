@@ -1,0 +1,733 @@
+// Baseline JPEG decode on the GPU: replaces the host decode behind
+// cv2.imread (meterelf/_image.py:49) for the files the meter cameras write -- baseline sequential
+// DCT, 8 bit, Huffman, one interleaved scan, YCbCr 4:2:0 / 4:2:2 / 4:4:4 or greyscale.
+//
+// The result must be the bytes libjpeg(-turbo) produces with its defaults (what cv2.imread and
+// Pillow both use): JDCT_ISLOW inverse DCT, "fancy" triangle-filter chroma upsampling, the
+// 16-bit fixed-point YCbCr->RGB tables.  All of that is integer arithmetic, restated here from
+// the algorithm descriptions in the libjpeg documentation (jidctint / jdsample / jdcolor) and
+// pinned bit-for-bit against Pillow on the reference's 304 fixture files plus synthetic files.
+//
+//   host   parse markers, build Huffman lookup tables, strip byte stuffing / RSTn markers
+//   J1     k_jpeg_huff   one lane per image: Huffman decode -> int16 coefficient blocks
+//   J2     k_jpeg_idct   one thread per 8x8 block: dequantise + ISLOW IDCT -> u8 planes
+//   J3     k_jpeg_color  one thread per 4 pixels: fancy upsample + YCC->BGR -> NHWC frame
+#include "melf_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace melf {
+
+// ------------------------------------------------------------------ host: parsing ----
+static const uint8_t ZIGZAG_TO_NATURAL[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffSpec {
+    uint8_t bits[17];  // bits[l] = number of codes of length l
+    uint8_t vals[256];
+    int nvals;
+    bool set;
+};
+
+struct JpegHeader {
+    int H = 0, W = 0, ncomp = 0;
+    int id[3] = {0, 0, 0}, hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int restart_interval = 0;
+    uint16_t qt[4][64];
+    bool qt_set[4] = {false, false, false, false};
+    HuffSpec dc[2], ac[2];
+    size_t scan_begin = 0;
+    bool saw_jfif = false, saw_adobe = false;
+    int adobe_transform = 0;
+    const char* why = nullptr;  // non-NULL: a valid-looking file this decoder does not handle
+};
+
+static inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+// Returns 0 = parsed (check h.why for "unsupported"), -1 = not a JPEG / truncated headers.
+static int parse_headers(const uint8_t* d, size_t n, JpegHeader& h)
+{
+    for (int i = 0; i < 2; ++i) { h.dc[i].set = false; h.ac[i].set = false; }
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return -1;
+    size_t i = 2;
+    bool have_sof = false;
+    for (;;) {
+        while (i < n && d[i] != 0xFF) ++i;  // tolerate garbage between segments like libjpeg's next_marker
+        while (i < n && d[i] == 0xFF) ++i;
+        if (i >= n) return -1;
+        const int m = d[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;  // parameterless
+        if (m == 0xD9) return -1;                                           // EOI before SOS
+        if (i + 2 > n) return -1;
+        const int L = be16(d + i);
+        if (L < 2 || i + L > n) return -1;
+        const uint8_t* s = d + i + 2;
+        const int len = L - 2;
+        switch (m) {
+            case 0xC0: case 0xC1: {  // baseline / extended sequential, Huffman
+                if (len < 6) return -1;
+                if (s[0] != 8) { h.why = "sample precision is not 8 bits"; }
+                h.H = be16(s + 1); h.W = be16(s + 3); h.ncomp = s[5];
+                if (h.ncomp != 1 && h.ncomp != 3) { h.why = "neither greyscale nor three components"; h.ncomp = h.ncomp > 3 ? 3 : h.ncomp; }
+                if (len < 6 + 3 * (int)s[5]) return -1;
+                for (int c = 0; c < h.ncomp; ++c) {
+                    h.id[c] = s[6 + 3 * c]; h.hs[c] = s[7 + 3 * c] >> 4; h.vs[c] = s[7 + 3 * c] & 15; h.tq[c] = s[8 + 3 * c] & 3;
+                }
+                have_sof = true;
+                break;
+            }
+            case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+                h.why = "not a baseline sequential Huffman JPEG (progressive / lossless / arithmetic)";
+                if (len >= 6) { h.H = be16(s + 1); h.W = be16(s + 3); }
+                return 0;
+            case 0xDB: {  // DQT
+                int o = 0;
+                while (o < len) {
+                    const int pq = s[o] >> 4, tq = s[o] & 15;
+                    ++o;
+                    if (tq > 3 || o + (pq ? 128 : 64) > len) return -1;
+                    for (int k = 0; k < 64; ++k) {
+                        const int v = pq ? be16(s + o + 2 * k) : s[o + k];
+                        h.qt[tq][ZIGZAG_TO_NATURAL[k]] = (uint16_t)v;
+                    }
+                    h.qt_set[tq] = true;
+                    o += pq ? 128 : 64;
+                }
+                break;
+            }
+            case 0xC4: {  // DHT
+                int o = 0;
+                while (o < len) {
+                    if (o + 17 > len) return -1;
+                    const int tc = s[o] >> 4, th = s[o] & 15;
+                    int total = 0;
+                    for (int l = 1; l <= 16; ++l) total += s[o + l];
+                    if (total > 256 || o + 17 + total > len || tc > 1) return -1;
+                    if (th > 1) { h.why = "Huffman table id above 1"; o += 17 + total; continue; }
+                    HuffSpec& t = tc ? h.ac[th] : h.dc[th];
+                    t.bits[0] = 0;
+                    for (int l = 1; l <= 16; ++l) t.bits[l] = s[o + l];
+                    memcpy(t.vals, s + o + 17, total);
+                    t.nvals = total;
+                    t.set = true;
+                    o += 17 + total;
+                }
+                break;
+            }
+            case 0xDD:
+                if (len < 2) return -1;
+                h.restart_interval = be16(s);
+                break;
+            case 0xE0:
+                if (len >= 5 && !memcmp(s, "JFIF\0", 5)) h.saw_jfif = true;
+                break;
+            case 0xEE:
+                if (len >= 12 && !memcmp(s, "Adobe", 5)) { h.saw_adobe = true; h.adobe_transform = s[11]; }
+                break;
+            case 0xDA: {  // SOS
+                if (!have_sof) return -1;
+                if (len < 1) return -1;
+                const int ns = s[0];
+                if (len < 1 + 2 * ns + 3) return -1;
+                if (ns != h.ncomp) { h.why = "more than one scan (non-interleaved components)"; return 0; }
+                for (int k = 0; k < ns; ++k) {
+                    const int cid = s[1 + 2 * k];
+                    int c = -1;
+                    for (int q = 0; q < h.ncomp; ++q) if (h.id[q] == cid) c = q;
+                    if (c != k) { h.why = "scan component order differs from the frame header"; return 0; }
+                    h.td[c] = s[2 + 2 * k] >> 4; h.ta[c] = s[2 + 2 * k] & 15;
+                    if (h.td[c] > 1 || h.ta[c] > 1) h.why = "Huffman table id above 1";
+                }
+                const uint8_t* e = s + 1 + 2 * ns;
+                if (e[0] != 0 || e[1] != 63 || e[2] != 0) { h.why = "not a full sequential scan"; return 0; }
+                h.scan_begin = i + L;
+                goto done;
+            }
+            default: break;
+        }
+        i += L;
+    }
+done:
+    if (h.why) return 0;
+    if (h.H <= 0 || h.W <= 0) { h.why = "empty image"; return 0; }
+    if (h.ncomp == 3) {
+        if (h.saw_adobe && h.adobe_transform != 1) h.why = "Adobe marker says the data are not YCbCr";
+        else if (!h.saw_jfif && !h.saw_adobe && h.id[0] == 'R' && h.id[1] == 'G' && h.id[2] == 'B') h.why = "RGB component ids";
+        else if (h.hs[1] != 1 || h.vs[1] != 1 || h.hs[2] != 1 || h.vs[2] != 1) h.why = "subsampled chroma with sampling factors above 1";
+        else if (!((h.hs[0] == 1 && h.vs[0] == 1) || (h.hs[0] == 2 && h.vs[0] == 1) || (h.hs[0] == 2 && h.vs[0] == 2)))
+            h.why = "luma sampling other than 1x1, 2x1, 2x2";
+    } else {
+        h.hs[0] = h.vs[0] = 1;  // a single-component scan is never interleaved: one block per MCU
+    }
+    for (int c = 0; c < h.ncomp && !h.why; ++c) {
+        if (!h.qt_set[h.tq[c]]) h.why = "missing quantisation table";
+        else if (!h.dc[h.td[c]].set || !h.ac[h.ta[c]].set) h.why = "missing Huffman table";
+    }
+    return 0;
+}
+
+int jpeg_probe(const uint8_t* data, size_t size, int* H, int* W, int* supported, std::string* why)
+{
+    JpegHeader h;
+    if (parse_headers(data, size, h) != 0) {
+        *H = *W = 0; *supported = 0;
+        if (why) *why = "not a JPEG file or truncated headers";
+        return 0;
+    }
+    *H = h.H; *W = h.W; *supported = h.why ? 0 : 1;
+    if (why) *why = h.why ? h.why : "";
+    return 0;
+}
+
+// ------------------------------------------------------------ device-side records ----
+struct JpegImageDev {
+    uint32_t scan_off, scan_len;  // clean entropy-coded bytes (no stuffing, no markers) in the scan area
+    uint32_t coef_blk[3];         // first coefficient block of each component (units of 64 int16)
+    uint32_t plane_off[3];        // byte offset of each component's sample plane
+    uint16_t blocks_x[3], blocks_y[3];
+    uint16_t mcus_x, mcus_y;
+    uint16_t restart_interval;
+    uint8_t ncomp, hs0, vs0, ok;
+    uint8_t tq[3], td[3], ta[3];
+    uint8_t pad[3];
+};
+static_assert(sizeof(JpegImageDev) % 4 == 0, "record must stay dword aligned");
+
+struct HuffSlow {  // codes longer than 8 bits: canonical decode (JPEG spec F.2.2.3)
+    int32_t maxcode[18];  // maxcode[l] = largest code of length l, -1 if none
+    int32_t valoff[18];   // huffval index of the first code of length l, minus that code
+    uint8_t huffval[256];
+};
+
+static void build_huff(const HuffSpec& t, uint16_t* look /* 256 */, HuffSlow* slow)
+{
+    memset(look, 0, 256 * sizeof(uint16_t));
+    memset(slow, 0, sizeof(*slow));
+    memcpy(slow->huffval, t.vals, t.nvals);
+    int code = 0, p = 0;
+    for (int l = 1; l <= 16; ++l) {
+        slow->valoff[l] = p - code;
+        for (int k = 0; k < t.bits[l]; ++k, ++p, ++code) {
+            if (l <= 8 && p < 256) {
+                const int first = (code << (8 - l)) & 255, cnt = 1 << (8 - l);
+                for (int q = 0; q < cnt; ++q) look[(first + q) & 255] = (uint16_t)((l << 8) | t.vals[p]);
+            }
+        }
+        slow->maxcode[l] = t.bits[l] ? code - 1 : -1;
+        code <<= 1;
+    }
+    slow->maxcode[17] = 0x7fffffff;
+}
+
+// Copies the entropy-coded segment without byte stuffing (FF 00 -> FF), fill bytes and RSTn markers;
+// stops at any other marker (normally EOI).  Restart boundaries stay recognisable to the decoder as
+// "discard the rest of the current byte after every restart_interval MCUs".
+static size_t clean_scan(const uint8_t* s, size_t n, uint8_t* out)
+{
+    size_t o = 0, i = 0;
+    while (i < n) {
+        const uint8_t* f = (const uint8_t*)memchr(s + i, 0xFF, n - i);
+        const size_t run = f ? (size_t)(f - (s + i)) : n - i;
+        memcpy(out + o, s + i, run);
+        o += run;
+        i += run;
+        if (!f) break;
+        if (i + 1 >= n) break;
+        const uint8_t m = s[i + 1];
+        if (m == 0x00) { out[o++] = 0xFF; i += 2; }
+        else if (m == 0xFF) { i += 1; }                   // fill byte
+        else if (m >= 0xD0 && m <= 0xD7) { i += 2; }       // RSTn
+        else break;                                        // EOI or another marker: end of scan
+    }
+    return o;
+}
+
+// ------------------------------------------------------------------ J1: Huffman ----
+__device__ __constant__ uint8_t c_zz2nat[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// One lane per image.  The loop is a flat state machine -- one Huffman symbol per iteration whatever
+// block or coefficient the lane is at -- so lanes stay busy although their images differ; the 8-bit
+// first-level lookup tables of the block's images live in LDS, longer codes take the canonical path.
+template <int IPB>
+__global__ __launch_bounds__(IPB) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_look,
+                                                   const HuffSlow* __restrict__ g_slow, const uint8_t* __restrict__ scan,
+                                                   int n, int16_t* __restrict__ coefs, int32_t* __restrict__ status)
+{
+    __shared__ uint16_t look[IPB * 1024];  // [image in block][table dc0, dc1, ac0, ac1][256]
+    __shared__ uint8_t nat[64];
+    const int lane = threadIdx.x;
+    const int img = blockIdx.x * IPB + lane;
+    {
+        const uint32_t* src = (const uint32_t*)(g_look + (size_t)blockIdx.x * IPB * 1024);
+        const int avail = min(IPB, n - blockIdx.x * IPB) * 512;
+        uint32_t* dst = (uint32_t*)look;
+        for (int i = lane; i < IPB * 512; i += IPB) dst[i] = i < avail ? src[i] : 0u;
+        if (lane < 64) nat[lane] = c_zz2nat[lane];
+        if (IPB < 64) for (int i = lane; i < 64; i += IPB) nat[i] = c_zz2nat[i];
+    }
+    __syncthreads();
+    if (img >= n) return;
+    const JpegImageDev I = imgs[img];
+    if (!I.ok) { status[img] = 1; return; }
+    const uint8_t* p = scan + I.scan_off;
+    const uint32_t limit = I.scan_len + 8;  // the scan area is zero-padded by 16 bytes per image
+    const uint16_t* mylook = look + lane * 1024;
+    const HuffSlow* myslow = g_slow + (size_t)img * 4;
+
+    uint64_t bitbuf = 0;
+    int bitcnt = 0;
+    uint32_t pos = 0;
+    const int total_mcus = (int)I.mcus_x * I.mcus_y;
+    const int yblocks = I.ncomp == 1 ? 1 : I.hs0 * I.vs0;
+    const int blocks_per_mcu = I.ncomp == 1 ? 1 : yblocks + 2;
+    int mcu = 0, mx = 0, my = 0, blk = 0, k = 0, comp = 0;
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int restarts_left = I.restart_interval;
+    int16_t* cblock = coefs + (size_t)I.coef_blk[0] * 64;
+    int tdc = I.td[0], tac = 2 + I.ta[0];
+    int32_t st = 0;
+
+    while (mcu < total_mcus) {
+        if (bitcnt <= 32) {
+            const uint8_t* q = p + pos;
+            const uint32_t w = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+            bitbuf |= (uint64_t)w << (32 - bitcnt);
+            bitcnt += 32;
+            pos += 4;
+            if (pos > limit) { st = 2; break; }  // ran past the data: truncated or corrupt
+        }
+        const int t = k == 0 ? tdc : tac;
+        const uint32_t e = mylook[t * 256 + (uint32_t)(bitbuf >> 56)];
+        int len, sym;
+        if (e) {
+            len = e >> 8;
+            sym = e & 255;
+        } else {
+            const HuffSlow* s = myslow + t;
+            const int code16 = (int)(bitbuf >> 48);
+            len = 9;
+            while (len <= 16 && (code16 >> (16 - len)) > s->maxcode[len]) ++len;
+            if (len > 16) { st = 2; break; }
+            sym = s->huffval[(s->valoff[len] + (code16 >> (16 - len))) & 255];
+        }
+        bitbuf <<= len;
+        bitcnt -= len;
+        const int sbits = k == 0 ? (sym & 15) : (sym & 15);
+        const int run = k == 0 ? 0 : (sym >> 4);
+        int v = 0;
+        if (sbits) {
+            const uint32_t raw = (uint32_t)(bitbuf >> (64 - sbits));
+            bitbuf <<= sbits;
+            bitcnt -= sbits;
+            v = raw < (1u << (sbits - 1)) ? (int)raw - (1 << sbits) + 1 : (int)raw;  // EXTEND (F.2.2.1)
+        }
+        if (k == 0) {
+            int pr = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
+            pr += v;
+            if (comp == 0) pred0 = pr; else if (comp == 1) pred1 = pr; else pred2 = pr;
+            cblock[0] = (int16_t)pr;
+            k = 1;
+        } else if (sbits) {
+            k += run;
+            if (k < 64) cblock[nat[k]] = (int16_t)v;
+            ++k;
+        } else if (run == 15) {
+            k += 16;
+        } else {
+            k = 64;  // EOB
+        }
+        if (k >= 64) {  // next block
+            k = 0;
+            if (++blk == blocks_per_mcu) {
+                blk = 0;
+                ++mcu;
+                if (++mx == I.mcus_x) { mx = 0; ++my; }
+                if (I.restart_interval && --restarts_left == 0) {
+                    restarts_left = I.restart_interval;
+                    const int drop = bitcnt & 7;  // the restart marker (stripped on the host) was byte aligned
+                    bitbuf <<= drop;
+                    bitcnt -= drop;
+                    pred0 = pred1 = pred2 = 0;
+                }
+            }
+            int bx, by;
+            if (blk < yblocks) {
+                comp = 0;
+                const int sub_y = blk / I.hs0;
+                bx = mx * I.hs0 + (blk - sub_y * I.hs0);
+                by = my * I.vs0 + sub_y;
+            } else {
+                comp = 1 + blk - yblocks;
+                bx = mx;
+                by = my;
+            }
+            cblock = coefs + ((size_t)I.coef_blk[comp] + (size_t)by * I.blocks_x[comp] + bx) * 64;
+            tdc = I.td[comp];
+            tac = 2 + I.ta[comp];
+        }
+    }
+    status[img] = st;
+}
+
+// ------------------------------------------------------------------ J2: IDCT ----
+// The "accurate integer" inverse DCT (libjpeg jidctint: Loeffler-Ligtenberg-Moschytz, 13-bit
+// constants, 2 extra bits kept between the passes).  Every shift below is part of the result.
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ void idct_1d(const int in[8], int out[8], const int shift, const bool pass1)
+{
+    constexpr int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
+                  F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+    (void)pass1;
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * F0_541;
+    int tmp2 = z1 + z3 * (-F1_847);
+    int tmp3 = z1 + z2 * F0_765;
+    z2 = in[0]; z3 = in[4];
+    int tmp0 = (z2 + z3) << 13;
+    int tmp1 = (z2 - z3) << 13;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = descale(tmp10 + tmp3, shift); out[7] = descale(tmp10 - tmp3, shift);
+    out[1] = descale(tmp11 + tmp2, shift); out[6] = descale(tmp11 - tmp2, shift);
+    out[2] = descale(tmp12 + tmp1, shift); out[5] = descale(tmp12 - tmp1, shift);
+    out[3] = descale(tmp13 + tmp0, shift); out[4] = descale(tmp13 - tmp0, shift);
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_qt,
+                                                   const int16_t* __restrict__ coefs, const int32_t* __restrict__ status,
+                                                   uint8_t* __restrict__ planes)
+{
+    const int img = blockIdx.y;
+    const JpegImageDev I = imgs[img];
+    if (!I.ok || status[img] != 0) return;
+    const int nb0 = I.blocks_x[0] * I.blocks_y[0];
+    const int nbc = I.ncomp == 3 ? I.blocks_x[1] * I.blocks_y[1] : 0;
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nb0 + 2 * nbc) return;
+    int c = 0;
+    if (j >= nb0) { j -= nb0; c = 1; if (j >= nbc) { j -= nbc; c = 2; } }
+    const int by = j / I.blocks_x[c], bx = j - by * I.blocks_x[c];
+    const int16_t* src = coefs + ((size_t)I.coef_blk[c] + j) * 64;
+    const uint16_t* q = g_qt + ((size_t)img * 4 + I.tq[c]) * 64;
+    int ws[64];
+    // pass 1: columns
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        int in[8], out[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) in[y] = (int)src[y * 8 + x] * (int)q[y * 8 + x];
+        idct_1d(in, out, 13 - 2, true);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) ws[y * 8 + x] = out[y];
+    }
+    // pass 2: rows, descale by 2^(13+2+3), level shift and clamp
+    const int stride = I.blocks_x[c] * 8;
+    uint8_t* dst = planes + I.plane_off[c] + (size_t)(by * 8) * stride + bx * 8;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        int out[8];
+        idct_1d(ws + y * 8, out, 13 + 2 + 3, false);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            lo |= (uint32_t)min(max(out[x] + 128, 0), 255) << (8 * x);
+            hi |= (uint32_t)min(max(out[x + 4] + 128, 0), 255) << (8 * x);
+        }
+        *(uint2*)(dst + (size_t)y * stride) = make_uint2(lo, hi);
+    }
+}
+
+// ------------------------------------------------------ J3: upsample + colour ----
+// "Fancy" upsampling (libjpeg jdsample): a triangle filter, 3/4 nearer sample + 1/4 further one in
+// each direction, with the rounding constant alternating 8, 7 (or 1, 2) so that the bias cancels;
+// at the image border the missing neighbour is the edge sample itself.
+__device__ __forceinline__ int chroma_h2v2(const uint8_t* P, int stride, int cw, int ch, int x, int y)
+{
+    const int cy = y >> 1, cx = x >> 1;
+    const int fy = (y & 1) ? min(cy + 1, ch - 1) : max(cy - 1, 0);
+    const uint8_t* near = P + (size_t)cy * stride;
+    const uint8_t* far = P + (size_t)fy * stride;
+    if (cw <= 2) return near[cx];  // libjpeg falls back to plain replication for very narrow components
+    const int t = 3 * near[cx] + far[cx];
+    if (x & 1) return cx == cw - 1 ? (4 * t + 7) >> 4 : (3 * t + 3 * near[cx + 1] + far[cx + 1] + 7) >> 4;
+    return cx == 0 ? (4 * t + 8) >> 4 : (3 * t + 3 * near[cx - 1] + far[cx - 1] + 8) >> 4;
+}
+__device__ __forceinline__ int chroma_h2v1(const uint8_t* P, int stride, int cw, int x, int y)
+{
+    const uint8_t* row = P + (size_t)y * stride;
+    const int cx = x >> 1, v = row[cx];
+    if (cw <= 2) return v;
+    if (x & 1) return cx == cw - 1 ? v : (3 * v + row[cx + 1] + 2) >> 2;
+    return cx == 0 ? v : (3 * v + row[cx - 1] + 1) >> 2;
+}
+
+// YCbCr -> RGB with libjpeg's 16-bit fixed-point tables (jdcolor): the rounding term sits in the
+// Cb part of the green sum, right shifts are arithmetic.
+__device__ __forceinline__ uint32_t ycc_to_bgr(int y, int cb, int cr)
+{
+    cb -= 128; cr -= 128;
+    const int r = y + ((91881 * cr + 32768) >> 16);
+    const int g = y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    const int b = y + ((116130 * cb + 32768) >> 16);
+    return (uint32_t)min(max(b, 0), 255) | ((uint32_t)min(max(g, 0), 255) << 8) | ((uint32_t)min(max(r, 0), 255) << 16);
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_color(const JpegImageDev* __restrict__ imgs, const int32_t* __restrict__ status,
+                                                    const uint8_t* __restrict__ planes, int H, int W,
+                                                    uint8_t* __restrict__ frames)
+{
+    const int img = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= W) return;
+    const JpegImageDev I = imgs[img];
+    uint8_t* out = frames + ((size_t)img * H + y) * W * 3 + (size_t)x0 * 3;
+    const int npx = min(4, W - x0);
+    if (!I.ok || status[img] != 0) {
+        for (int k = 0; k < npx * 3; ++k) out[k] = 0;
+        return;
+    }
+    const uint8_t* Y = planes + I.plane_off[0];
+    const int ys = I.blocks_x[0] * 8;
+    uint32_t px[4] = {0, 0, 0, 0};
+    if (I.ncomp == 1) {
+        for (int k = 0; k < npx; ++k) { const uint32_t v = Y[(size_t)y * ys + x0 + k]; px[k] = v | (v << 8) | (v << 16); }
+    } else {
+        const uint8_t* Cb = planes + I.plane_off[1];
+        const uint8_t* Cr = planes + I.plane_off[2];
+        const int cs = I.blocks_x[1] * 8;
+        const int cw = (W + I.hs0 - 1) / I.hs0, ch = (H + I.vs0 - 1) / I.vs0;
+        for (int k = 0; k < npx; ++k) {
+            const int x = x0 + k;
+            int cb, cr;
+            if (I.hs0 == 2 && I.vs0 == 2) { cb = chroma_h2v2(Cb, cs, cw, ch, x, y); cr = chroma_h2v2(Cr, cs, cw, ch, x, y); }
+            else if (I.hs0 == 2) { cb = chroma_h2v1(Cb, cs, cw, x, y); cr = chroma_h2v1(Cr, cs, cw, x, y); }
+            else { cb = Cb[(size_t)y * cs + x]; cr = Cr[(size_t)y * cs + x]; }
+            px[k] = ycc_to_bgr(Y[(size_t)y * ys + x], cb, cr);
+        }
+    }
+    if (npx == 4 && ((W * 3) & 3) == 0) {  // 12 bytes, dword aligned
+        uint32_t* o = (uint32_t*)out;
+        o[0] = px[0] | (px[1] << 24);
+        o[1] = (px[1] >> 8) | (px[2] << 16);
+        o[2] = (px[2] >> 16) | (px[3] << 8);
+    } else {
+        for (int k = 0; k < npx; ++k) { out[3 * k] = px[k] & 255; out[3 * k + 1] = (px[k] >> 8) & 255; out[3 * k + 2] = (px[k] >> 16) & 255; }
+    }
+}
+
+// ------------------------------------------------------------------ workspace ----
+struct JpegWorkspace {
+    uint8_t* h_stage = nullptr;  // pinned: records, tables and clean scans of one batch
+    size_t h_cap = 0;
+    uint8_t* d_stage = nullptr;
+    size_t d_cap = 0;
+    int16_t* d_coefs = nullptr;
+    size_t coef_cap = 0;  // int16 elements
+    uint8_t* d_planes = nullptr;
+    size_t plane_cap = 0;
+    int32_t* d_status = nullptr;
+    size_t status_cap = 0;
+    // layout of the current batch inside the stage buffers
+    size_t off_imgs = 0, off_qt = 0, off_look = 0, off_slow = 0, off_scan = 0, total = 0;
+    size_t coef_elems = 0, plane_bytes = 0;
+    int max_blocks = 0;
+};
+
+void jpeg_workspace_free(JpegWorkspace* w)
+{
+    if (!w) return;
+    if (w->h_stage) (void)hipHostFree(w->h_stage);
+    if (w->d_stage) (void)hipFree(w->d_stage);
+    if (w->d_coefs) (void)hipFree(w->d_coefs);
+    if (w->d_planes) (void)hipFree(w->d_planes);
+    if (w->d_status) (void)hipFree(w->d_status);
+    delete w;
+}
+
+template <class T>
+static hipError_t grow_dev(T** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t want = need + need / 4;
+    hipError_t e = hipMalloc((void**)p, want * sizeof(T));
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Host half of a batch: parse every file, lay the batch out, fill the pinned stage buffer.
+// host_status[i]: 0 = handed to the GPU, 1 = valid but unsupported, 2 = unreadable, 3 = other size.
+int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                       int32_t* host_status, std::string* err)
+{
+    if (!*pws) *pws = new JpegWorkspace();
+    JpegWorkspace* w = *pws;
+    std::vector<JpegHeader> hdr(n);
+    std::vector<size_t> scan_off(n + 1, 0);
+    const int nthreads = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, n / 16 + 1}));
+    auto par_for = [&](auto fn) {
+        if (nthreads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t]() { for (int i = t; i < n; i += nthreads) fn(i); });
+        for (auto& x : th) x.join();
+    };
+    par_for([&](int i) {
+        JpegHeader& h = hdr[i];
+        if (!data[i] || parse_headers(data[i], sizes[i], h) != 0) { host_status[i] = 2; return; }
+        if (h.why) { host_status[i] = 1; return; }
+        if (h.H != H || h.W != W) { host_status[i] = 3; return; }
+        host_status[i] = 0;
+    });
+    // layout
+    size_t coef_blocks = 0, plane_bytes = 0;
+    int max_blocks = 0;
+    std::vector<JpegImageDev> rec(n);
+    for (int i = 0; i < n; ++i) {
+        JpegImageDev& r = rec[i];
+        memset(&r, 0, sizeof(r));
+        scan_off[i + 1] = scan_off[i];
+        if (host_status[i] != 0) continue;
+        const JpegHeader& h = hdr[i];
+        r.ok = 1;
+        r.ncomp = (uint8_t)h.ncomp; r.hs0 = (uint8_t)h.hs[0]; r.vs0 = (uint8_t)h.vs[0];
+        r.restart_interval = (uint16_t)h.restart_interval;
+        r.mcus_x = (uint16_t)((W + 8 * h.hs[0] - 1) / (8 * h.hs[0]));
+        r.mcus_y = (uint16_t)((H + 8 * h.vs[0] - 1) / (8 * h.vs[0]));
+        int blocks = 0;
+        for (int c = 0; c < h.ncomp; ++c) {
+            r.tq[c] = (uint8_t)h.tq[c]; r.td[c] = (uint8_t)h.td[c]; r.ta[c] = (uint8_t)h.ta[c];
+            r.blocks_x[c] = (uint16_t)(r.mcus_x * (c == 0 ? h.hs[0] : 1));
+            r.blocks_y[c] = (uint16_t)(r.mcus_y * (c == 0 ? h.vs[0] : 1));
+            r.coef_blk[c] = (uint32_t)coef_blocks;
+            r.plane_off[c] = (uint32_t)plane_bytes;
+            const size_t nb = (size_t)r.blocks_x[c] * r.blocks_y[c];
+            coef_blocks += nb;
+            plane_bytes += nb * 64;
+            blocks += (int)nb;
+        }
+        max_blocks = std::max(max_blocks, blocks);
+        scan_off[i + 1] = scan_off[i] + align_up(sizes[i] - h.scan_begin + 16, 16);
+    }
+    if (coef_blocks >= (1ull << 32) / 64 || plane_bytes >= (1ull << 32) || scan_off[n] >= (1ull << 32)) {
+        if (err) *err = "JPEG batch too large for 32-bit offsets; decode in smaller batches";
+        return MELF_ERR_TOO_LARGE;
+    }
+    w->off_imgs = 0;
+    w->off_qt = align_up(w->off_imgs + (size_t)n * sizeof(JpegImageDev), 256);
+    w->off_look = align_up(w->off_qt + (size_t)n * 4 * 64 * sizeof(uint16_t), 256);
+    w->off_slow = align_up(w->off_look + (size_t)n * 4 * 256 * sizeof(uint16_t), 256);
+    w->off_scan = align_up(w->off_slow + (size_t)n * 4 * sizeof(HuffSlow), 256);
+    w->total = w->off_scan + scan_off[n] + 64;
+    w->coef_elems = coef_blocks * 64;
+    w->plane_bytes = plane_bytes;
+    w->max_blocks = max_blocks;
+    if (w->total > w->h_cap) {
+        if (w->h_stage) (void)hipHostFree(w->h_stage);
+        w->h_stage = nullptr; w->h_cap = 0;
+        const size_t want = w->total + w->total / 4;
+        if (hipHostMalloc((void**)&w->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+            if (err) *err = "hipHostMalloc failed for the JPEG staging buffer";
+            return MELF_ERR_HIP;
+        }
+        w->h_cap = want;
+    }
+    uint8_t* base = w->h_stage;
+    par_for([&](int i) {
+        JpegImageDev& r = rec[i];
+        uint16_t* qt = (uint16_t*)(base + w->off_qt) + (size_t)i * 256;
+        uint16_t* look = (uint16_t*)(base + w->off_look) + (size_t)i * 1024;
+        HuffSlow* slow = (HuffSlow*)(base + w->off_slow) + (size_t)i * 4;
+        if (host_status[i] != 0) {
+            memset(look, 0, 1024 * sizeof(uint16_t));
+            return;
+        }
+        const JpegHeader& h = hdr[i];
+        for (int t = 0; t < 4; ++t) {
+            if (h.qt_set[t]) memcpy(qt + t * 64, h.qt[t], 128); else memset(qt + t * 64, 0, 128);
+        }
+        for (int t = 0; t < 2; ++t) {
+            if (h.dc[t].set) build_huff(h.dc[t], look + t * 256, slow + t); else { memset(look + t * 256, 0, 512); memset(slow + t, 0, sizeof(HuffSlow)); }
+            if (h.ac[t].set) build_huff(h.ac[t], look + (2 + t) * 256, slow + 2 + t); else { memset(look + (2 + t) * 256, 0, 512); memset(slow + 2 + t, 0, sizeof(HuffSlow)); }
+        }
+        uint8_t* dst = base + w->off_scan + scan_off[i];
+        const size_t len = clean_scan(data[i] + h.scan_begin, sizes[i] - h.scan_begin, dst);
+        memset(dst + len, 0, scan_off[i + 1] - scan_off[i] - len);
+        r.scan_off = (uint32_t)scan_off[i];
+        r.scan_len = (uint32_t)len;
+    });
+    memcpy(base + w->off_imgs, rec.data(), (size_t)n * sizeof(JpegImageDev));
+    return MELF_SUCCESS;
+}
+
+// Device half: H2D of the stage buffer, then J1..J3.  `timer(k)` brackets kernel k (0..2) when profiling.
+int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
+                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg)
+{
+#define JTRY(expr)                                                               \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);   \
+            return MELF_ERR_HIP;                                                 \
+        }                                                                        \
+    } while (0)
+    JTRY(grow_dev(&w->d_stage, &w->d_cap, w->total));
+    JTRY(grow_dev(&w->d_coefs, &w->coef_cap, w->coef_elems + 64));
+    JTRY(grow_dev(&w->d_planes, &w->plane_cap, w->plane_bytes + 64));
+    JTRY(grow_dev(&w->d_status, &w->status_cap, (size_t)n));
+    JTRY(hipMemcpyAsync(w->d_stage, w->h_stage, w->total, hipMemcpyHostToDevice, stream));
+    JTRY(hipMemsetAsync(w->d_coefs, 0, w->coef_elems * sizeof(int16_t), stream));
+    JTRY(hipMemsetAsync(w->d_status, 0, (size_t)n * sizeof(int32_t), stream));
+    const JpegImageDev* imgs = (const JpegImageDev*)(w->d_stage + w->off_imgs);
+    const uint16_t* qt = (const uint16_t*)(w->d_stage + w->off_qt);
+    const uint16_t* look = (const uint16_t*)(w->d_stage + w->off_look);
+    const HuffSlow* slow = (const HuffSlow*)(w->d_stage + w->off_slow);
+    const uint8_t* scan = w->d_stage + w->off_scan;
+    if (timer) timer(timer_arg, 0, 0);
+    if (n <= 16 * 1024) {  // 16 images per workgroup (32 KiB of lookup tables): small batches spread over the CUs
+        hipLaunchKernelGGL(k_jpeg_huff<16>, dim3((n + 15) / 16), dim3(16), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
+    } else {
+        hipLaunchKernelGGL(k_jpeg_huff<64>, dim3((n + 63) / 64), dim3(64), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
+    }
+    if (timer) timer(timer_arg, 0, 1);
+    JTRY(hipGetLastError());
+    if (w->max_blocks > 0) {
+        if (timer) timer(timer_arg, 1, 0);
+        hipLaunchKernelGGL(k_jpeg_idct, dim3((w->max_blocks + 255) / 256, n), dim3(256), 0, stream, imgs, qt, w->d_coefs, w->d_status, w->d_planes);
+        if (timer) timer(timer_arg, 1, 1);
+        JTRY(hipGetLastError());
+    }
+    if (timer) timer(timer_arg, 2, 0);
+    hipLaunchKernelGGL(k_jpeg_color, dim3((W + 1023) / 1024, H, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames);
+    if (timer) timer(timer_arg, 2, 1);
+    JTRY(hipGetLastError());
+    if (status_out_host) {
+        JTRY(hipMemcpyAsync(status_out_host, w->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        JTRY(hipStreamSynchronize(stream));
+    }
+    return MELF_SUCCESS;
+#undef JTRY
+}
+
+}  // namespace melf

@@ -41,7 +41,8 @@ extern "C" int melf_device_count(int* count)
 }
 extern "C" const char* melf_kernel_name(int k)
 {
-    static const char* names[MELF_K_COUNT] = {"k_lplane", "k_match", "k_dials", "k_fused_mask", "k_bgr2hls"};
+    static const char* names[MELF_K_COUNT] = {"k_lplane", "k_match", "k_dials", "k_fused_mask", "k_bgr2hls",
+                                               "k_jpeg_huff", "k_jpeg_idct", "k_jpeg_color"};
     return (k >= 0 && k < MELF_K_COUNT) ? names[k] : "?";
 }
 
@@ -240,6 +241,7 @@ struct melf_ctx {
     size_t stage_in_cap = 0;
     uint8_t* d_stage_out = nullptr;
     size_t stage_out_cap = 0;
+    JpegWorkspace* jpeg = nullptr;     // created by the first JPEG batch
     // profiling
     bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
     bool profiling = false;
@@ -460,6 +462,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
+    jpeg_workspace_free(c->jpeg);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -808,4 +811,89 @@ extern "C" int melf_inrange(melf_ctx* c, const uint8_t* img_host, int rows, int 
     HIP_TRY(hipMemcpyAsync(mask_host, c->d_stage_out, npx, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MELF_SUCCESS;
+}
+
+// ------------------------------------------------------------ JPEG decode ----
+extern "C" int melf_jpeg_probe(const uint8_t* data, size_t size, int32_t* H, int32_t* W, int32_t* supported)
+{
+    if (!data || !H || !W || !supported) return fail(MELF_ERR_INVALID, "bad argument");
+    int h = 0, w = 0, ok = 0;
+    std::string why;
+    jpeg_probe(data, size, &h, &w, &ok, &why);
+    *H = h; *W = w; *supported = ok;
+    g_err = why;
+    return MELF_SUCCESS;
+}
+
+namespace {
+struct JpegTimers {
+    melf_ctx* c;
+    hipStream_t s;
+    TimedEvent ev[3];
+    bool on[3];
+};
+void jpeg_timer_hook(void* arg, int k, int stop)
+{
+    JpegTimers* t = (JpegTimers*)arg;
+    if (!t->c->profiling) return;
+    if (!stop) {
+        t->ev[k].kernel = MELF_K_JPEG_HUFF + k;
+        t->on[k] = hipEventCreate(&t->ev[k].start) == hipSuccess && hipEventCreate(&t->ev[k].stop) == hipSuccess;
+        if (t->on[k]) hipEventRecord(t->ev[k].start, t->s);
+    } else if (t->on[k]) {
+        hipEventRecord(t->ev[k].stop, t->s);
+        t->c->events.push_back(t->ev[k]);
+    }
+}
+
+// decode into device memory `d_frames` (n*H*W*3 bytes) on the context's stream; fills status (host)
+int jpeg_decode_to_device(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                          uint8_t* d_frames, int32_t* status)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned stage buffer of the previous batch is free again
+    std::vector<int32_t> hstat(n);
+    std::string err;
+    if (int rc = jpeg_prepare_batch(&c->jpeg, data, sizes, n, H, W, hstat.data(), &err)) return fail(rc, err);
+    std::vector<int32_t> dstat(n);
+    JpegTimers t{c, c->stream, {}, {false, false, false}};
+    if (int rc = jpeg_launch_batch(c->jpeg, n, H, W, d_frames, dstat.data(), c->stream, &err, jpeg_timer_hook, &t)) return fail(rc, err);
+    for (int i = 0; i < n; ++i) status[i] = hstat[i] ? hstat[i] : (dstat[i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
+    return MELF_SUCCESS;
+}
+}  // namespace
+
+extern "C" int melf_jpeg_decode_batch(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                                      void* out, int out_on_device, int32_t* status)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (n == 0) return MELF_SUCCESS;
+    if (!data || !sizes || !out || !status || n < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || n > 32768)
+        return fail(MELF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * H * W * 3;
+    uint8_t* d = (uint8_t*)out;
+    if (!out_on_device) {
+        if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
+        d = c->d_stage_in;
+    }
+    if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, d, status)) return rc;
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                                       melf_result* out_host, int32_t* status)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (n == 0) return MELF_SUCCESS;
+    if (!data || !sizes || !out_host || !status || n < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || n > 32768)
+        return fail(MELF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * H * W * 3;
+    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
+    if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, c->d_stage_in, status)) return rc;
+    return melf_process_batch_dev(c, c->d_stage_in, n, H, W, (size_t)H * W * 3, nullptr, out_host, c->stream);
 }

@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libmeterelf_hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <string>
 #include <stdint.h>
 
 #include "../../include/meterelf_hip.h"
@@ -97,5 +98,14 @@ void launch_aligned_average(const uint8_t* d_frames, int n, size_t frame_stride,
                             int cols, const int32_t* d_mx, const int32_t* d_my, int ax, int ay, uint8_t* d_out,
                             hipStream_t stream);
 void launch_inrange3(const uint8_t* d_img, int npx, const int lo[3], const int hi[3], uint8_t* d_out, hipStream_t stream);
+
+// ---- k_jpeg.hip: baseline JPEG decode ----
+struct JpegWorkspace;
+int jpeg_probe(const uint8_t* data, size_t size, int* H, int* W, int* supported, std::string* why);
+int jpeg_prepare_batch(JpegWorkspace** ws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                       int32_t* host_status, std::string* err);
+int jpeg_launch_batch(JpegWorkspace* ws, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
+                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg);
+void jpeg_workspace_free(JpegWorkspace* ws);
 
 }  // namespace melf

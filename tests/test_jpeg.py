@@ -1,0 +1,201 @@
+"""JPEG decode on the GPU against libjpeg-turbo (Pillow), the decoder
+whose output the reference's goldens were produced from (cv2.imread uses the same libjpeg defaults:
+ISLOW IDCT, fancy upsampling).  Bar: every byte of every frame identical.
+
+CPU part: the header probe (no GPU needed).  GPU part: all 304 fixture files, synthetic files over
+sampling modes / qualities / odd sizes / restart intervals / greyscale, corrupt and unsupported input,
+and the end-to-end path (JPEG bytes -> values) against the golden stdout.
+"""
+import glob
+import io
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _files(sd):
+    return sorted(glob.glob(os.path.join(GOLDEN, sd, '*.jpg')))
+
+
+def _pillow_bgr(data):
+    from PIL import Image
+    with Image.open(io.BytesIO(data)) as im:
+        rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def _encode(img_rgb, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img_rgb).save(buf, 'JPEG', **kw)
+    return buf.getvalue()
+
+
+def _natural_image(rng, H, W):
+    """Smooth gradients + blobs + some noise: exercises long and short Huffman codes."""
+    (yy, xx) = np.mgrid[0:H, 0:W]
+    img = np.zeros((H, W, 3), np.float64)
+    for c in range(3):
+        img[..., c] = 128 + 100 * np.sin(xx / (7.0 + 5 * c) + rng.uniform(0, 6)) * np.cos(yy / (11.0 + 3 * c))
+    for _ in range(6):
+        (cy, cx, r) = (rng.integers(0, H), rng.integers(0, W), rng.integers(3, max(4, min(H, W) // 3)))
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = rng.integers(0, 256, 3)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ CPU: probe ----
+def test_probe_fixture_headers():
+    from meterelf_amd import _hip
+    for (sd, hw) in (('sample-images1', None), ('sample-images2', (640, 480))):
+        for f in _files(sd):
+            data = open(f, 'rb').read()
+            (H, W, ok, why) = _hip.jpeg_probe(data)
+            ref = _pillow_bgr(data).shape[:2]
+            assert (H, W) == ref and ok, (f, H, W, ok, why)
+            if hw:
+                assert (H, W) == hw
+
+
+def test_probe_rejects_what_the_decoder_does_not_handle():
+    from meterelf_amd import _hip
+    rng = np.random.default_rng(5)
+    img = _natural_image(rng, 48, 64)
+    (H, W, ok, why) = _hip.jpeg_probe(_encode(img, progressive=True))
+    assert (H, W) == (48, 64) and not ok and 'progressive' in why
+    (H, W, ok, why) = _hip.jpeg_probe(_encode(img, quality=90))
+    assert (H, W, ok) == (48, 64, True)
+    (H, W, ok, why) = _hip.jpeg_probe(_encode(img[..., 0]))  # greyscale
+    assert (H, W, ok) == (48, 64, True)
+    (H, W, ok, why) = _hip.jpeg_probe(b'not a jpeg at all')
+    assert not ok
+    (H, W, ok, why) = _hip.jpeg_probe(_encode(img)[:100])
+    assert not ok
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.dstack([img, img[..., :1]]), 'CMYK').save(buf, 'JPEG')
+    (H, W, ok, why) = _hip.jpeg_probe(buf.getvalue())
+    assert not ok
+
+
+# ------------------------------------------------------------------ GPU ----
+@pytest.fixture(scope='module')
+def ctx():
+    from meterelf_amd import _hip
+    if _hip.device_count() < 1:
+        pytest.fail('GPU tests need an MI355X: no HIP device visible (no CPU fallback exists)')
+    from meterelf_amd import MeterReader, _params
+    reader = MeterReader(_params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml')))
+    yield reader.ctx
+    reader.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])
+def test_fixture_files_decode_like_libjpeg(ctx, sd):
+    from meterelf_amd import _hip
+    by_shape = {}
+    for f in _files(sd):
+        data = open(f, 'rb').read()
+        by_shape.setdefault(_hip.jpeg_probe(data)[:2], []).append((f, data))
+    total = 0
+    for ((H, W), items) in by_shape.items():
+        (frames, status) = ctx.jpeg_decode([d for (_, d) in items], H, W)
+        assert (status == 0).all(), status
+        for ((f, d), got) in zip(items, frames):
+            ref = _pillow_bgr(d)
+            assert np.array_equal(got, ref), (f, int((got != ref).sum()), np.argwhere(got != ref)[:3])
+            total += 1
+    assert total == len(_files(sd))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('subsampling', ['4:4:4', '4:2:2', '4:2:0'])
+@pytest.mark.parametrize('shape', [(64, 64), (480, 640), (251, 333), (17, 23), (8, 8), (100, 7), (33, 1024)])
+def test_synthetic_files(ctx, subsampling, shape):
+    (H, W) = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    files = []
+    for (q, opt) in ((35, False), (75, True), (92, False), (100, True)):
+        files.append(_encode(_natural_image(rng, H, W), quality=q, subsampling=subsampling, optimize=opt))
+    files.append(_encode(rng.integers(0, 256, (H, W, 3), dtype=np.uint8), quality=97, subsampling=subsampling))
+    files.append(_encode(np.full((H, W, 3), 255, np.uint8), quality=50, subsampling=subsampling))
+    (frames, status) = ctx.jpeg_decode(files, H, W)
+    assert (status == 0).all(), status
+    for (i, (d, got)) in enumerate(zip(files, frames)):
+        ref = _pillow_bgr(d)
+        assert np.array_equal(got, ref), (i, int((got != ref).sum()), np.argwhere(got != ref)[:3])
+
+
+@pytest.mark.gpu
+def test_restart_intervals_and_greyscale(ctx):
+    rng = np.random.default_rng(77)
+    (H, W) = (120, 200)
+    img = _natural_image(rng, H, W)
+    files = [_encode(img, quality=80, subsampling='4:2:0', restart_marker_blocks=3),
+             _encode(img, quality=80, subsampling='4:4:4', restart_marker_rows=1),
+             _encode(img, quality=60, subsampling='4:2:2', restart_marker_blocks=1),
+             _encode(img[..., 1], quality=85),
+             _encode(img[..., 2], quality=40, restart_marker_blocks=5)]
+    assert b'\xff\xdd' in files[0]
+    (frames, status) = ctx.jpeg_decode(files, H, W)
+    assert (status == 0).all(), status
+    for (i, (d, got)) in enumerate(zip(files, frames)):
+        ref = _pillow_bgr(d)
+        assert np.array_equal(got, ref), (i, int((got != ref).sum()), np.argwhere(got != ref)[:3])
+
+
+@pytest.mark.gpu
+def test_bad_input_is_reported_per_file(ctx):
+    from meterelf_amd import _hip
+    rng = np.random.default_rng(3)
+    (H, W) = (64, 96)
+    img = _natural_image(rng, H, W)
+    good = _encode(img, quality=85)
+    truncated = good[:len(good) // 2]
+    files = [good, _encode(img, progressive=True), b'garbage', _encode(_natural_image(rng, 32, 32)), truncated, good]
+    (frames, status) = ctx.jpeg_decode(files, H, W)
+    assert list(status[:4]) == [_hip.JPEG_OK, _hip.JPEG_UNSUPPORTED, _hip.JPEG_CORRUPT, _hip.JPEG_SIZE_MISMATCH]
+    assert status[4] in (_hip.JPEG_CORRUPT, _hip.JPEG_OK)  # a truncated scan may still fill every block
+    assert status[5] == _hip.JPEG_OK
+    assert np.array_equal(frames[0], _pillow_bgr(good)) and np.array_equal(frames[5], frames[0])
+    assert not frames[1].any() and not frames[2].any() and not frames[3].any()
+
+
+@pytest.mark.gpu
+def test_large_batch_of_mixed_files(ctx):
+    """More files than one decode workgroup holds, mixed sampling modes in one batch."""
+    rng = np.random.default_rng(11)
+    (H, W) = (96, 128)
+    base = [_encode(_natural_image(rng, H, W), quality=int(rng.integers(30, 98)),
+                    subsampling=['4:2:0', '4:2:2', '4:4:4'][i % 3], optimize=bool(i & 1)) for i in range(12)]
+    files = [base[i % len(base)] for i in range(200)]
+    (frames, status) = ctx.jpeg_decode(files, H, W)
+    assert (status == 0).all()
+    refs = [_pillow_bgr(d) for d in base]
+    for (i, got) in enumerate(frames):
+        assert np.array_equal(got, refs[i % len(base)]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])
+def test_jpeg_bytes_to_values_match_host_decode_path(sd):
+    """melf_jpeg_process_batch (decode + read on the GPU) gives the records of the host-decode path."""
+    from meterelf_amd import MeterReader, _hip, _params
+    from meterelf_amd._image import imread_bgr
+    reader = MeterReader(_params.load(os.path.join(GOLDEN, sd, 'params.yml')))
+    try:
+        by_shape = {}
+        for f in _files(sd):
+            data = open(f, 'rb').read()
+            by_shape.setdefault(_hip.jpeg_probe(data)[:2], []).append((f, data))
+        for ((H, W), items) in by_shape.items():
+            (recs, status) = reader.ctx.jpeg_process_batch([d for (_, d) in items], H, W)
+            assert (status == 0).all()
+            ref = reader.read_frames(np.stack([imread_bgr(f) for (f, _) in items]))
+            assert recs.tobytes() == ref.tobytes()
+    finally:
+        reader.close()
