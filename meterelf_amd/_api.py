@@ -4,9 +4,12 @@
 
 Lazy, yields in input order, per-image ImageProcessingError becomes the `error`
 field (re-raised only when DEBUG is set).  Unlike the reference's one-at-a-time
-loop, files are decoded and sent to the GPU in chunks (METERELF_BATCH, default
-64), so up to one chunk is read ahead of the consumer; the JPEG decode of a chunk
-(host work, cv2.imread in the reference) runs on a small thread pool
+loop, files go to the GPU in chunks (METERELF_BATCH, default 256), so up to one
+chunk is read ahead of the consumer.
+
+cv2.imread of the reference (meterelf/_image.py:49): baseline JPEG files are decoded on the
+GPU (METERELF_DECODE=gpu, the default; bit-identical to libjpeg's defaults); any other file, and
+everything when METERELF_DECODE=host, is decoded on the host by Pillow on a small thread pool
 (METERELF_DECODE_THREADS, default min(8, cpu count); Pillow releases the GIL).
 """
 import os
@@ -39,7 +42,8 @@ def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
 
 def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[MeterImageData]:
     params = _params.load(params_file)
-    batch = max(1, int(os.getenv('METERELF_BATCH', '64')))
+    gpu_decode = os.getenv('METERELF_DECODE', 'gpu') != 'host'
+    batch = max(1, int(os.getenv('METERELF_BATCH', '256' if gpu_decode else '64')))
     if _debug.DEBUG:
         batch = 1  # DEBUG re-raises at the failing file, before any later file is touched
     reader: Optional[MeterReader] = None
@@ -52,15 +56,33 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         except ImageProcessingError as e:
             return e
 
+    def _read_bytes(filename: str) -> Optional[bytes]:
+        try:
+            with open(filename, 'rb') as fp:
+                return fp.read()
+        except OSError:
+            return None
+
     try:
         for chunk in _chunks(filenames, batch):
             if reader is None:
                 reader = MeterReader(params)
             assert len(reader.dial_names) == 4  # meterelf/_reading.py:166
             errors: Dict[int, ImageProcessingError] = {}
+            by_index: Dict[int, object] = {}
+            on_host = list(range(len(chunk)))
+            if gpu_decode:
+                blobs = [_read_bytes(f) for f in chunk]
+                have = [i for (i, b) in enumerate(blobs) if b]
+                recs = reader.read_jpeg_files([blobs[i] for i in have]) if have else []
+                for (i, rec) in zip(have, recs):
+                    if rec is not None:
+                        by_index[i] = rec
+                on_host = [i for i in range(len(chunk)) if i not in by_index]
             frames, where = [], []
-            decoded = list(pool.map(_decode, chunk)) if pool is not None else [_decode(f) for f in chunk]
-            for (i, item) in enumerate(decoded):
+            host_files = [chunk[i] for i in on_host]
+            decoded = list(pool.map(_decode, host_files)) if pool is not None else [_decode(f) for f in host_files]
+            for (i, item) in zip(on_host, decoded):
                 if isinstance(item, ImageProcessingError):
                     errors[i] = item
                     if _debug.DEBUG:
@@ -69,7 +91,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                     frames.append(item)
                     where.append(i)
             records = reader.read_many(frames) if frames else []
-            by_index = dict(zip(where, records))
+            by_index.update(zip(where, records))
             for (i, filename) in enumerate(chunk):
                 meter_values: Dict[str, float] = {}
                 error = errors.get(i)

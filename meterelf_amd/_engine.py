@@ -78,6 +78,23 @@ class MeterReader:
             ctx = self._crop_ctx[(h, w)] = _hip.Context(blob, self.device)
         return ctx.process_batch(crops)
 
+    def read_jpeg_files(self, files: List[bytes]) -> List[Optional[np.void]]:
+        """JPEG files' bytes -> records, decoded and read on the GPU (melf_jpeg_process_batch).
+        None for a file the GPU decoder does not take (not a baseline JPEG, corrupt): the caller
+        decodes that one on the host."""
+        out: List[Optional[np.void]] = [None] * len(files)
+        groups: Dict[Tuple[int, int], List[int]] = {}
+        for (i, data) in enumerate(files):
+            (h, w, ok, _why) = _hip.jpeg_probe(data)
+            if ok:
+                groups.setdefault((h, w), []).append(i)
+        for ((h, w), idxs) in groups.items():
+            (recs, status) = self.ctx.jpeg_process_batch([files[i] for i in idxs], h, w)
+            for (k, i) in enumerate(idxs):
+                if status[k] == _hip.JPEG_OK:
+                    out[i] = recs[k]
+        return out
+
     def read_many(self, images: List[np.ndarray], cropped: Optional[List[bool]] = None) -> List[np.void]:
         """Heterogeneous list of frames: grouped by shape, one batched call per group."""
         cropped = cropped or [False] * len(images)

@@ -199,11 +199,16 @@ struct JpegImageDev {
 };
 static_assert(sizeof(JpegImageDev) % 4 == 0, "record must stay dword aligned");
 
-struct HuffSlow {  // codes longer than 8 bits: canonical decode (JPEG spec F.2.2.3)
-    int32_t maxcode[18];  // maxcode[l] = largest code of length l, -1 if none
-    int32_t valoff[18];   // huffval index of the first code of length l, minus that code
+struct HuffSlow {  // codes longer than 8 bits: canonical decode (JPEG spec F.2.2.3), lengths 9..16
+    // limit[l - 9]: the canonical code counter after the codes of length l (one past the largest code of
+    // length l, carried over from shorter lengths if there is none).  A 16-bit window's l-bit prefix is
+    // below limit[l] exactly for l >= the code's length, so the length is 9 + the number of l with
+    // prefix >= limit[l]: eight independent compares, no data-dependent loop.
+    uint32_t limit[8];
+    int32_t valoff[8];  // huffval index of the first code of length l, minus that code
     uint8_t huffval[256];
 };
+static_assert(sizeof(HuffSlow) == 320, "HuffSlow is copied to LDS as 80 dwords");
 
 static void build_huff(const HuffSpec& t, uint16_t* look /* 256 */, HuffSlow* slow)
 {
@@ -212,17 +217,16 @@ static void build_huff(const HuffSpec& t, uint16_t* look /* 256 */, HuffSlow* sl
     memcpy(slow->huffval, t.vals, t.nvals);
     int code = 0, p = 0;
     for (int l = 1; l <= 16; ++l) {
-        slow->valoff[l] = p - code;
+        if (l >= 9) slow->valoff[l - 9] = p - code;
         for (int k = 0; k < t.bits[l]; ++k, ++p, ++code) {
             if (l <= 8 && p < 256) {
                 const int first = (code << (8 - l)) & 255, cnt = 1 << (8 - l);
                 for (int q = 0; q < cnt; ++q) look[(first + q) & 255] = (uint16_t)((l << 8) | t.vals[p]);
             }
         }
-        slow->maxcode[l] = t.bits[l] ? code - 1 : -1;
+        if (l >= 9) slow->limit[l - 9] = (uint32_t)code;
         code <<= 1;
     }
-    slow->maxcode[17] = 0x7fffffff;
 }
 
 // Copies the entropy-coded segment without byte stuffing (FF 00 -> FF), fill bytes and RSTn markers;
@@ -255,81 +259,99 @@ __device__ __constant__ uint8_t c_zz2nat[64] = {
     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // One lane per image.  The loop is a flat state machine -- one Huffman symbol per iteration whatever
-// block or coefficient the lane is at -- so lanes stay busy although their images differ; the 8-bit
-// first-level lookup tables of the block's images live in LDS, longer codes take the canonical path.
+// block or coefficient the lane is at -- so lanes stay busy although their images differ.  All decode
+// tables of the workgroup's images live in LDS (8-bit first-level lookup, canonical limits for longer
+// codes); the bit stream is read as aligned dwords two words ahead of the bit buffer.
 template <int IPB>
 __global__ __launch_bounds__(IPB) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_look,
                                                    const HuffSlow* __restrict__ g_slow, const uint8_t* __restrict__ scan,
                                                    int n, int16_t* __restrict__ coefs, int32_t* __restrict__ status)
 {
-    __shared__ uint16_t look[IPB * 1024];  // [image in block][table dc0, dc1, ac0, ac1][256]
+    __shared__ uint16_t look[IPB * 1024];   // [image in block][table dc0, dc1, ac0, ac1][256]
+    __shared__ uint32_t slow[IPB * 4 * 80];  // [image in block][table] HuffSlow
     __shared__ uint8_t nat[64];
+    __shared__ __attribute__((aligned(16))) uint32_t sbuf[IPB * 16];  // 64 bytes of bit stream per lane
     const int lane = threadIdx.x;
     const int img = blockIdx.x * IPB + lane;
     {
+        const int here = min(IPB, n - blockIdx.x * IPB);
         const uint32_t* src = (const uint32_t*)(g_look + (size_t)blockIdx.x * IPB * 1024);
-        const int avail = min(IPB, n - blockIdx.x * IPB) * 512;
         uint32_t* dst = (uint32_t*)look;
-        for (int i = lane; i < IPB * 512; i += IPB) dst[i] = i < avail ? src[i] : 0u;
-        if (lane < 64) nat[lane] = c_zz2nat[lane];
-        if (IPB < 64) for (int i = lane; i < 64; i += IPB) nat[i] = c_zz2nat[i];
+        for (int i = lane; i < IPB * 512; i += IPB) dst[i] = i < here * 512 ? src[i] : 0u;
+        const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)blockIdx.x * IPB * 4);
+        for (int i = lane; i < IPB * 320; i += IPB) slow[i] = i < here * 320 ? ssrc[i] : 0u;
+        for (int i = lane; i < 64; i += IPB) nat[i] = c_zz2nat[i];
     }
     __syncthreads();
     if (img >= n) return;
-    const JpegImageDev I = imgs[img];
-    if (!I.ok) { status[img] = 1; return; }
-    const uint8_t* p = scan + I.scan_off;
-    const uint32_t limit = I.scan_len + 8;  // the scan area is zero-padded by 16 bytes per image
+    // every field goes into its own register: indexing the record by component would put it in scratch
+    const JpegImageDev* R = imgs + img;
+    if (!R->ok) { status[img] = 1; return; }
+    const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x, restart_interval = R->restart_interval;
+    const uint32_t cblk0 = R->coef_blk[0], cblk1 = R->coef_blk[1], cblk2 = R->coef_blk[2];
+    const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
+    const int td0 = R->td[0], td1 = R->td[1], td2 = R->td[2];
+    const int ta0 = 2 + R->ta[0], ta1 = 2 + R->ta[1], ta2 = 2 + R->ta[2];
+    const uint4* p = (const uint4*)(scan + R->scan_off);  // 64-byte aligned, zero-padded by >= 128 bytes
+    const uint32_t nchunks = R->scan_len / 64 + 2;         // 64-byte chunks inside the padded area
     const uint16_t* mylook = look + lane * 1024;
-    const HuffSlow* myslow = g_slow + (size_t)img * 4;
+    const uint32_t* myslow = slow + lane * 320;
 
-    uint64_t bitbuf = 0;
-    int bitcnt = 0;
-    uint32_t pos = 0;
-    const int total_mcus = (int)I.mcus_x * I.mcus_y;
-    const int yblocks = I.ncomp == 1 ? 1 : I.hs0 * I.vs0;
-    const int blocks_per_mcu = I.ncomp == 1 ? 1 : yblocks + 2;
+    const int total_mcus = mcus_x * (int)R->mcus_y;
+    const int yblocks = ncomp == 1 ? 1 : hs0 * vs0;
+    const int blocks_per_mcu = ncomp == 1 ? 1 : yblocks + 2;
     int mcu = 0, mx = 0, my = 0, blk = 0, k = 0, comp = 0;
     int pred0 = 0, pred1 = 0, pred2 = 0;
-    int restarts_left = I.restart_interval;
-    int16_t* cblock = coefs + (size_t)I.coef_blk[0] * 64;
-    int tdc = I.td[0], tac = 2 + I.ta[0];
+    int restarts_left = restart_interval;
+    int16_t* cblock = coefs + (size_t)cblk0 * 64;
+    int tdc = td0, tac = ta0;
     int32_t st = 0;
+
+    // Bit buffer: the top `bitcnt` bits are valid.  The stream comes in 64-byte chunks, loaded on demand
+    // into the lane's LDS slot and consumed a dword per refill.  No load stays in flight across loop
+    // iterations: gfx9 counts loads and stores in one vmcnt, so a pending load would make every iteration
+    // wait for the coefficient stores; this way the wait comes once per 64 bytes (~100 symbols).
+    uint32_t* mybuf = sbuf + lane * 16;
+    uint32_t chunk = 0;
+    int sub = 16;
+    uint64_t bitbuf = 0;
+    int bitcnt = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the record's fields are in registers before the loop starts
 
     while (mcu < total_mcus) {
         if (bitcnt <= 32) {
-            const uint8_t* q = p + pos;
-            const uint32_t w = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
-            bitbuf |= (uint64_t)w << (32 - bitcnt);
+            if (sub == 16) {
+                if (chunk >= nchunks) { st = 2; break; }  // ran past the data: truncated or corrupt
+                const uint4* q = p + (size_t)chunk * 4;
+                const uint4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+                ((uint4*)mybuf)[0] = c0; ((uint4*)mybuf)[1] = c1; ((uint4*)mybuf)[2] = c2; ((uint4*)mybuf)[3] = c3;
+                ++chunk;
+                sub = 0;
+            }
+            const uint32_t raw32 = mybuf[sub++];
+            bitbuf |= (uint64_t)__builtin_bswap32(raw32) << (32 - bitcnt);
             bitcnt += 32;
-            pos += 4;
-            if (pos > limit) { st = 2; break; }  // ran past the data: truncated or corrupt
         }
+        const uint32_t w = (uint32_t)(bitbuf >> 32);  // the next 32 bits: code + magnitude fit (<= 16 + 15)
         const int t = k == 0 ? tdc : tac;
-        const uint32_t e = mylook[t * 256 + (uint32_t)(bitbuf >> 56)];
-        int len, sym;
-        if (e) {
-            len = e >> 8;
-            sym = e & 255;
-        } else {
-            const HuffSlow* s = myslow + t;
-            const int code16 = (int)(bitbuf >> 48);
+        const uint32_t e = mylook[t * 256 + (w >> 24)];
+        int len = e >> 8, sym = e & 255;
+        if (!e) {
+            const uint32_t* s = myslow + t * 80;
+            const uint32_t code16 = w >> 16;
             len = 9;
-            while (len <= 16 && (code16 >> (16 - len)) > s->maxcode[len]) ++len;
+#pragma unroll
+            for (int l = 9; l <= 16; ++l) len += (code16 >> (16 - l)) >= s[l - 9] ? 1 : 0;
             if (len > 16) { st = 2; break; }
-            sym = s->huffval[(s->valoff[len] + (code16 >> (16 - len))) & 255];
+            const int idx = (int)s[8 + len - 9] + (int)(code16 >> (16 - len));
+            sym = ((const uint8_t*)(s + 16))[idx & 255];
         }
-        bitbuf <<= len;
-        bitcnt -= len;
-        const int sbits = k == 0 ? (sym & 15) : (sym & 15);
-        const int run = k == 0 ? 0 : (sym >> 4);
-        int v = 0;
-        if (sbits) {
-            const uint32_t raw = (uint32_t)(bitbuf >> (64 - sbits));
-            bitbuf <<= sbits;
-            bitcnt -= sbits;
-            v = raw < (1u << (sbits - 1)) ? (int)raw - (1 << sbits) + 1 : (int)raw;  // EXTEND (F.2.2.1)
-        }
+        const int sbits = sym & 15;
+        const int run = sym >> 4;
+        const uint32_t raw = (uint32_t)(((uint64_t)(w << len)) >> (32 - sbits));  // sbits = 0 -> 0
+        const int v = (sbits && !(raw >> (sbits - 1))) ? (int)raw - (1 << sbits) + 1 : (int)raw;  // EXTEND (F.2.2.1)
+        bitbuf <<= len + sbits;
+        bitcnt -= len + sbits;
         if (k == 0) {
             int pr = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
             pr += v;
@@ -350,29 +372,27 @@ __global__ __launch_bounds__(IPB) void k_jpeg_huff(const JpegImageDev* __restric
             if (++blk == blocks_per_mcu) {
                 blk = 0;
                 ++mcu;
-                if (++mx == I.mcus_x) { mx = 0; ++my; }
-                if (I.restart_interval && --restarts_left == 0) {
-                    restarts_left = I.restart_interval;
+                if (++mx == mcus_x) { mx = 0; ++my; }
+                if (restart_interval && --restarts_left == 0) {
+                    restarts_left = restart_interval;
                     const int drop = bitcnt & 7;  // the restart marker (stripped on the host) was byte aligned
                     bitbuf <<= drop;
                     bitcnt -= drop;
                     pred0 = pred1 = pred2 = 0;
                 }
             }
-            int bx, by;
             if (blk < yblocks) {
                 comp = 0;
-                const int sub_y = blk / I.hs0;
-                bx = mx * I.hs0 + (blk - sub_y * I.hs0);
-                by = my * I.vs0 + sub_y;
+                const int sub_y = blk >= hs0 ? 1 : 0;  // hs0, vs0 <= 2
+                const int bx = mx * hs0 + (blk - sub_y * hs0), by = my * vs0 + sub_y;
+                cblock = coefs + ((size_t)cblk0 + (size_t)(by * bxs0 + bx)) * 64;
+                tdc = td0; tac = ta0;
             } else {
                 comp = 1 + blk - yblocks;
-                bx = mx;
-                by = my;
+                cblock = coefs + ((size_t)(comp == 1 ? cblk1 : cblk2) + (size_t)(my * bxs1 + mx)) * 64;
+                tdc = comp == 1 ? td1 : td2;
+                tac = comp == 1 ? ta1 : ta2;
             }
-            cblock = coefs + ((size_t)I.coef_blk[comp] + (size_t)by * I.blocks_x[comp] + bx) * 64;
-            tdc = I.td[comp];
-            tac = 2 + I.ta[comp];
         }
     }
     status[img] = st;
@@ -627,7 +647,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
             blocks += (int)nb;
         }
         max_blocks = std::max(max_blocks, blocks);
-        scan_off[i + 1] = scan_off[i] + align_up(sizes[i] - h.scan_begin + 16, 16);
+        scan_off[i + 1] = scan_off[i] + align_up(sizes[i] - h.scan_begin + 128, 64);
     }
     if (coef_blocks >= (1ull << 32) / 64 || plane_bytes >= (1ull << 32) || scan_off[n] >= (1ull << 32)) {
         if (err) *err = "JPEG batch too large for 32-bit offsets; decode in smaller batches";
@@ -705,11 +725,8 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
     const HuffSlow* slow = (const HuffSlow*)(w->d_stage + w->off_slow);
     const uint8_t* scan = w->d_stage + w->off_scan;
     if (timer) timer(timer_arg, 0, 0);
-    if (n <= 16 * 1024) {  // 16 images per workgroup (32 KiB of lookup tables): small batches spread over the CUs
-        hipLaunchKernelGGL(k_jpeg_huff<16>, dim3((n + 15) / 16), dim3(16), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
-    } else {
-        hipLaunchKernelGGL(k_jpeg_huff<64>, dim3((n + 63) / 64), dim3(64), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
-    }
+    // 16 images per workgroup (52 KiB of decode tables in LDS): batches spread over the CUs
+    hipLaunchKernelGGL(k_jpeg_huff<16>, dim3((n + 15) / 16), dim3(16), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
     if (timer) timer(timer_arg, 0, 1);
     JTRY(hipGetLastError());
     if (w->max_blocks > 0) {

@@ -36,6 +36,10 @@ class OracleReader:
     def read_frames(self, frames):
         return orc_to_records(po.process_frames(frames, self.op), len(frames))
 
+    def read_jpeg_files(self, files):
+        """No GPU decoder here: every file goes back to the caller's host-decode branch."""
+        return [None] * len(files)
+
     def read_many(self, images, cropped=None):
         return [self.read_frames(img[None])[0] for img in images]
 

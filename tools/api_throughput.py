@@ -1,15 +1,58 @@
 #!/usr/bin/env python3
-"""End-to-end files/s of get_meter_values (JPEG decode on the host + GPU path) over the fixtures."""
-import glob, os, sys, time
+"""End-to-end files/s of get_meter_values over the fixture files: JPEG decode on the host
+(Pillow, 1 and 8 threads) against JPEG decode on the GPU, plus the decode kernels' own timings."""
+import glob
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from meterelf_amd import get_meter_values
+import numpy as np
+
+from meterelf_amd import MeterReader, _hip, _params, get_meter_values
+
 d = os.path.join(ROOT, 'tests', 'golden', 'sample-images2')
-files = sorted(glob.glob(os.path.join(d, '*.jpg'))) * 4
+pfile = os.path.join(d, 'params.yml')
+files = sorted(glob.glob(os.path.join(d, '*.jpg'))) * 8
+
+
+def run(label):
+    list(get_meter_values(pfile, files[:64]))
+    t0 = time.perf_counter()
+    vals = [r.value for r in get_meter_values(pfile, files)]
+    dt = time.perf_counter() - t0
+    print('%-28s %d files, %.0f files/s' % (label, len(files), len(files) / dt))
+    return vals
+
+
+os.environ['METERELF_DECODE'] = 'host'
+ref = None
 for threads in (1, 8):
     os.environ['METERELF_DECODE_THREADS'] = str(threads)
-    list(get_meter_values(os.path.join(d, 'params.yml'), files[:64]))
+    ref = run('host decode, %d thread(s)' % threads)
+os.environ['METERELF_DECODE'] = 'gpu'
+for batch in (64, 256, 1024):
+    os.environ['METERELF_BATCH'] = str(batch)
+    got = run('GPU decode, chunks of %d' % batch)
+    assert got == ref, 'values differ between decode paths'
+
+# the decode + read call alone, file bytes already in memory
+reader = MeterReader(_params.load(pfile))
+blobs = [open(f, 'rb').read() for f in files]
+(H, W, ok, _) = _hip.jpeg_probe(blobs[0])
+for n in (256, 1024, len(blobs)):
+    reader.ctx.jpeg_process_batch(blobs[:n], H, W)
+    reader.ctx.set_profiling(True)
+    reader.ctx.timings()
     t0 = time.perf_counter()
-    n = sum(1 for r in get_meter_values(os.path.join(d, 'params.yml'), files) if r.value)
-    dt = time.perf_counter() - t0
-    print('decode threads %d: %d files, %.1f files/s' % (threads, n, len(files) / dt))
+    reps = 3
+    for _ in range(reps):
+        (recs, status) = reader.ctx.jpeg_process_batch(blobs[:n], H, W)
+    dt = (time.perf_counter() - t0) / reps
+    t = reader.ctx.timings()
+    reader.ctx.set_profiling(False)
+    ks = '  '.join('%s %.3f ms' % (k, ms / cnt) for (k, (ms, cnt)) in t.items() if cnt and k.startswith('k_jpeg'))
+    print('melf_jpeg_process_batch n=%d: %.1f ms/call = %.0f files/s | %s' % (n, dt * 1e3, n / dt, ks))
+    assert (status == 0).all()
+reader.close()
