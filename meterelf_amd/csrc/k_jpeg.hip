@@ -258,12 +258,13 @@ __device__ __constant__ uint8_t c_zz2nat[64] = {
     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// One lane per image.  The loop is a flat state machine -- one Huffman symbol per iteration whatever
+// Sequential fallback (streams with restart intervals, scans too long for LDS): one lane per image.
+// The loop is a flat state machine -- one Huffman symbol per iteration whatever
 // block or coefficient the lane is at -- so lanes stay busy although their images differ.  All decode
 // tables of the workgroup's images live in LDS (8-bit first-level lookup, canonical limits for longer
 // codes); the bit stream is read as aligned dwords two words ahead of the bit buffer.
 template <int IPB>
-__global__ __launch_bounds__(IPB) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_look,
+__global__ __launch_bounds__(IPB) void k_jpeg_huff_seq(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_look,
                                                    const HuffSlow* __restrict__ g_slow, const uint8_t* __restrict__ scan,
                                                    int n, int16_t* __restrict__ coefs, int32_t* __restrict__ status)
 {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(IPB) void k_jpeg_huff(const JpegImageDev* __restric
     if (img >= n) return;
     // every field goes into its own register: indexing the record by component would put it in scratch
     const JpegImageDev* R = imgs + img;
-    if (!R->ok) { status[img] = 1; return; }
+    if (R->ok != 2) return;  // 1: the segment-parallel kernel's image, 0: not decodable
     const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x, restart_interval = R->restart_interval;
     const uint32_t cblk0 = R->coef_blk[0], cblk1 = R->coef_blk[1], cblk2 = R->coef_blk[2];
     const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
@@ -396,6 +397,206 @@ __global__ __launch_bounds__(IPB) void k_jpeg_huff(const JpegImageDev* __restric
         }
     }
     status[img] = st;
+}
+
+// ------------------------------------------------- J1: Huffman, segment-parallel ----
+// One workgroup per image, one lane per bit-stream segment.  A Huffman stream can only be decoded from
+// a known state (bit position, block within the MCU, coefficient index), but decoders started from a
+// wrong state fall into step with the true one after a few hundred bits (self-synchronisation), so:
+//   round 0   every lane decodes its segment from a guessed state and publishes its exit state;
+//   round r   a lane whose predecessor's exit state changed decodes again from that state; the true
+//             state of lane 0 propagates at least one lane per round and in practice the states stop
+//             changing after 2-4 rounds (fixed point: exit[i] = F_i(exit[i-1]) for all i);
+//   scan      blocks completed and DC differences summed per segment -> exclusive prefix over lanes;
+//   output    one more decode that writes coefficients at the right block with absolute DC values.
+// The scan (byte-swapped dwords) and all decode tables of the image sit in LDS.
+struct SegState {
+    uint32_t p;      // bit position
+    int blk, k;      // block within the MCU, coefficient index (0 = DC symbol comes next)
+};
+
+template <bool WRITE, int T>
+__device__ __forceinline__ void jpeg_decode_segment(
+    const uint32_t* __restrict__ W, const uint16_t* __restrict__ look, const uint32_t* __restrict__ slow,
+    const uint8_t* __restrict__ nat, const int yblocks, const int bpm, const int tdc0, const int tdc1, const int tdc2,
+    const int tac0, const int tac1, const int tac2, SegState& s, const uint32_t p_end, int& nblk, int& d0, int& d1, int& d2,
+    // WRITE only:
+    int nb, const int total_blocks, int pred0, int pred1, int pred2, const int hs0, const int vs0, const int mcus_x,
+    const int bxs0, const int bxs1, int16_t* __restrict__ c0, int16_t* __restrict__ c1, int16_t* __restrict__ c2, int& bad)
+{
+    uint32_t p = s.p;
+    int blk = s.blk, k = s.k;
+    int comp = blk < yblocks ? 0 : 1 + blk - yblocks;
+    int tdc = comp == 0 ? tdc0 : (comp == 1 ? tdc1 : tdc2);
+    int tac = comp == 0 ? tac0 : (comp == 1 ? tac1 : tac2);
+    int mx = 0, my = 0;
+    int16_t* cb = nullptr;
+    auto block_ptr = [&]() {
+        if (blk < yblocks) {
+            const int sub_y = blk >= hs0 ? 1 : 0;
+            cb = c0 + (size_t)((my * vs0 + sub_y) * bxs0 + mx * hs0 + (blk - sub_y * hs0)) * 64;
+        } else {
+            cb = (comp == 1 ? c1 : c2) + (size_t)(my * bxs1 + mx) * 64;
+        }
+    };
+    if (WRITE) {
+        const int mcu = nb / bpm;
+        my = mcu / mcus_x;
+        mx = mcu - my * mcus_x;
+        block_ptr();
+    }
+    nblk = 0; d0 = 0; d1 = 0; d2 = 0;
+    while (p < p_end) {
+        if (WRITE && nb >= total_blocks) break;
+        const uint32_t wi = p >> 5;
+        const uint64_t two = ((uint64_t)W[wi] << 32) | W[wi + 1];
+        const uint32_t w = (uint32_t)((two << (p & 31u)) >> 32);  // the next 32 bits: code + magnitude fit (<= 16 + 15)
+        const int t = k == 0 ? tdc : tac;
+        const uint32_t e = look[t * 256 + (w >> 24)];
+        int len = e >> 8, sym = e & 255;
+        if (!e) {
+            const uint32_t* sl = slow + t * 80;
+            const uint32_t code16 = w >> 16;
+            len = 9;
+#pragma unroll
+            for (int l = 9; l <= 16; ++l) len += (code16 >> (16 - l)) >= sl[l - 9] ? 1 : 0;
+            if (len > 16) {  // not a code: only a speculative decode (or a corrupt file) gets here
+                if (WRITE) bad = 1;
+                len = 16; sym = 0;
+            } else {
+                const int idx = (int)sl[8 + len - 9] + (int)(code16 >> (16 - len));
+                sym = ((const uint8_t*)(sl + 16))[idx & 255];
+            }
+        }
+        const int sbits = sym & 15;
+        const int run = sym >> 4;
+        const uint32_t raw = (uint32_t)(((uint64_t)(w << len)) >> (32 - sbits));  // sbits = 0 -> 0
+        const int v = (sbits && !(raw >> (sbits - 1))) ? (int)raw - (1 << sbits) + 1 : (int)raw;  // EXTEND (F.2.2.1)
+        p += len + sbits;
+        if (k == 0) {
+            if (comp == 0) d0 += v; else if (comp == 1) d1 += v; else d2 += v;
+            if (WRITE) {
+                int pr;
+                if (comp == 0) pr = (pred0 += v); else if (comp == 1) pr = (pred1 += v); else pr = (pred2 += v);
+                cb[0] = (int16_t)pr;
+            }
+            k = 1;
+        } else if (sbits) {
+            k += run;
+            if (WRITE && k < 64) cb[nat[k]] = (int16_t)v;
+            ++k;
+        } else if (run == 15) {
+            k += 16;
+        } else {
+            k = 64;  // EOB
+        }
+        if (k >= 64) {
+            k = 0;
+            ++nblk;
+            if (++blk == bpm) {
+                blk = 0;
+                if (WRITE) { if (++mx == mcus_x) { mx = 0; ++my; } }
+            }
+            comp = blk < yblocks ? 0 : 1 + blk - yblocks;
+            tdc = comp == 0 ? tdc0 : (comp == 1 ? tdc1 : tdc2);
+            tac = comp == 0 ? tac0 : (comp == 1 ? tac1 : tac2);
+            if (WRITE) { ++nb; block_ptr(); }
+        }
+    }
+    s.p = p; s.blk = blk; s.k = k;
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_look,
+                                                 const HuffSlow* __restrict__ g_slow, const uint8_t* __restrict__ scan,
+                                                 int16_t* __restrict__ coefs, int32_t* __restrict__ status)
+{
+    __shared__ uint16_t look[1024];
+    __shared__ uint32_t slow[320];
+    __shared__ uint8_t nat[64];
+    __shared__ uint32_t e_p[T];
+    __shared__ uint32_t e_s[T];
+    __shared__ int sc[4][T];
+    extern __shared__ uint32_t W[];  // the scan as big-endian dwords
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x;
+    const JpegImageDev* R = imgs + img;
+    if (R->ok != 1) return;
+    const uint32_t scan_len = R->scan_len;
+    const uint32_t bits = scan_len * 8u;
+    const uint32_t S = max(256u, (bits + T - 1) / T);
+    const int nseg = (int)((bits + S - 1) / S);
+    {
+        const uint32_t* src = (const uint32_t*)(scan + R->scan_off);
+        const uint32_t nw = bits / 32 + 4;  // segments end at bits + 32 at the latest: inside the zero bytes after the scan
+        for (uint32_t i = tid; i < nw; i += T) W[i] = __builtin_bswap32(src[i]);
+        const uint32_t* lsrc = (const uint32_t*)(g_look + (size_t)img * 1024);
+        for (int i = tid; i < 512; i += T) ((uint32_t*)look)[i] = lsrc[i];
+        const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)img * 4);
+        for (int i = tid; i < 320; i += T) slow[i] = ssrc[i];
+        for (int i = tid; i < 64; i += T) nat[i] = c_zz2nat[i];
+    }
+    const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
+    const int yblocks = ncomp == 1 ? 1 : hs0 * vs0;
+    const int bpm = ncomp == 1 ? 1 : yblocks + 2;
+    const int total_blocks = mcus_x * (int)R->mcus_y * bpm;
+    const int tdc0 = R->td[0], tdc1 = R->td[1], tdc2 = R->td[2];
+    const int tac0 = 2 + R->ta[0], tac1 = 2 + R->ta[1], tac2 = 2 + R->ta[2];
+    const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
+    int16_t* c0 = coefs + (size_t)R->coef_blk[0] * 64;
+    int16_t* c1 = coefs + (size_t)R->coef_blk[1] * 64;
+    int16_t* c2 = coefs + (size_t)R->coef_blk[2] * 64;
+    __syncthreads();
+
+    const bool mine = tid < nseg;
+    const uint32_t p_end = min((uint32_t)(tid + 1) * S, bits + 32u);
+    SegState entry = {(uint32_t)tid * S, 0, 0}, ex = entry;
+    int nblk = 0, d0 = 0, d1 = 0, d2 = 0, bad = 0;
+    if (mine) {
+        jpeg_decode_segment<false, T>(W, look, slow, nat, yblocks, bpm, tdc0, tdc1, tdc2, tac0, tac1, tac2, ex, p_end, nblk, d0, d1, d2,
+                                      0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+    }
+    e_p[tid] = ex.p;
+    e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
+    for (;;) {
+        __syncthreads();
+        SegState ne = {0, 0, 0};
+        if (tid > 0) { ne.p = e_p[tid - 1]; ne.blk = (int)(e_s[tid - 1] >> 8); ne.k = (int)(e_s[tid - 1] & 255u); }
+        const bool ch = mine && (ne.p != entry.p || ne.blk != entry.blk || ne.k != entry.k);
+        if (!__syncthreads_or(ch)) break;
+        if (ch) {
+            entry = ne;
+            ex = ne;
+            jpeg_decode_segment<false, T>(W, look, slow, nat, yblocks, bpm, tdc0, tdc1, tdc2, tac0, tac1, tac2, ex, p_end, nblk, d0, d1, d2,
+                                          0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+            e_p[tid] = ex.p;
+            e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
+        }
+    }
+    // exclusive prefix over the segments: blocks completed, DC differences per component
+    sc[0][tid] = mine ? nblk : 0; sc[1][tid] = mine ? d0 : 0; sc[2][tid] = mine ? d1 : 0; sc[3][tid] = mine ? d2 : 0;
+    __syncthreads();
+    for (int off = 1; off < T; off <<= 1) {
+        int a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = tid >= off ? sc[q][tid - off] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sc[q][tid] += a[q];
+        __syncthreads();
+    }
+    const int done_blocks = sc[0][T - 1];
+    const int nb_in = sc[0][tid] - (mine ? nblk : 0);
+    const int p0 = sc[1][tid] - (mine ? d0 : 0), p1 = sc[2][tid] - (mine ? d1 : 0), p2 = sc[3][tid] - (mine ? d2 : 0);
+    if (mine && nb_in < total_blocks) {
+        if (entry.blk != nb_in % bpm) bad = 1;  // the propagated state and the block count disagree: corrupt stream
+        SegState st = entry;
+        int n2, e0, e1, e2;
+        jpeg_decode_segment<true, T>(W, look, slow, nat, yblocks, bpm, tdc0, tdc1, tdc2, tac0, tac1, tac2, st, p_end, n2, e0, e1, e2,
+                                     nb_in, total_blocks, p0, p1, p2, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+    }
+    const int anybad = __syncthreads_or(bad);
+    if (tid == 0) status[img] = (anybad || done_blocks < total_blocks) ? 2 : 0;
 }
 
 // ------------------------------------------------------------------ J2: IDCT ----
@@ -568,6 +769,8 @@ struct JpegWorkspace {
     size_t off_imgs = 0, off_qt = 0, off_look = 0, off_slow = 0, off_scan = 0, total = 0;
     size_t coef_elems = 0, plane_bytes = 0;
     int max_blocks = 0;
+    int n_par = 0, n_seq = 0;   // images for the segment-parallel / the sequential Huffman kernel
+    size_t max_par_scan = 0;    // longest clean scan among the former (bytes)
 };
 
 void jpeg_workspace_free(JpegWorkspace* w)
@@ -593,6 +796,7 @@ static hipError_t grow_dev(T** p, size_t* cap, size_t need)
     return e;
 }
 
+static const size_t PAR_SCAN_MAX = 128 * 1024;  // longest scan the segment-parallel kernel keeps in LDS
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Host half of a batch: parse every file, lay the batch out, fill the pinned stage buffer.
@@ -695,7 +899,14 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         memset(dst + len, 0, scan_off[i + 1] - scan_off[i] - len);
         r.scan_off = (uint32_t)scan_off[i];
         r.scan_len = (uint32_t)len;
+        r.ok = (h.restart_interval != 0 || len > PAR_SCAN_MAX) ? 2 : 1;
     });
+    w->n_par = w->n_seq = 0;
+    w->max_par_scan = 0;
+    for (int i = 0; i < n; ++i) {
+        if (rec[i].ok == 1) { ++w->n_par; w->max_par_scan = std::max(w->max_par_scan, (size_t)rec[i].scan_len); }
+        else if (rec[i].ok == 2) ++w->n_seq;
+    }
     memcpy(base + w->off_imgs, rec.data(), (size_t)n * sizeof(JpegImageDev));
     return MELF_SUCCESS;
 }
@@ -725,8 +936,18 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
     const HuffSlow* slow = (const HuffSlow*)(w->d_stage + w->off_slow);
     const uint8_t* scan = w->d_stage + w->off_scan;
     if (timer) timer(timer_arg, 0, 0);
-    // 16 images per workgroup (52 KiB of decode tables in LDS): batches spread over the CUs
-    hipLaunchKernelGGL(k_jpeg_huff<16>, dim3((n + 15) / 16), dim3(16), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
+    if (w->n_par > 0) {  // one workgroup per image, one lane per stream segment
+        const size_t shmem = (size_t)w->max_par_scan + 160;
+        static size_t attr_done = 0;
+        if (shmem > attr_done) {
+            JTRY(hipFuncSetAttribute((const void*)k_jpeg_huff<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr_done = shmem;
+        }
+        hipLaunchKernelGGL(k_jpeg_huff<256>, dim3(n), dim3(256), shmem, stream, imgs, look, slow, scan, w->d_coefs, w->d_status);
+    }
+    if (w->n_seq > 0) {  // restart intervals / very long scans: 16 images per workgroup, one lane each
+        hipLaunchKernelGGL(k_jpeg_huff_seq<16>, dim3((n + 15) / 16), dim3(16), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
+    }
     if (timer) timer(timer_arg, 0, 1);
     JTRY(hipGetLastError());
     if (w->max_blocks > 0) {
