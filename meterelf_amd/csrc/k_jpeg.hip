@@ -710,14 +710,68 @@ __device__ __forceinline__ uint32_t ycc_to_bgr(int y, int cb, int cr)
     return (uint32_t)min(max(b, 0), 255) | ((uint32_t)min(max(g, 0), 255) << 8) | ((uint32_t)min(max(r, 0), 255) << 16);
 }
 
+// 4:2:0 fast path (W % 8 == 0): one thread per 8 output pixels of one row = 4 chroma columns.
+// The border cases of the triangle filter are the general formula with the missing neighbour
+// replaced by the sample itself ((4t + 8) >> 4 == (3t + t + 8) >> 4), i.e. clamped indices.
+__global__ __launch_bounds__(256) void k_jpeg_color420(const JpegImageDev* __restrict__ imgs, const int32_t* __restrict__ status,
+                                                       const uint8_t* __restrict__ planes, int H, int W,
+                                                       uint8_t* __restrict__ frames)
+{
+    const int img = blockIdx.z, y = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;  // group of 8 pixels
+    if (g * 8 >= W) return;
+    const JpegImageDev* R = imgs + img;
+    if (!(R->ok && R->ncomp == 3 && R->hs0 == 2 && R->vs0 == 2)) return;  // the generic kernel's image
+    if (status[img] != 0) {  // failed in the entropy decoder: zero frame
+        uint2* z = (uint2*)(frames + ((size_t)img * H + y) * W * 3 + (size_t)g * 24);
+        z[0] = z[1] = z[2] = make_uint2(0u, 0u);
+        return;
+    }
+    const int ys = R->blocks_x[0] * 8, cs = R->blocks_x[1] * 8;
+    const int cw = (W + 1) >> 1, ch = (H + 1) >> 1;
+    const int cy = y >> 1, fy = (y & 1) ? min(cy + 1, ch - 1) : max(cy - 1, 0);
+    const int cx0 = g * 4;
+    const int cl = max(cx0 - 1, 0), cr = min(cx0 + 4, cw - 1);
+    int t[2][6];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const uint8_t* P = planes + R->plane_off[1 + c];
+        const uint8_t* near = P + (size_t)cy * cs;
+        const uint8_t* far = P + (size_t)fy * cs;
+        const uint32_t n4 = *(const uint32_t*)(near + cx0), f4 = *(const uint32_t*)(far + cx0);
+        t[c][0] = 3 * near[cl] + far[cl];
+        t[c][5] = 3 * near[cr] + far[cr];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[c][1 + j] = 3 * (int)((n4 >> (8 * j)) & 255u) + (int)((f4 >> (8 * j)) & 255u);
+    }
+    const uint2 yy = *(const uint2*)(planes + R->plane_off[0] + (size_t)y * ys + g * 8);
+    uint32_t px[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cbe = (3 * t[0][1 + j] + t[0][j] + 8) >> 4, cbo = (3 * t[0][1 + j] + t[0][2 + j] + 7) >> 4;
+        const int cre = (3 * t[1][1 + j] + t[1][j] + 8) >> 4, cro = (3 * t[1][1 + j] + t[1][2 + j] + 7) >> 4;
+        const uint32_t ysrc = j < 2 ? yy.x : yy.y;
+        px[2 * j] = ycc_to_bgr((int)((ysrc >> (16 * (j & 1))) & 255u), cbe, cre);
+        px[2 * j + 1] = ycc_to_bgr((int)((ysrc >> (16 * (j & 1) + 8)) & 255u), cbo, cro);
+    }
+    uint32_t* o = (uint32_t*)(frames + ((size_t)img * H + y) * W * 3 + (size_t)g * 24);
+    uint32_t d[6];
+    d[0] = px[0] | (px[1] << 24); d[1] = (px[1] >> 8) | (px[2] << 16); d[2] = (px[2] >> 16) | (px[3] << 8);
+    d[3] = px[4] | (px[5] << 24); d[4] = (px[5] >> 8) | (px[6] << 16); d[5] = (px[6] >> 16) | (px[7] << 8);
+    *(uint2*)(o) = make_uint2(d[0], d[1]);
+    *(uint2*)(o + 2) = make_uint2(d[2], d[3]);
+    *(uint2*)(o + 4) = make_uint2(d[4], d[5]);
+}
+
 __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImageDev* __restrict__ imgs, const int32_t* __restrict__ status,
                                                     const uint8_t* __restrict__ planes, int H, int W,
-                                                    uint8_t* __restrict__ frames)
+                                                    uint8_t* __restrict__ frames, int fast420)
 {
     const int img = blockIdx.z, y = blockIdx.y;
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (x0 >= W) return;
     const JpegImageDev I = imgs[img];
+    if (fast420 && I.ok && I.ncomp == 3 && I.hs0 == 2 && I.vs0 == 2) return;  // k_jpeg_color420 did it
     uint8_t* out = frames + ((size_t)img * H + y) * W * 3 + (size_t)x0 * 3;
     const int npx = min(4, W - x0);
     if (!I.ok || status[img] != 0) {
@@ -770,6 +824,7 @@ struct JpegWorkspace {
     size_t coef_elems = 0, plane_bytes = 0;
     int max_blocks = 0;
     int n_par = 0, n_seq = 0;   // images for the segment-parallel / the sequential Huffman kernel
+    int n_420 = 0;              // three-component 4:2:0 images (fast colour kernel)
     size_t max_par_scan = 0;    // longest clean scan among the former (bytes)
 };
 
@@ -901,11 +956,12 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         r.scan_len = (uint32_t)len;
         r.ok = (h.restart_interval != 0 || len > PAR_SCAN_MAX) ? 2 : 1;
     });
-    w->n_par = w->n_seq = 0;
+    w->n_par = w->n_seq = w->n_420 = 0;
     w->max_par_scan = 0;
     for (int i = 0; i < n; ++i) {
         if (rec[i].ok == 1) { ++w->n_par; w->max_par_scan = std::max(w->max_par_scan, (size_t)rec[i].scan_len); }
         else if (rec[i].ok == 2) ++w->n_seq;
+        if (rec[i].ok && rec[i].ncomp == 3 && rec[i].hs0 == 2 && rec[i].vs0 == 2) ++w->n_420;
     }
     memcpy(base + w->off_imgs, rec.data(), (size_t)n * sizeof(JpegImageDev));
     return MELF_SUCCESS;
@@ -957,7 +1013,10 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
         JTRY(hipGetLastError());
     }
     if (timer) timer(timer_arg, 2, 0);
-    hipLaunchKernelGGL(k_jpeg_color, dim3((W + 1023) / 1024, H, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames);
+    const int fast420 = (W % 8 == 0 && w->n_420 > 0) ? 1 : 0;
+    if (fast420) hipLaunchKernelGGL(k_jpeg_color420, dim3((W / 8 + 255) / 256, H, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames);
+    if (!fast420 || w->n_420 < n)
+        hipLaunchKernelGGL(k_jpeg_color, dim3((W + 1023) / 1024, H, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, fast420);
     if (timer) timer(timer_arg, 2, 1);
     JTRY(hipGetLastError());
     if (status_out_host) {
