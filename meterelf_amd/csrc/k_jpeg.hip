@@ -15,6 +15,7 @@
 #include "melf_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -199,16 +200,17 @@ struct JpegImageDev {
 };
 static_assert(sizeof(JpegImageDev) % 4 == 0, "record must stay dword aligned");
 
-struct HuffSlow {  // codes longer than 8 bits: canonical decode (JPEG spec F.2.2.3), lengths 9..16
-    // limit[l - 9]: the canonical code counter after the codes of length l (one past the largest code of
-    // length l, carried over from shorter lengths if there is none).  A 16-bit window's l-bit prefix is
-    // below limit[l] exactly for l >= the code's length, so the length is 9 + the number of l with
-    // prefix >= limit[l]: eight independent compares, no data-dependent loop.
-    uint32_t limit[8];
-    int32_t valoff[8];  // huffval index of the first code of length l, minus that code
+struct HuffSlow {  // canonical decode data (JPEG spec F.2.2.3) for code lengths 1..16
+    // limit[l - 1]: the canonical code counter after the codes of length l (one past the largest code of
+    // length l, carried over from shorter lengths if there is none).  A bit window's l-bit prefix is
+    // below limit[l - 1] exactly for l >= the code's length, so the length is 1 + the number of l with
+    // prefix >= limit[l - 1]: independent compares, no data-dependent loop.
+    uint32_t limit[16];
+    int32_t valoff[16];  // huffval index of the first code of length l, minus that code
     uint8_t huffval[256];
 };
-static_assert(sizeof(HuffSlow) == 320, "HuffSlow is copied to LDS as 80 dwords");
+constexpr int SLOW_DW = 96;
+static_assert(sizeof(HuffSlow) == SLOW_DW * 4, "HuffSlow is copied to LDS as dwords");
 
 static void build_huff(const HuffSpec& t, uint16_t* look /* 256 */, HuffSlow* slow)
 {
@@ -217,14 +219,14 @@ static void build_huff(const HuffSpec& t, uint16_t* look /* 256 */, HuffSlow* sl
     memcpy(slow->huffval, t.vals, t.nvals);
     int code = 0, p = 0;
     for (int l = 1; l <= 16; ++l) {
-        if (l >= 9) slow->valoff[l - 9] = p - code;
+        slow->valoff[l - 1] = p - code;
         for (int k = 0; k < t.bits[l]; ++k, ++p, ++code) {
             if (l <= 8 && p < 256) {
                 const int first = (code << (8 - l)) & 255, cnt = 1 << (8 - l);
                 for (int q = 0; q < cnt; ++q) look[(first + q) & 255] = (uint16_t)((l << 8) | t.vals[p]);
             }
         }
-        if (l >= 9) slow->limit[l - 9] = (uint32_t)code;
+        slow->limit[l - 1] = (uint32_t)code;
         code <<= 1;
     }
 }
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(IPB) void k_jpeg_huff_seq(const JpegImageDev* __res
                                                    int n, int16_t* __restrict__ coefs, int32_t* __restrict__ status)
 {
     __shared__ uint16_t look[IPB * 1024];   // [image in block][table dc0, dc1, ac0, ac1][256]
-    __shared__ uint32_t slow[IPB * 4 * 80];  // [image in block][table] HuffSlow
+    __shared__ uint32_t slow[IPB * 4 * SLOW_DW];  // [image in block][table] HuffSlow
     __shared__ uint8_t nat[64];
     __shared__ __attribute__((aligned(16))) uint32_t sbuf[IPB * 16];  // 64 bytes of bit stream per lane
     const int lane = threadIdx.x;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(IPB) void k_jpeg_huff_seq(const JpegImageDev* __res
         uint32_t* dst = (uint32_t*)look;
         for (int i = lane; i < IPB * 512; i += IPB) dst[i] = i < here * 512 ? src[i] : 0u;
         const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)blockIdx.x * IPB * 4);
-        for (int i = lane; i < IPB * 320; i += IPB) slow[i] = i < here * 320 ? ssrc[i] : 0u;
+        for (int i = lane; i < IPB * 4 * SLOW_DW; i += IPB) slow[i] = i < here * 4 * SLOW_DW ? ssrc[i] : 0u;
         for (int i = lane; i < 64; i += IPB) nat[i] = c_zz2nat[i];
     }
     __syncthreads();
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(IPB) void k_jpeg_huff_seq(const JpegImageDev* __res
     const uint4* p = (const uint4*)(scan + R->scan_off);  // 64-byte aligned, zero-padded by >= 128 bytes
     const uint32_t nchunks = R->scan_len / 64 + 2;         // 64-byte chunks inside the padded area
     const uint16_t* mylook = look + lane * 1024;
-    const uint32_t* myslow = slow + lane * 320;
+    const uint32_t* myslow = slow + lane * 4 * SLOW_DW;
 
     const int total_mcus = mcus_x * (int)R->mcus_y;
     const int yblocks = ncomp == 1 ? 1 : hs0 * vs0;
@@ -338,14 +340,14 @@ __global__ __launch_bounds__(IPB) void k_jpeg_huff_seq(const JpegImageDev* __res
         const uint32_t e = mylook[t * 256 + (w >> 24)];
         int len = e >> 8, sym = e & 255;
         if (!e) {
-            const uint32_t* s = myslow + t * 80;
+            const uint32_t* s = myslow + t * SLOW_DW;
             const uint32_t code16 = w >> 16;
             len = 9;
 #pragma unroll
-            for (int l = 9; l <= 16; ++l) len += (code16 >> (16 - l)) >= s[l - 9] ? 1 : 0;
+            for (int l = 9; l <= 16; ++l) len += (code16 >> (16 - l)) >= s[l - 1] ? 1 : 0;
             if (len > 16) { st = 2; break; }
-            const int idx = (int)s[8 + len - 9] + (int)(code16 >> (16 - len));
-            sym = ((const uint8_t*)(s + 16))[idx & 255];
+            const int idx = (int)s[16 + len - 1] + (int)(code16 >> (16 - len));
+            sym = ((const uint8_t*)(s + 32))[idx & 255];
         }
         const int sbits = sym & 15;
         const int run = sym >> 4;
@@ -414,134 +416,171 @@ struct SegState {
     uint32_t p;      // bit position
     int blk, k;      // block within the MCU, coefficient index (0 = DC symbol comes next)
 };
+constexpr int LOOK_BITS = 11;  // first-level lookup of the segment-parallel kernel (built in LDS by the kernel itself)
 
-template <bool WRITE, int T>
+// Per-MCU-position tables packed into registers: 1 bit of DC table id, 1 bit of AC table id and 2 bits
+// of component per block position (an MCU has at most 6 blocks here).
+struct McuLayout {
+    uint32_t dc_bits, ac_bits, comp_bits;
+    int bpm, yblocks;
+};
+
+template <bool WRITE>
 __device__ __forceinline__ void jpeg_decode_segment(
     const uint32_t* __restrict__ W, const uint16_t* __restrict__ look, const uint32_t* __restrict__ slow,
-    const uint8_t* __restrict__ nat, const int yblocks, const int bpm, const int tdc0, const int tdc1, const int tdc2,
-    const int tac0, const int tac1, const int tac2, SegState& s, const uint32_t p_end, int& nblk, int& d0, int& d1, int& d2,
+    const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk, int64_t& dsum,
     // WRITE only:
     int nb, const int total_blocks, int pred0, int pred1, int pred2, const int hs0, const int vs0, const int mcus_x,
     const int bxs0, const int bxs1, int16_t* __restrict__ c0, int16_t* __restrict__ c1, int16_t* __restrict__ c2, int& bad)
 {
     uint32_t p = s.p;
     int blk = s.blk, k = s.k;
-    int comp = blk < yblocks ? 0 : 1 + blk - yblocks;
-    int tdc = comp == 0 ? tdc0 : (comp == 1 ? tdc1 : tdc2);
-    int tac = comp == 0 ? tac0 : (comp == 1 ? tac1 : tac2);
     int mx = 0, my = 0;
     int16_t* cb = nullptr;
     auto block_ptr = [&]() {
-        if (blk < yblocks) {
+        if (blk < L.yblocks) {
             const int sub_y = blk >= hs0 ? 1 : 0;
             cb = c0 + (size_t)((my * vs0 + sub_y) * bxs0 + mx * hs0 + (blk - sub_y * hs0)) * 64;
         } else {
-            cb = (comp == 1 ? c1 : c2) + (size_t)(my * bxs1 + mx) * 64;
+            cb = (blk == L.yblocks ? c1 : c2) + (size_t)(my * bxs1 + mx) * 64;
         }
     };
     if (WRITE) {
-        const int mcu = nb / bpm;
+        const int mcu = nb / L.bpm;
         my = mcu / mcus_x;
         mx = mcu - my * mcus_x;
         block_ptr();
     }
-    nblk = 0; d0 = 0; d1 = 0; d2 = 0;
+    nblk = 0;
+    dsum = 0;
+    // bit buffer over the scan in global memory (dwords in file byte order): the top `bitcnt` bits are valid
+    uint32_t di = (p >> 5) + 2;
+    uint64_t bitbuf = (((uint64_t)__builtin_bswap32(W[di - 2]) << 32) | __builtin_bswap32(W[di - 1])) << (p & 31u);
+    int bitcnt = 64 - (int)(p & 31u);
     while (p < p_end) {
         if (WRITE && nb >= total_blocks) break;
-        const uint32_t wi = p >> 5;
-        const uint64_t two = ((uint64_t)W[wi] << 32) | W[wi + 1];
-        const uint32_t w = (uint32_t)((two << (p & 31u)) >> 32);  // the next 32 bits: code + magnitude fit (<= 16 + 15)
-        const int t = k == 0 ? tdc : tac;
-        const uint32_t e = look[t * 256 + (w >> 24)];
+        if (bitcnt < 32) {
+            bitbuf |= (uint64_t)__builtin_bswap32(W[di++]) << (32 - bitcnt);
+            bitcnt += 32;
+        }
+        const uint32_t w = (uint32_t)(bitbuf >> 32);  // the next 32 bits: code + magnitude fit (<= 16 + 15)
+        const bool isdc = k == 0;
+        const uint32_t t = 2u * (isdc ? 0u : 1u) + (((isdc ? L.dc_bits : L.ac_bits) >> blk) & 1u);
+        const uint32_t e = look[(t << LOOK_BITS) + (w >> (32 - LOOK_BITS))];
         int len = e >> 8, sym = e & 255;
-        if (!e) {
-            const uint32_t* sl = slow + t * 80;
+        if (!e) {  // longer than LOOK_BITS (rare)
+            const uint32_t* sl = slow + t * SLOW_DW;
             const uint32_t code16 = w >> 16;
-            len = 9;
+            len = LOOK_BITS + 1;
 #pragma unroll
-            for (int l = 9; l <= 16; ++l) len += (code16 >> (16 - l)) >= sl[l - 9] ? 1 : 0;
+            for (int l = LOOK_BITS + 1; l <= 16; ++l) len += (code16 >> (16 - l)) >= sl[l - 1] ? 1 : 0;
             if (len > 16) {  // not a code: only a speculative decode (or a corrupt file) gets here
                 if (WRITE) bad = 1;
                 len = 16; sym = 0;
             } else {
-                const int idx = (int)sl[8 + len - 9] + (int)(code16 >> (16 - len));
-                sym = ((const uint8_t*)(sl + 16))[idx & 255];
+                const int idx = (int)sl[16 + len - 1] + (int)(code16 >> (16 - len));
+                sym = ((const uint8_t*)(sl + 32))[idx & 255];
             }
         }
         const int sbits = sym & 15;
         const int run = sym >> 4;
-        const uint32_t raw = (uint32_t)(((uint64_t)(w << len)) >> (32 - sbits));  // sbits = 0 -> 0
-        const int v = (sbits && !(raw >> (sbits - 1))) ? (int)raw - (1 << sbits) + 1 : (int)raw;  // EXTEND (F.2.2.1)
+        const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - len - sbits, sbits);  // width 0 -> 0
+        const int half = (1 << sbits) >> 1;
+        const int v = raw < half ? raw - 2 * half + 1 : raw;  // EXTEND (F.2.2.1); sbits = 0 -> 0
         p += len + sbits;
-        if (k == 0) {
-            if (comp == 0) d0 += v; else if (comp == 1) d1 += v; else d2 += v;
-            if (WRITE) {
+        bitbuf <<= len + sbits;
+        bitcnt -= len + sbits;
+        const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
+        if (isdc) dsum += (int64_t)v << (16 * comp);  // three 16-bit lanes, separated again after the scan
+        const int pos = isdc ? 0 : k + run;
+        if (WRITE) {
+            if (isdc) {
                 int pr;
                 if (comp == 0) pr = (pred0 += v); else if (comp == 1) pr = (pred1 += v); else pr = (pred2 += v);
                 cb[0] = (int16_t)pr;
+            } else if (sbits && pos < 64) {
+                cb[nat[pos]] = (int16_t)v;
             }
-            k = 1;
-        } else if (sbits) {
-            k += run;
-            if (WRITE && k < 64) cb[nat[k]] = (int16_t)v;
-            ++k;
-        } else if (run == 15) {
-            k += 16;
-        } else {
-            k = 64;  // EOB
         }
+        k = isdc ? 1 : (sbits ? pos + 1 : (run == 15 ? k + 16 : 64));
         if (k >= 64) {
             k = 0;
             ++nblk;
-            if (++blk == bpm) {
+            if (++blk == L.bpm) {
                 blk = 0;
                 if (WRITE) { if (++mx == mcus_x) { mx = 0; ++my; } }
             }
-            comp = blk < yblocks ? 0 : 1 + blk - yblocks;
-            tdc = comp == 0 ? tdc0 : (comp == 1 ? tdc1 : tdc2);
-            tac = comp == 0 ? tac0 : (comp == 1 ? tac1 : tac2);
             if (WRITE) { ++nb; block_ptr(); }
         }
     }
     s.p = p; s.blk = blk; s.k = k;
 }
 
-template <int T>
-__global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_look,
-                                                 const HuffSlow* __restrict__ g_slow, const uint8_t* __restrict__ scan,
-                                                 int16_t* __restrict__ coefs, int32_t* __restrict__ status)
+// the three 16-bit lanes of a packed DC-difference sum (each true sum fits: it is a difference of two DC values)
+__device__ __forceinline__ void unpack_dsum(int64_t d, int& a, int& b, int& c)
 {
-    __shared__ uint16_t look[1024];
-    __shared__ uint32_t slow[320];
+    a = (int)(int16_t)(d & 0xffff);
+    d = (d - a) >> 16;
+    b = (int)(int16_t)(d & 0xffff);
+    d = (d - b) >> 16;
+    c = (int)(int16_t)(d & 0xffff);
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const HuffSlow* __restrict__ g_slow,
+                                                 const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
+                                                 int32_t* __restrict__ status)
+{
+    __shared__ uint16_t look[4 << LOOK_BITS];
+    __shared__ uint32_t slow[4 * SLOW_DW];
     __shared__ uint8_t nat[64];
     __shared__ uint32_t e_p[T];
     __shared__ uint32_t e_s[T];
-    __shared__ int sc[4][T];
-    extern __shared__ uint32_t W[];  // the scan as big-endian dwords
+    __shared__ int sc_n[T];
+    __shared__ int64_t sc_d[T];
     const int tid = threadIdx.x;
     const int img = blockIdx.x;
     const JpegImageDev* R = imgs + img;
     if (R->ok != 1) return;
+    const uint32_t* W = (const uint32_t*)(scan + R->scan_off);  // zero-padded by 128 bytes; read through L1/L2
     const uint32_t scan_len = R->scan_len;
     const uint32_t bits = scan_len * 8u;
-    const uint32_t S = max(256u, (bits + T - 1) / T);
+    // segment length: a multiple of 32 bits with an odd dword count, so that the lanes' stream reads fall into
+    // different LDS banks
+    const uint32_t S = 32u * (max(8u, (bits + 32u * T - 1) / (32u * T)) | 1u);
     const int nseg = (int)((bits + S - 1) / S);
     {
-        const uint32_t* src = (const uint32_t*)(scan + R->scan_off);
-        const uint32_t nw = bits / 32 + 4;  // segments end at bits + 32 at the latest: inside the zero bytes after the scan
-        for (uint32_t i = tid; i < nw; i += T) W[i] = __builtin_bswap32(src[i]);
-        const uint32_t* lsrc = (const uint32_t*)(g_look + (size_t)img * 1024);
-        for (int i = tid; i < 512; i += T) ((uint32_t*)look)[i] = lsrc[i];
         const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)img * 4);
-        for (int i = tid; i < 320; i += T) slow[i] = ssrc[i];
+        for (int i = tid; i < 4 * SLOW_DW; i += T) slow[i] = ssrc[i];
         for (int i = tid; i < 64; i += T) nat[i] = c_zz2nat[i];
     }
+    __syncthreads();
+    // first-level lookup tables: the canonical decode of every LOOK_BITS-bit prefix
+    for (int i = tid; i < (4 << LOOK_BITS); i += T) {
+        const uint32_t* sl = slow + (i >> LOOK_BITS) * SLOW_DW;
+        const uint32_t x = (uint32_t)i & ((1u << LOOK_BITS) - 1u);
+        int len = 1;
+#pragma unroll
+        for (int l = 1; l <= LOOK_BITS; ++l) len += (x >> (LOOK_BITS - l)) >= sl[l - 1] ? 1 : 0;
+        uint32_t e = 0;
+        if (len <= LOOK_BITS) {
+            const int idx = (int)sl[16 + len - 1] + (int)(x >> (LOOK_BITS - len));
+            e = ((uint32_t)len << 8) | ((const uint8_t*)(sl + 32))[idx & 255];
+        }
+        look[i] = (uint16_t)e;
+    }
     const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
-    const int yblocks = ncomp == 1 ? 1 : hs0 * vs0;
-    const int bpm = ncomp == 1 ? 1 : yblocks + 2;
-    const int total_blocks = mcus_x * (int)R->mcus_y * bpm;
-    const int tdc0 = R->td[0], tdc1 = R->td[1], tdc2 = R->td[2];
-    const int tac0 = 2 + R->ta[0], tac1 = 2 + R->ta[1], tac2 = 2 + R->ta[2];
+    McuLayout L;
+    L.yblocks = ncomp == 1 ? 1 : hs0 * vs0;
+    L.bpm = ncomp == 1 ? 1 : L.yblocks + 2;
+    L.dc_bits = L.ac_bits = L.comp_bits = 0;
+    for (int b = 0; b < L.bpm; ++b) {
+        const int c = b < L.yblocks ? 0 : 1 + b - L.yblocks;
+        L.dc_bits |= (uint32_t)(R->td[c] & 1) << b;
+        L.ac_bits |= (uint32_t)(R->ta[c] & 1) << b;
+        L.comp_bits |= (uint32_t)c << (2 * b);
+    }
+    const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
     const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
     int16_t* c0 = coefs + (size_t)R->coef_blk[0] * 64;
     int16_t* c1 = coefs + (size_t)R->coef_blk[1] * 64;
@@ -551,10 +590,10 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
     const bool mine = tid < nseg;
     const uint32_t p_end = min((uint32_t)(tid + 1) * S, bits + 32u);
     SegState entry = {(uint32_t)tid * S, 0, 0}, ex = entry;
-    int nblk = 0, d0 = 0, d1 = 0, d2 = 0, bad = 0;
+    int nblk = 0, bad = 0;
+    int64_t dsum = 0;
     if (mine) {
-        jpeg_decode_segment<false, T>(W, look, slow, nat, yblocks, bpm, tdc0, tdc1, tdc2, tac0, tac1, tac2, ex, p_end, nblk, d0, d1, d2,
-                                      0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+        jpeg_decode_segment<false>(W, look, slow, nat, L, ex, p_end, nblk, dsum, 0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
     }
     e_p[tid] = ex.p;
     e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
@@ -567,33 +606,34 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
         if (ch) {
             entry = ne;
             ex = ne;
-            jpeg_decode_segment<false, T>(W, look, slow, nat, yblocks, bpm, tdc0, tdc1, tdc2, tac0, tac1, tac2, ex, p_end, nblk, d0, d1, d2,
-                                          0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+            jpeg_decode_segment<false>(W, look, slow, nat, L, ex, p_end, nblk, dsum, 0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
             e_p[tid] = ex.p;
             e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
         }
     }
-    // exclusive prefix over the segments: blocks completed, DC differences per component
-    sc[0][tid] = mine ? nblk : 0; sc[1][tid] = mine ? d0 : 0; sc[2][tid] = mine ? d1 : 0; sc[3][tid] = mine ? d2 : 0;
+    // exclusive prefix over the segments: blocks completed, packed DC differences per component
+    sc_n[tid] = mine ? nblk : 0;
+    sc_d[tid] = mine ? dsum : 0;
     __syncthreads();
     for (int off = 1; off < T; off <<= 1) {
-        int a[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = tid >= off ? sc[q][tid - off] : 0;
+        const int a = tid >= off ? sc_n[tid - off] : 0;
+        const int64_t b = tid >= off ? sc_d[tid - off] : 0;
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sc[q][tid] += a[q];
+        sc_n[tid] += a;
+        sc_d[tid] += b;
         __syncthreads();
     }
-    const int done_blocks = sc[0][T - 1];
-    const int nb_in = sc[0][tid] - (mine ? nblk : 0);
-    const int p0 = sc[1][tid] - (mine ? d0 : 0), p1 = sc[2][tid] - (mine ? d1 : 0), p2 = sc[3][tid] - (mine ? d2 : 0);
+    const int done_blocks = sc_n[T - 1];
+    const int nb_in = sc_n[tid] - (mine ? nblk : 0);
+    int p0, p1, p2;
+    unpack_dsum(sc_d[tid] - (mine ? dsum : 0), p0, p1, p2);
     if (mine && nb_in < total_blocks) {
-        if (entry.blk != nb_in % bpm) bad = 1;  // the propagated state and the block count disagree: corrupt stream
+        if (entry.blk != nb_in % L.bpm) bad = 1;  // the propagated state and the block count disagree: corrupt stream
         SegState st = entry;
-        int n2, e0, e1, e2;
-        jpeg_decode_segment<true, T>(W, look, slow, nat, yblocks, bpm, tdc0, tdc1, tdc2, tac0, tac1, tac2, st, p_end, n2, e0, e1, e2,
-                                     nb_in, total_blocks, p0, p1, p2, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+        int n2;
+        int64_t d2;
+        jpeg_decode_segment<true>(W, look, slow, nat, L, st, p_end, n2, d2, nb_in, total_blocks, p0, p1, p2, hs0, vs0, mcus_x, bxs0,
+                                  bxs1, c0, c1, c2, bad);
     }
     const int anybad = __syncthreads_or(bad);
     if (tid == 0) status[img] = (anybad || done_blocks < total_blocks) ? 2 : 0;
@@ -851,7 +891,6 @@ static hipError_t grow_dev(T** p, size_t* cap, size_t need)
     return e;
 }
 
-static const size_t PAR_SCAN_MAX = 128 * 1024;  // longest scan the segment-parallel kernel keeps in LDS
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Host half of a batch: parse every file, lay the batch out, fill the pinned stage buffer.
@@ -954,7 +993,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         memset(dst + len, 0, scan_off[i + 1] - scan_off[i] - len);
         r.scan_off = (uint32_t)scan_off[i];
         r.scan_len = (uint32_t)len;
-        r.ok = (h.restart_interval != 0 || len > PAR_SCAN_MAX) ? 2 : 1;
+        r.ok = h.restart_interval != 0 ? 2 : 1;
     });
     w->n_par = w->n_seq = w->n_420 = 0;
     w->max_par_scan = 0;
@@ -993,13 +1032,15 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
     const uint8_t* scan = w->d_stage + w->off_scan;
     if (timer) timer(timer_arg, 0, 0);
     if (w->n_par > 0) {  // one workgroup per image, one lane per stream segment
-        const size_t shmem = (size_t)w->max_par_scan + 160;
-        static size_t attr_done = 0;
-        if (shmem > attr_done) {
-            JTRY(hipFuncSetAttribute((const void*)k_jpeg_huff<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            attr_done = shmem;
-        }
-        hipLaunchKernelGGL(k_jpeg_huff<256>, dim3(n), dim3(256), shmem, stream, imgs, look, slow, scan, w->d_coefs, w->d_status);
+        static int tsel = -1;
+        if (tsel < 0) { const char* e = getenv("MELF_JPEG_T"); tsel = e ? atoi(e) : 512; }
+#define LAUNCH_HUFF(TT) \
+    hipLaunchKernelGGL(k_jpeg_huff<TT>, dim3(n), dim3(TT), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status)
+        if (tsel == 128) LAUNCH_HUFF(128);
+        else if (tsel == 256) LAUNCH_HUFF(256);
+        else if (tsel == 1024) LAUNCH_HUFF(1024);
+        else LAUNCH_HUFF(512);
+#undef LAUNCH_HUFF
     }
     if (w->n_seq > 0) {  // restart intervals / very long scans: 16 images per workgroup, one lane each
         hipLaunchKernelGGL(k_jpeg_huff_seq<16>, dim3((n + 15) / 16), dim3(16), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
