@@ -61,6 +61,7 @@ def main():
     ap.add_argument('--sample-dir', default='sample-images1')
     ap.add_argument('--cpu-sample', type=int, default=256, help='frames timed through the CPU oracle (0 = skip)')
     ap.add_argument('--no-fused-mask', action='store_true')
+    ap.add_argument('--no-jpeg', action='store_true', help='skip the JPEG-files-in block (SURVEY 8 f1)')
     args = ap.parse_args()
 
     import torch
@@ -229,10 +230,53 @@ def main():
             if same and o.status == 0:
                 same = '{:07.3f}'.format(float(r['value'])) == '{:07.3f}'.format(o.value)
             mism += 0 if same else 1
+        # the same sample again on every host core (threads over chunks; the C call releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        ncores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+        ncores = min(ncores, 16, S)  # one GPU's share of the host
+        parts = [sample[i::ncores] for i in range(ncores) if len(sample[i::ncores])]
+        with ThreadPoolExecutor(max_workers=ncores) as pool:
+            tm0 = time.perf_counter()
+            list(pool.map(lambda part: po.process_frames(part, op), parts))
+            tm = time.perf_counter() - tm0
         cpu = {'value': round(S / tc, 2), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+               'all_cores': {'value': round(S / tm, 2), 'unit': 'frames/s', 'cores': ncores},
                'sample': 'first %d frames of the same batch through oracle/melf_oracle.c (exact direct '
                          'correlation, single thread; the reference itself needs OpenCV 3.4.5, absent here)' % S,
                'parity_mismatches_vs_gpu': mism}
+
+    # ---- the same path fed with JPEG files (decode on the GPU), fixture files tiled to B ----
+    jpeg = None
+    if world == 1 and not args.no_jpeg:
+        import glob as _glob
+        jfiles = [f for f in sorted(_glob.glob(os.path.join(ROOT, 'tests', 'golden', args.sample_dir, '*.jpg')))
+                  if os.path.basename(f) not in REJECTED]
+        blobs = [open(f, 'rb').read() for f in jfiles]
+        blobs = [b for b in blobs if _hip.jpeg_probe(b)[:3] == (H, W, True)]
+        if blobs:
+            JB = 1024
+            batch = [blobs[i % len(blobs)] for i in range(JB)]
+            (jf, jst) = ctx.jpeg_decode(blobs[:8], H, W)
+            from meterelf_amd._image import imread_bgr
+            same = bool((jst == 0).all()) and all(
+                np.array_equal(jf[i], imread_bgr(f)) for (i, f) in enumerate([f for f in jfiles][:8])
+                if _hip.jpeg_probe(open(f, 'rb').read())[:2] == (H, W))
+            ctx.jpeg_process_batch(batch, H, W)  # warm-up (allocations)
+            ctx.set_profiling(True)
+            ctx.timings()
+            tj0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                (jrecs, jstatus) = ctx.jpeg_process_batch(batch, H, W)
+            tj = (time.perf_counter() - tj0) / reps
+            jt = ctx.timings()
+            ctx.set_profiling(False)
+            jpeg = {'workload': '%d JPEG files (%d distinct %s fixtures, %.1f KB average) -> decode + full reading path, '
+                                'file bytes in host memory to result records' % (JB, len(blobs), args.sample_dir,
+                                                                                 sum(map(len, blobs)) / len(blobs) / 1024),
+                    'files_per_s': round(JB / tj, 1), 'ms_per_call': round(tj * 1e3, 3),
+                    'kernel_ms': {k: round(ms / c, 4) for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
+                    'decoded_frames_equal_libjpeg_turbo': same, 'files_ok': int((jstatus == 0).sum())}
 
     line = {
         'metric': 'frames/sec (640x480), full pipeline, digits identical to the oracle',
@@ -243,7 +287,7 @@ def main():
                                '%s params, frames %dx%d synthesised from the readable fixtures (shift +-8, noise sigma 2)'
                                % (B, args.sample_dir, W, H),
                    'global_batch': B * world, 'parallelism': 'dp%d' % world, 'frames_read_ok_last_step': n_ok},
-        'roofline': roofline, 'cpu_baseline': cpu, 'fused_mask': fused,
+        'roofline': roofline, 'cpu_baseline': cpu, 'fused_mask': fused, 'jpeg_decode': jpeg,
     }
     print(json.dumps(line))
     sys.stdout.flush()

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -851,12 +852,20 @@ int jpeg_decode_to_device(melf_ctx* c, const uint8_t* const* data, const size_t*
                           uint8_t* d_frames, int32_t* status)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned stage buffer of the previous batch is free again
+    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<int32_t> hstat(n);
     std::string err;
     if (int rc = jpeg_prepare_batch(&c->jpeg, data, sizes, n, H, W, hstat.data(), &err)) return fail(rc, err);
+    const auto t1 = std::chrono::steady_clock::now();
     std::vector<int32_t> dstat(n);
     JpegTimers t{c, c->stream, {}, {false, false, false}};
     if (int rc = jpeg_launch_batch(c->jpeg, n, H, W, d_frames, dstat.data(), c->stream, &err, jpeg_timer_hook, &t)) return fail(rc, err);
+    if (trace) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[melf jpeg] n=%d host prepare %.2f ms, H2D + kernels + status %.2f ms\n", n,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
     for (int i = 0; i < n; ++i) status[i] = hstat[i] ? hstat[i] : (dstat[i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
     return MELF_SUCCESS;
 }

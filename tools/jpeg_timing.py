@@ -1,3 +1,7 @@
+"""Times melf_jpeg_process_batch (GPU JPEG decode + meter reading) on fixture files: ms per call and per kernel.
+
+    python3 tools/jpeg_timing.py [sample-images2] [n]      (MELF_JPEG_TRACE=1 adds the host/device split)
+"""
 import glob, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,8 +13,7 @@ blobs = [open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(d, '*.jpg')
 blobs = [b for b in blobs if _hip.jpeg_probe(b)[:2] == (H, W)]
 blobs = (blobs * 20)[:int(sys.argv[2]) if len(sys.argv) > 2 else 1024]
 import numpy as np
-for rep in range(2):
-    (fr, st) = reader.ctx.jpeg_decode(blobs[:64], H, W)
+reader.ctx.jpeg_process_batch(blobs, H, W)  # warm-up: allocates the workspaces
 reader.ctx.set_profiling(True); reader.ctx.timings()
 t0 = time.perf_counter()
 for _ in range(3):
