@@ -176,6 +176,22 @@ struct MfmaGeom {
     double tmean;
 };
 
+#ifdef MELF_MATCH_STAMP
+// Diagnostic build only (make stamp; never the shipped library): per-wave shader-clock and 100 MHz
+// real-time stamps around the whole wave, read back with melf_debug_match_stamps -- the in-kernel clock
+// check of MI355X_MICROARCH.md ("DVFS give-back", item 6).
+__device__ uint64_t g_match_stamps[4 * 8192];
+__device__ uint64_t g_match_loop_end[8192];  // shader clock when the MFMA loops are done (epilogue starts)
+extern "C" __attribute__((visibility("default"))) int melf_debug_match_stamps(uint64_t* out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_stamps), sizeof(uint64_t) * 4 * (size_t)(nwaves < 8192 ? nwaves : 8192)) == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("default"))) int melf_debug_match_loop_end(uint64_t* out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_loop_end), sizeof(uint64_t) * (size_t)(nwaves < 8192 ? nwaves : 8192)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 __device__ inline bool better_m(float v, int i, float bv, int bi)
 {
     return i != INT_MAX && (bi == INT_MAX || v > bv || (v == bv && i < bi));
@@ -250,9 +266,17 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                     // image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD
 #pragma unroll
                     for (int kb = d; kb < (d == ND - 1 ? NKB : d + 1); ++kb)
+#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 2)
+                        buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)((i + NBUF - 1) & 3) * ROWV + kb * 64];  // diagnostic: four image rows only
+#else
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
+#endif
                     // template fragments of step i + PD (the table carries PD extra all-zero rows)
+#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 1)
+                    a[(s + PD) % NA][d] = Ap[((size_t)((i + PD) & 1) * ND + d) * 64];  // diagnostic: template rows 0/1 only (wrong results)
+#else
                     a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
+#endif
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < R; ++r)
@@ -267,30 +291,53 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
         }
     }
 
+#ifdef MELF_MATCH_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_match_loop_end[blockIdx.x] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: exact u8 correlation, OpenCV's float post-pass, first-max reduction ----
+    // All window sums are fetched first (unconditional loads at clamped addresses, one wait), then the
+    // arithmetic runs on registers: with the loads inside the bounds checks every element paid its own
+    // L2 round trip -- a third of the wave's lifetime.
     const int n = lane & 31, hh = lane >> 5;
     const int f = grp * 32 + n;
-    float bestv = 0.f;
+    uint32_t wsr[R][NXB][16];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int yc = min(y0 + r, g.rh - 1);
+        const uint32_t* wrow = ws + ((size_t)grp * g.rh + yc) * 64 * 32 + n;
+#pragma unroll
+        for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (on(r, xb)) wsr[r][xb][e] = wrow[(32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh) * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // cc = sum T*L is below 2^31 (119*188*255^2 at most for templates this kernel takes), so the three terms
+    // can be added modulo 2^32 and converted with one cvt_f64_u32 (an int64 -> double conversion is four
+    // instructions, two of them quarter rate).  A lane visits its elements in increasing raster index, so the
+    // first maximum is "strictly greater wins".
+    const bool lane_ok = f < g.nframes;
+    float bestv = -INFINITY;
     int besti = INT_MAX;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int y = y0 + r;
-        if (y >= g.rh) continue;
+        const bool row_ok = lane_ok && y < g.rh;
 #pragma unroll
         for (int xb = 0; xb < NXB; ++xb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (!on(r, xb)) continue;
                 const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (x >= g.rw || f >= g.nframes) continue;
-                const uint32_t wsv = ws[(((size_t)grp * g.rh + y) * 64 + x) * 32 + n];
-                const int64_t cc = (int64_t)acc[r][xb][e] + (int64_t)128 * wsv + g.k1;
+                const bool valid = row_ok && x < g.rw;
+                const uint32_t wsv = wsr[r][xb][e];
+                const uint32_t cc = (uint32_t)acc[r][xb][e] + 128u * wsv + (uint32_t)g.k1;
                 double num = (double)cc;
                 num -= (double)wsv * g.tmean;
-                const float v = (float)num;
+                const float v = valid ? (float)num : -INFINITY;
                 const int idx = y * g.rw + x;
-                if (result_map) result_map[(size_t)f * g.rh * g.rw + idx] = v;
-                if (better_m(v, idx, bestv, besti)) { bestv = v; besti = idx; }
+                if (result_map && valid) result_map[(size_t)f * g.rh * g.rw + idx] = v;
+                if (v > bestv) { bestv = v; besti = idx; }
             }
     }
     {
@@ -316,6 +363,9 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
     // ids with equal (id % 8) share an L2.  Give each XCD whole frame groups (they share Lg rows).
     const int nblk = gridDim.x;
     const int id = blockIdx.x;
+#ifdef MELF_MATCH_STAMP
+    const uint64_t st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
+#endif
     const int per = nblk / 8, rem = nblk % 8, xcd = id & 7, sub = id >> 3;
     const int vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + sub;
     const int grp = vid / g.nparts, rblk = vid - grp * g.nparts;
@@ -333,6 +383,12 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
     } else {
         match_wave<ND, NXB, R, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * R);
     }
+#ifdef MELF_MATCH_STAMP
+    if (threadIdx.x == 0 && id < 8192) {
+        g_match_stamps[4 * id + 0] = st_clk; g_match_stamps[4 * id + 1] = __builtin_amdgcn_s_memtime();
+        g_match_stamps[4 * id + 2] = st_rt;  g_match_stamps[4 * id + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -349,7 +405,9 @@ bool mfma_match_ok(int th, int tw, int rows, int cols)
 {
     const int rh = rows - th + 1, rw = cols - tw + 1;
     const int nd = (tw + 31 + 31) / 32;  // Toeplitz blocks per template row
-    return rh >= 1 && rw >= 1 && rw <= 64 && nd == MM_ND && cols <= 32 * (MM_ND + (rw > 32 ? 2 : 1) - 1);
+    // th * tw * 255^2 < 2^32: the epilogue adds the correlation's three terms modulo 2^32
+    return rh >= 1 && rw >= 1 && rw <= 64 && nd == MM_ND && cols <= 32 * (MM_ND + (rw > 32 ? 2 : 1) - 1) &&
+           (long)th * tw * 65025L < (1L << 32);
 }
 
 MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
