@@ -112,12 +112,10 @@ class ShardedMeterReader:
         if process_factory is not None:
             self._process: ProcessFn = process_factory(self.blob, self.dial_names)
         else:
-            import torch
-            device = torch.cuda.current_device()
-            if dev_tensor is not None:
-                self._ctx = _hip.Context(self.blob, device, blob_device_ptr=dev_tensor.data_ptr())
-            else:
-                self._ctx = _hip.Context(self.blob, device)
+            if dev_tensor is not None:  # RCCL path: the blob already sits on this rank's GPU
+                self._ctx = _hip.Context(self.blob, dev_tensor.device.index, blob_device_ptr=dev_tensor.data_ptr())
+            else:  # host collective (gloo): no torch.cuda involved, the library picks the rank's GPU itself
+                self._ctx = _hip.Context(self.blob, int(os.environ.get('LOCAL_RANK', '0')))
             self._process = self._ctx.process_batch
 
     @property
@@ -134,6 +132,60 @@ class ShardedMeterReader:
     def read_local(self, frames: np.ndarray) -> np.ndarray:
         """This rank's shard only; no communication."""
         return self._process(frames)
+
+    def read_files_local(self, filenames: Sequence[str]) -> np.ndarray:
+        """This rank's files -> records.  JPEG files are decoded on the rank's GPU
+        (melf_jpeg_process_batch); whatever the GPU decoder does not take, and every file when
+        the compute is injected (CPU tests), is decoded on the host.  An unreadable file gives a
+        record with status -1."""
+        from ._image import imread_bgr
+        n = len(filenames)
+        out = np.zeros(n, _hip.RESULT_DTYPE)
+        todo = list(range(n))
+        if self._ctx is not None:
+            blobs = []
+            for f in filenames:
+                try:
+                    with open(f, 'rb') as fp:
+                        blobs.append(fp.read())
+                except OSError:
+                    blobs.append(b'')
+            groups = {}
+            for (i, data) in enumerate(blobs):
+                (h, w, ok, _why) = _hip.jpeg_probe(data) if data else (0, 0, False, '')
+                if ok:
+                    groups.setdefault((h, w), []).append(i)
+            done = set()
+            for ((h, w), idxs) in groups.items():
+                (recs, status) = self._ctx.jpeg_process_batch([blobs[i] for i in idxs], h, w)
+                for (k, i) in enumerate(idxs):
+                    if status[k] == _hip.JPEG_OK:
+                        out[i] = recs[k]
+                        done.add(i)
+            todo = [i for i in range(n) if i not in done]
+        by_shape = {}
+        for i in todo:
+            img = imread_bgr(filenames[i])
+            if img is None:
+                out[i]['status'] = -1
+            else:
+                by_shape.setdefault(img.shape, []).append((i, img))
+        for items in by_shape.values():
+            recs = self._process(np.stack([img for (_, img) in items]))
+            for ((i, _), r) in zip(items, recs):
+                out[i] = r
+        return out
+
+    def read_files_global(self, filenames: Sequence[str], gather: bool = True) -> np.ndarray:
+        """Every rank gets the same list of file names, reads its contiguous shard of the FILES
+        (no rank touches another rank's files) and, if `gather`, receives all records."""
+        n = len(filenames)
+        (a, b) = self.my_range(n)
+        local = self.read_files_local(filenames[a:b]) if b > a else np.zeros(0, _hip.RESULT_DTYPE)
+        if not gather:
+            return local
+        counts = [shard_range(n, r, self.world)[1] - shard_range(n, r, self.world)[0] for r in range(self.world)]
+        return all_gather_records(local, counts)
 
     def read_global(self, frames: np.ndarray, gather: bool = True) -> np.ndarray:
         """Every rank holds the same (n, H, W, 3) array (or a memory map of it),

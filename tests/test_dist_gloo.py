@@ -43,6 +43,8 @@ reader = _dist.ShardedMeterReader(pfile if rank == 0 else None, process_factory=
 local = reader.read_local(frames[a:b])
 allrec = reader.read_global(frames, gather=True)
 np.save(os.path.join({out!r}, 'rank%d.npy' % rank), allrec)
+byfile = reader.read_files_global(files + ['/nonexistent/file.jpg'], gather=True)   # sharded over FILES
+np.save(os.path.join({out!r}, 'files%d.npy' % rank), byfile)
 np.save(os.path.join({out!r}, 'blob%d.npy' % rank), reader.blob)
 assert np.array_equal(allrec[a:b], local)
 dist.barrier()
@@ -85,6 +87,9 @@ def test_world_size_2_gloo(tmp_path):
     frames = np.stack([imread_bgr(f) for f in files])
     single = helpers.orc_to_records(po.process_frames(frames, po.Params(pfile)), 9)
     assert np.array_equal(r0, single)
+    f0 = np.load(tmp_path / 'files0.npy')
+    assert np.array_equal(f0, np.load(tmp_path / 'files1.npy')) and len(f0) == 10
+    assert np.array_equal(f0[:9], single) and f0[9]['status'] == -1
     with open(os.path.join(GOLDEN, 'sample-images2_stdout.txt')) as fp:
         expected = dict(line.split(': ', 1) for line in fp.read().splitlines())
     for (f, r) in zip(files, r0):

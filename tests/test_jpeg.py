@@ -199,3 +199,37 @@ def test_jpeg_bytes_to_values_match_host_decode_path(sd):
             assert recs.tobytes() == ref.tobytes()
     finally:
         reader.close()
+
+
+@pytest.mark.gpu
+def test_sharded_reader_reads_files_on_the_gpu(tmp_path):
+    """_dist.ShardedMeterReader.read_files_local: one rank (gloo group of 1), real HIP context, JPEG bytes
+    decoded on the GPU; an unreadable and a non-JPEG file go through the host branch."""
+    import socket
+
+    import torch.distributed as dist
+
+    from meterelf_amd import MeterReader, _dist, _params
+    from meterelf_amd._image import imread_bgr
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    try:
+        pfile = os.path.join(GOLDEN, 'sample-images1', 'params.yml')
+        files = _files('sample-images1')[:12]
+        reader = _dist.ShardedMeterReader(pfile)
+        from PIL import Image
+        prog = str(tmp_path / 'progressive.jpg')  # not a baseline JPEG: the host decodes it
+        Image.open(files[3]).save(prog, 'JPEG', progressive=True, quality=95)
+        got = reader.read_files_global(files + ['/nonexistent.jpg', prog])
+        reader.close()
+        ref_reader = MeterReader(_params.load(pfile))
+        for (i, f) in enumerate(files + [None, prog]):
+            if f is not None:
+                assert got[i].tobytes() == ref_reader.read_frames(imread_bgr(f)[None])[0].tobytes(), f
+        ref_reader.close()
+        assert got[12]['status'] == -1
+    finally:
+        dist.destroy_process_group()
