@@ -233,3 +233,56 @@ def test_sharded_reader_reads_files_on_the_gpu(tmp_path):
         assert got[12]['status'] == -1
     finally:
         dist.destroy_process_group()
+
+
+def test_probe_survives_mutated_headers():
+    """Header parser fuzz (CPU only): truncations and random byte flips must never crash, only say no."""
+    from meterelf_amd import _hip
+    rng = np.random.default_rng(99)
+    base = open(_files('sample-images1')[0], 'rb').read()
+    head = 700  # all markers of these files sit in the first ~620 bytes
+    for cut in list(range(0, head, 7)) + [len(base) - 1]:
+        _hip.jpeg_probe(base[:cut] if cut else b'\xff')
+    for _ in range(3000):
+        b = bytearray(base[:4096])
+        for _k in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(2, head))] = int(rng.integers(0, 256))
+        (H, W, ok, why) = _hip.jpeg_probe(bytes(b))
+        assert isinstance(ok, bool)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('subsampling', ['4:4:4', '4:2:2', '4:2:0'])
+def test_tiny_and_narrow_images(ctx, subsampling):
+    """Widths 1..5 take libjpeg's plain-replication upsampling (downsampled width <= 2), heights 1..3 the
+    replicated context rows; plus sizes straddling MCU boundaries."""
+    rng = np.random.default_rng(4242)
+    for (H, W) in [(1, 1), (1, 9), (9, 1), (2, 2), (3, 3), (2, 4), (4, 5), (5, 4), (3, 17), (16, 16), (17, 16), (16, 17),
+                   (15, 31), (33, 47), (48, 2), (2, 48)]:
+        files = [_encode(rng.integers(0, 256, (H, W, 3), dtype=np.uint8), quality=q, subsampling=subsampling)
+                 for q in (50, 90, 100)]
+        (frames, status) = ctx.jpeg_decode(files, H, W)
+        assert (status == 0).all(), (H, W, status)
+        for (i, (d, got)) in enumerate(zip(files, frames)):
+            ref = _pillow_bgr(d)
+            assert np.array_equal(got, ref), ((H, W), i, int((got != ref).sum()), np.argwhere(got != ref)[:3])
+
+
+@pytest.mark.gpu
+def test_corrupt_scans_never_hang_or_crash(ctx):
+    """Entropy-coded data with random damage: every file comes back (status 0 or 2), the call returns."""
+    rng = np.random.default_rng(31337)
+    (H, W) = (64, 64)
+    good = _encode(_natural_image(rng, H, W), quality=80)
+    sos = good.index(b'\xff\xda')
+    files = []
+    for _ in range(64):
+        b = bytearray(good)
+        for _k in range(int(rng.integers(1, 20))):
+            b[int(rng.integers(sos + 14, len(b) - 2))] = int(rng.integers(0, 256))
+        files.append(bytes(b))
+    files.append(good[:sos + 20])
+    (frames, status) = ctx.jpeg_decode(files, H, W)
+    assert set(status.tolist()) <= {0, 2}
+    (frames2, status2) = ctx.jpeg_decode([good], H, W)   # the context is still healthy
+    assert status2[0] == 0 and np.array_equal(frames2[0], _pillow_bgr(good))
