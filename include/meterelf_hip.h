@@ -186,6 +186,10 @@ enum { MELF_JPEG_OK = 0, MELF_JPEG_UNSUPPORTED = 1, MELF_JPEG_CORRUPT = 2, MELF_
 /* Header check only (no GPU, no context): image size and whether the GPU decoder handles the file. */
 int melf_jpeg_probe(const uint8_t* data, size_t size, int32_t* H, int32_t* W, int32_t* supported);
 
+/* The same check for n files at once (one call instead of n from a scripting host). */
+int melf_jpeg_probe_batch(const uint8_t* const* data, const size_t* sizes, int n, int32_t* H, int32_t* W,
+                          int32_t* supported);
+
 /* Decodes n files of H x W pixels.  out: n*H*W*3 bytes, on the host (out_on_device = 0) or in HBM.
  * Synchronises the context's stream. */
 int melf_jpeg_decode_batch(melf_ctx* ctx, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,

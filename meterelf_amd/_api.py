@@ -72,7 +72,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
             by_index: Dict[int, object] = {}
             on_host = list(range(len(chunk)))
             if gpu_decode:
-                blobs = [_read_bytes(f) for f in chunk]
+                blobs = [_read_bytes(f) for f in chunk]  # sequential: a thread pool costs more per small file than it overlaps
                 have = [i for (i, b) in enumerate(blobs) if b]
                 recs = reader.read_jpeg_files([blobs[i] for i in have]) if have else []
                 for (i, rec) in zip(have, recs):

@@ -151,10 +151,9 @@ class ShardedMeterReader:
                 except OSError:
                     blobs.append(b'')
             groups = {}
-            for (i, data) in enumerate(blobs):
-                (h, w, ok, _why) = _hip.jpeg_probe(data) if data else (0, 0, False, '')
-                if ok:
-                    groups.setdefault((h, w), []).append(i)
+            (hs, ws, oks) = _hip.jpeg_probe_batch(blobs)
+            for i in np.flatnonzero(oks):
+                groups.setdefault((int(hs[i]), int(ws[i])), []).append(int(i))
             done = set()
             for ((h, w), idxs) in groups.items():
                 (recs, status) = self._ctx.jpeg_process_batch([blobs[i] for i in idxs], h, w)

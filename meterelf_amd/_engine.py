@@ -84,10 +84,9 @@ class MeterReader:
         decodes that one on the host."""
         out: List[Optional[np.void]] = [None] * len(files)
         groups: Dict[Tuple[int, int], List[int]] = {}
-        for (i, data) in enumerate(files):
-            (h, w, ok, _why) = _hip.jpeg_probe(data)
-            if ok:
-                groups.setdefault((h, w), []).append(i)
+        (hs, ws, oks) = _hip.jpeg_probe_batch(files)
+        for i in np.flatnonzero(oks):
+            groups.setdefault((int(hs[i]), int(ws[i])), []).append(int(i))
         for ((h, w), idxs) in groups.items():
             (recs, status) = self.ctx.jpeg_process_batch([files[i] for i in idxs], h, w)
             for (k, i) in enumerate(idxs):

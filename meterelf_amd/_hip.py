@@ -64,7 +64,7 @@ EXPORTS = [
     'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
-    'melf_jpeg_probe', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
+    'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
 ]
 
 _lib = None
@@ -109,6 +109,7 @@ def lib():
     L.melf_ctx_timings.argtypes = [vp, vp, vp]
     i32p = C.POINTER(C.c_int32)
     L.melf_jpeg_probe.argtypes = [vp, C.c_size_t, i32p, i32p, i32p]
+    L.melf_jpeg_probe_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.melf_jpeg_decode_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
     L.melf_jpeg_process_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     if L.melf_abi_version() != ABI_VERSION:
@@ -136,10 +137,23 @@ def jpeg_probe(data):
     """(H, W, supported, reason) of a JPEG file's bytes; header parse only, no GPU."""
     L = lib()
     H, W, ok = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-    buf = (C.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, np.ndarray) else None
-    p = C.cast(buf, C.c_void_p) if buf is not None else _ptr(data)
+    if isinstance(data, np.ndarray):
+        p = _ptr(data)
+    else:
+        data = data if isinstance(data, bytes) else bytes(data)
+        p = C.cast(C.c_char_p(data), C.c_void_p)  # no copy: the bytes object outlives the call
     check(L.melf_jpeg_probe(p, len(data), C.byref(H), C.byref(W), C.byref(ok)))
     return H.value, W.value, bool(ok.value), L.melf_last_error().decode()
+
+
+def jpeg_probe_batch(files):
+    """Header check of many files' bytes in one call: (H, W, supported) int32 arrays."""
+    n = len(files)
+    (H, W, ok) = (np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
+    if n:
+        (ptrs, sizes, keep) = _file_table(files)
+        check(lib().melf_jpeg_probe_batch(ptrs, sizes, n, _ptr(H), _ptr(W), _ptr(ok)))
+    return H, W, ok
 
 
 def _file_table(files):

@@ -826,6 +826,18 @@ extern "C" int melf_jpeg_probe(const uint8_t* data, size_t size, int32_t* H, int
     return MELF_SUCCESS;
 }
 
+extern "C" int melf_jpeg_probe_batch(const uint8_t* const* data, const size_t* sizes, int n, int32_t* H, int32_t* W,
+                                     int32_t* supported)
+{
+    if (n < 0 || (n > 0 && (!data || !sizes || !H || !W || !supported))) return fail(MELF_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        int h = 0, w = 0, ok = 0;
+        if (data[i] && sizes[i]) jpeg_probe(data[i], sizes[i], &h, &w, &ok, nullptr);
+        H[i] = h; W[i] = w; supported[i] = ok;
+    }
+    return MELF_SUCCESS;
+}
+
 namespace {
 struct JpegTimers {
     melf_ctx* c;
