@@ -117,6 +117,30 @@ __device__ inline void for_each_kept(uint64_t outer, int lane, int wx0, int wy0,
     }
 }
 
+constexpr int DIAL_LIST_CAP = 1024;
+
+// Three bytes of a packed 3-channel pixel with ONE (unaligned) dword load instead of three byte loads: the
+// dword starts one byte early (so it never runs past the buffer's end) except at the buffer's very first pixel.
+__device__ __forceinline__ uint32_t load_px3(const uint8_t* p, const uint8_t* buffer_start)
+{
+    const bool first = p == buffer_start;
+    uint32_t v;
+    __builtin_memcpy(&v, first ? p : p - 1, 4);
+    return first ? (v & 0xffffffu) : (v >> 8);
+}
+
+#ifdef MELF_DIALS_STAMP
+// Diagnostic build only: shader-clock stamps at the phase boundaries of each wave (tools/dials_clock.py).
+__device__ uint64_t g_dials_stamps[8 * 8192];
+extern "C" __attribute__((visibility("default"))) int melf_debug_dials_stamps(uint64_t* out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dials_stamps), sizeof(uint64_t) * 8 * (size_t)(nwaves < 8192 ? nwaves : 8192)) == hipSuccess ? 0 : -1;
+}
+#define DSTAMP(k) do { if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + d) < 8192) g_dials_stamps[8 * (blockIdx.x * (blockDim.x >> 6) + d) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DSTAMP(k) do { } while (0)
+#endif
+
 template <bool FROM_HLS>
 __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, melf_params P,
                                                               const DialGeom* __restrict__ geom,
@@ -128,9 +152,12 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
     __shared__ double s_pos[MELF_MAX_DIALS], s_angle[MELF_MAX_DIALS];
     __shared__ float s_mv;
     __shared__ int s_mi;
+    __shared__ uint16_t s_list[MELF_MAX_DIALS][DIAL_LIST_CAP];  // candidate pixels (y << 6 | x) of each dial's window
+    __shared__ uint32_t s_mask[MELF_MAX_DIALS][128];            // exact in-range bits, two dwords per window row
 
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63, d = threadIdx.x >> 6;
+    DSTAMP(0);
     const uint8_t* frame = src.base + (size_t)f * src.frame_stride;
 
     // ---- minMaxLoc over the K2 partials; DialsNotFoundError check (_image.py:62-64) ----
@@ -169,6 +196,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
         }
     }
 
+    DSTAMP(1);
     // ---- one wave per dial ----
     const DialGeom G = geom[d];
     const melf_dial D = P.dial[d];
@@ -176,12 +204,12 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
 
     auto fetch = [&](int X, int Y, int& H, int& L, int& S) {
         if (FROM_HLS) {
-            const uint8_t* p = frame + ((size_t)Y * P.tw + X) * 3;
-            H = p[0]; L = p[1]; S = p[2];
+            const uint32_t px = load_px3(frame + ((size_t)Y * P.tw + X) * 3, src.base);
+            H = px & 255; L = (px >> 8) & 255; S = (px >> 16) & 255;
         } else {
             const int cxp = mx + X, cyp = my + Y;  // meter-crop coordinates
-            const uint8_t* p = frame + (size_t)(src.y0 + cyp) * src.row_stride + (size_t)(src.x0 + cxp) * 3;
-            hls_pixel(p[0], p[1], p[2], hls_scalar_tail(cxp, src.crop_cols), P.hue_shift, H, L, S);
+            const uint32_t px = load_px3(frame + (size_t)(src.y0 + cyp) * src.row_stride + (size_t)(src.x0 + cxp) * 3, src.base);
+            hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, hls_scalar_tail(cxp, src.crop_cols), P.hue_shift, H, L, S);
         }
     };
 
@@ -202,43 +230,116 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
     const int lol = max(cl - D.range_l, 0), hil = min(cl + D.range_l, 255);
     const int los = max(cs - D.range_s, 0), his = min(cs + D.range_s, 255);
 
+    DSTAMP(2);
     // inRange over the window (get_mask_by_color, _utils.py:113-119): row masks via ballot.
     // Phase 1 requests every window pixel of this lane's column (lane = column, one packed VGPR per
     // window row) so that all the loads are in flight together; phase 2 converts and tests.
     const int Xl = wx0 + lane;
     const bool colvalid = lane < ws && Xl >= 0 && Xl < P.tw;
+    const int Xc = min(max(Xl, 0), P.tw - 1);
     const bool tail = !FROM_HLS && hls_scalar_tail(mx + Xl, src.crop_cols);
     uint64_t m0 = 0, V = 0;
-    for (int yc = 0; yc < ws; yc += 16) {
-        uint32_t pxv[16];
+    auto exact_rows = [&]() {  // every window pixel through the exact float path
+        for (int yc = 0; yc < ws; yc += 16) {
+            uint32_t pxv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int Y = wy0 + yc + k;
-            pxv[k] = 0;
-            if (yc + k < ws && colvalid && Y >= 0 && Y < P.th) {
-                const uint8_t* p = FROM_HLS ? frame + ((size_t)Y * P.tw + Xl) * 3
-                                            : frame + (size_t)(src.y0 + my + Y) * src.row_stride + (size_t)(src.x0 + mx + Xl) * 3;
-                pxv[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+            for (int k = 0; k < 16; ++k) {
+                // unconditional loads at clamped (always valid) coordinates: a load inside the bounds check makes
+                // the compiler wait for each one separately (16 serialized round trips per chunk)
+                const int Y = min(max(wy0 + yc + k, 0), P.th - 1);
+                const uint8_t* p = FROM_HLS ? frame + ((size_t)Y * P.tw + Xc) * 3
+                                            : frame + (size_t)(src.y0 + my + Y) * src.row_stride + (size_t)(src.x0 + mx + Xc) * 3;
+                pxv[k] = load_px3(p, src.base);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int y = yc + k, Y = wy0 + y;
+                const bool valid = y < ws && colvalid && Y >= 0 && Y < P.th;
+                bool in = false;
+                if (valid) {
+                    int H, L, S;
+                    const uint32_t px = pxv[k];
+                    if (FROM_HLS) { H = px & 255; L = (px >> 8) & 255; S = (px >> 16) & 255; }
+                    else hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, tail, P.hue_shift, H, L, S);
+                    in = H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his;
+                }
+                const uint64_t b = __ballot(in), vb = __ballot(valid);
+                if (lane == y) { m0 = b; V = vb; }
             }
         }
+    };
+    if (FROM_HLS) {
+        exact_rows();
+    } else {
+        // Two steps.  (1) An integer test that can only err towards "maybe" picks candidates: with
+        // sum = max + min and diff = max - min, L is sum/2 rounded either way and S is 255*diff/den rounded
+        // (den = sum below mid-grey, 510 - sum above), both float paths within 1e-4 of the real value, so a
+        // pixel whose L or S misses the bounds by a whole unit cannot be in range.  (2) The candidates --
+        // typically the needle, a tenth of the window -- are compacted and only they take the exact float
+        // path, 64 at a time.  More candidates than the list holds: every pixel takes the exact path.
+        uint64_t C = 0;
+        for (int yc = 0; yc < ws; yc += 16) {
+            uint32_t pxv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int y = yc + k, Y = wy0 + y;
-            const bool valid = y < ws && colvalid && Y >= 0 && Y < P.th;
-            bool in = false;
-            if (valid) {
-                int H, L, S;
-                const uint32_t px = pxv[k];
-                if (FROM_HLS) { H = px & 255; L = (px >> 8) & 255; S = (px >> 16) & 255; }
-                else hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, tail, P.hue_shift, H, L, S);
-                in = H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his;
+            for (int k = 0; k < 16; ++k) {
+                const int Y = min(max(wy0 + yc + k, 0), P.th - 1);  // clamped, unconditional (see exact_rows)
+                const uint8_t* p = frame + (size_t)(src.y0 + my + Y) * src.row_stride + (size_t)(src.x0 + mx + Xc) * 3;
+                pxv[k] = load_px3(p, src.base);
             }
-            const uint64_t b = __ballot(in), vb = __ballot(valid);
-            if (lane == y) { m0 = b; V = vb; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int y = yc + k, Y = wy0 + y;
+                const bool valid = y < ws && colvalid && Y >= 0 && Y < P.th;
+                const int b8 = pxv[k] & 255, g8 = (pxv[k] >> 8) & 255, r8 = (pxv[k] >> 16) & 255;
+                const int vmax = max(max(b8, g8), r8), vmin = min(min(b8, g8), r8);
+                const int sum = vmax + vmin, diff = vmax - vmin;
+                const int den = sum <= 255 ? sum : 510 - sum;
+                const bool l_ok = sum >= 2 * lol - 1 && sum <= 2 * hil + 1;
+                const bool s_ok = diff == 0 ? los == 0 : (510 * diff >= (2 * los - 2) * den && 510 * diff <= (2 * his + 2) * den);
+                const uint64_t cb = __ballot(valid && l_ok && s_ok), vb = __ballot(valid);
+                if (lane == y) { C = cb; V = vb; }
+            }
+        }
+        DSTAMP(6);
+        const int mine = __popcll(C);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (total > DIAL_LIST_CAP) {
+            exact_rows();
+        } else {
+            uint16_t* list = s_list[d];
+            uint32_t* mask = s_mask[d];
+            mask[lane] = 0;
+            mask[64 + lane] = 0;
+            int at = incl - mine;
+            uint64_t bits = C;
+            while (bits) {
+                const int x = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                list[at++] = (uint16_t)(lane << 6 | x);
+            }
+            DSTAMP(7);
+            for (int t = lane; t < total; t += 64) {
+                const int e = list[t], y = e >> 6, x = e & 63;
+                const int cxp = mx + wx0 + x;
+                const uint8_t* p = frame + (size_t)(src.y0 + my + wy0 + y) * src.row_stride + (size_t)(src.x0 + cxp) * 3;
+                int H, L, S;
+                const uint32_t px = load_px3(p, src.base);
+                hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, hls_scalar_tail(cxp, src.crop_cols), P.hue_shift, H, L, S);
+                if (H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his)
+                    atomicOr(&mask[2 * y + (x >> 5)], 1u << (x & 31));
+            }
+            m0 = (uint64_t)mask[2 * lane] | ((uint64_t)mask[2 * lane + 1] << 32);
         }
     }
 
     // dilate then erode, 3x3, pixels outside the dials crop never win (_reading.py:128-130)
+    DSTAMP(3);
     const uint64_t hz = m0 | (m0 << 1) | (m0 >> 1);
     const uint64_t dil = (hz | row_up(hz, lane, 0) | row_down(hz, lane, 0)) | ~V;
     const uint64_t he = dil & ((dil << 1) | 1ull) & ((dil >> 1) | (1ull << 63));
@@ -295,6 +396,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
         // contourArea > 100: filled contour, else the whole closed mask (_reading.py:141-148); both are
         // used only through `& dial.mask` / `& dial.circle_mask` (:150, :51) -- the filled contour can
         // cover pocket pixels that the disk mask lacks.
+        DSTAMP(4);
         const uint64_t N = (best2 > 200 ? bestF : M) & disk;
         const uint64_t outer = N & annulus;
 
@@ -370,6 +472,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
             pos = py_fmod(10.0 * fixed, 10.0);  // _reading.py:95-96
         }
     }
+    DSTAMP(5);
     if (lane == 0) { s_status[d] = status; s_pos[d] = pos; s_angle[d] = angle; }
     __syncthreads();
 
