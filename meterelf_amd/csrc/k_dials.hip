@@ -118,6 +118,7 @@ __device__ inline void for_each_kept(uint64_t outer, int lane, int wx0, int wy0,
 }
 
 constexpr int DIAL_LIST_CAP = 1024;
+constexpr int RING_CAP = 256;
 
 // Three bytes of a packed 3-channel pixel with ONE (unaligned) dword load instead of three byte loads: the
 // dword starts one byte early (so it never runs past the buffer's end) except at the buffer's very first pixel.
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
     __shared__ int s_mi;
     __shared__ uint16_t s_list[MELF_MAX_DIALS][DIAL_LIST_CAP];  // candidate pixels (y << 6 | x) of each dial's window
     __shared__ uint32_t s_mask[MELF_MAX_DIALS][128];            // exact in-range bits, two dwords per window row
+    __shared__ double s_ra[MELF_MAX_DIALS][RING_CAP], s_rd[MELF_MAX_DIALS][RING_CAP];  // ring points: angle (NaN = dropped), distance^2
 
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63, d = threadIdx.x >> 6;
@@ -421,55 +423,142 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
         double mom = 0.0;
         const bool have_mom = angle_by_vector(msign * sx, msign * sy, mom);
 
-        // pass 1: count and minimum of the kept angles (_reading.py:79-82)
-        int nk = 0;
-        double mina = 1e300;
-        for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double) {
-            ++nk;
-            if (a < mina) mina = a;
-        });
-        nk = wave_sum_i32(nk);
+        // The ring points (needle pixels inside the annulus, a few dozen) are compacted into a list first: the
+        // angle of each -- a double-precision atan -- is then computed once, 64 points at a time, and the three
+        // passes of the reference (count / minimum, trimming, weighted mean) run over the cached values.  Walking
+        // each row's bits per lane instead costs an atan per point and pass, times the longest row.
+        const int rmine = __popcll(outer);
+        int rincl = rmine;
 #pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) mina = fmin(mina, __shfl_xor(mina, o2, 64));
-        if (nk == 0) {
-            status = 2;  // unreadable dial (_reading.py:79-81)
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(rincl, o, 64);
+            if (lane >= o) rincl += t;
+        }
+        const int rtotal = __shfl(rincl, 63, 64);
+        if (rtotal <= RING_CAP) {
+            uint16_t* list = s_list[d];
+            double* ra = s_ra[d];
+            double* rd = s_rd[d];
+            {
+                int at = rincl - rmine;
+                uint64_t bits = outer;
+                while (bits) {
+                    const int x = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    list[at++] = (uint16_t)(lane << 6 | x);
+                }
+            }
+            int nk = 0;
+            double mina = 1e300;
+            for (int t = lane; t < rtotal; t += 64) {
+                const int e = list[t];
+                const double dx = (double)(wx0 + (e & 63)) - cx, dy = (double)(wy0 + (e >> 6)) - cy;
+                double a, keep = __builtin_nan("");
+                if (angle_by_vector(dx, dy, a) && have_mom) {
+                    double dist = fabs(a - mom);
+                    const double dist2 = fabs(fabs(a - mom) - 1);
+                    if (dist2 < dist) dist = dist2;
+                    if (dist < 0.25) { keep = a; ++nk; if (a < mina) mina = a; }
+                }
+                ra[t] = keep;
+                rd[t] = dx * dx + dy * dy;
+            }
+            nk = wave_sum_i32(nk);
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) mina = fmin(mina, __shfl_xor(mina, o2, 64));
+            if (nk == 0) {
+                status = 2;  // unreadable dial (_reading.py:79-81)
+            } else {
+                const int cut = nk >= 5 ? min(2, (nk - 3) / 2) : 0;
+                const Key PINF = {1e300, 1e300}, NINF = {-1e300, -1e300};
+                Key klo = NINF, khi = PINF;
+                if (cut > 0) {
+                    Key l1 = PINF, l2 = PINF, h1 = NINF, h2 = NINF;
+                    for (int t = lane; t < rtotal; t += 64) {
+                        const double a = ra[t];
+                        if (a != a) continue;
+                        Key k;
+                        k.a = fabs(a - mina) < 0.75 ? a : a - 1;
+                        k.d = rd[t];
+                        if (key_lt(k, l1)) { l2 = l1; l1 = k; } else if (key_lt(k, l2)) { l2 = k; }
+                        if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
+                    }
+                    for (int c2 = 0; c2 < cut; ++c2) {
+                        klo = wave_min_key(l1);
+                        if (l1.a == klo.a && l1.d == klo.d) { l1 = l2; l2 = PINF; }
+                        khi = wave_max_key(h1);
+                        if (h1.a == khi.a && h1.d == khi.d) { h1 = h2; h2 = NINF; }
+                    }
+                }
+                double sad = 0.0, sd = 0.0;
+                for (int t = lane; t < rtotal; t += 64) {
+                    const double a = ra[t];
+                    if (a != a) continue;
+                    Key k;
+                    k.a = fabs(a - mina) < 0.75 ? a : a - 1;
+                    k.d = rd[t];
+                    if (cut == 0 || (key_lt(klo, k) && key_lt(k, khi))) {
+                        sad += k.a * k.d;
+                        sd += k.d;
+                    }
+                }
+                sad = wave_sum_f64(sad);
+                sd = wave_sum_f64(sd);
+                angle = sad / sd;
+                const double fixed = angle - (D.angle_of_zero / 360.0);
+                pos = py_fmod(10.0 * fixed, 10.0);  // _reading.py:95-96
+            }
         } else {
-            // pass 2: the `cut` smallest / largest (angle, sqdist) tuples to drop (_reading.py:86-91)
-            const int cut = nk >= 5 ? min(2, (nk - 3) / 2) : 0;
-            const Key PINF = {1e300, 1e300}, NINF = {-1e300, -1e300};
-            Key klo = NINF, khi = PINF;
-            if (cut > 0) {
-                Key l1 = PINF, l2 = PINF, h1 = NINF, h2 = NINF;
+            // pass 1: count and minimum of the kept angles (_reading.py:79-82)
+            int nk = 0;
+            double mina = 1e300;
+            for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double) {
+                ++nk;
+                if (a < mina) mina = a;
+            });
+            nk = wave_sum_i32(nk);
+    #pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) mina = fmin(mina, __shfl_xor(mina, o2, 64));
+            if (nk == 0) {
+                status = 2;  // unreadable dial (_reading.py:79-81)
+            } else {
+                // pass 2: the `cut` smallest / largest (angle, sqdist) tuples to drop (_reading.py:86-91)
+                const int cut = nk >= 5 ? min(2, (nk - 3) / 2) : 0;
+                const Key PINF = {1e300, 1e300}, NINF = {-1e300, -1e300};
+                Key klo = NINF, khi = PINF;
+                if (cut > 0) {
+                    Key l1 = PINF, l2 = PINF, h1 = NINF, h2 = NINF;
+                    for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double dd) {
+                        Key k;
+                        k.a = fabs(a - mina) < 0.75 ? a : a - 1;
+                        k.d = dd;
+                        if (key_lt(k, l1)) { l2 = l1; l1 = k; } else if (key_lt(k, l2)) { l2 = k; }
+                        if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
+                    });
+                    for (int c2 = 0; c2 < cut; ++c2) {
+                        klo = wave_min_key(l1);
+                        if (l1.a == klo.a && l1.d == klo.d) { l1 = l2; l2 = PINF; }
+                        khi = wave_max_key(h1);
+                        if (h1.a == khi.a && h1.d == khi.d) { h1 = h2; h2 = NINF; }
+                    }
+                }
+                // pass 3: distance^2-weighted mean angle of the rest (_reading.py:92-94)
+                double sad = 0.0, sd = 0.0;
                 for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double dd) {
                     Key k;
                     k.a = fabs(a - mina) < 0.75 ? a : a - 1;
                     k.d = dd;
-                    if (key_lt(k, l1)) { l2 = l1; l1 = k; } else if (key_lt(k, l2)) { l2 = k; }
-                    if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
+                    if (cut == 0 || (key_lt(klo, k) && key_lt(k, khi))) {
+                        sad += k.a * dd;
+                        sd += dd;
+                    }
                 });
-                for (int c2 = 0; c2 < cut; ++c2) {
-                    klo = wave_min_key(l1);
-                    if (l1.a == klo.a && l1.d == klo.d) { l1 = l2; l2 = PINF; }
-                    khi = wave_max_key(h1);
-                    if (h1.a == khi.a && h1.d == khi.d) { h1 = h2; h2 = NINF; }
-                }
+                sad = wave_sum_f64(sad);
+                sd = wave_sum_f64(sd);
+                angle = sad / sd;
+                const double fixed = angle - (D.angle_of_zero / 360.0);
+                pos = py_fmod(10.0 * fixed, 10.0);  // _reading.py:95-96
             }
-            // pass 3: distance^2-weighted mean angle of the rest (_reading.py:92-94)
-            double sad = 0.0, sd = 0.0;
-            for_each_kept(outer, lane, wx0, wy0, cx, cy, have_mom, mom, [&](double a, double dd) {
-                Key k;
-                k.a = fabs(a - mina) < 0.75 ? a : a - 1;
-                k.d = dd;
-                if (cut == 0 || (key_lt(klo, k) && key_lt(k, khi))) {
-                    sad += k.a * dd;
-                    sd += dd;
-                }
-            });
-            sad = wave_sum_f64(sad);
-            sd = wave_sum_f64(sd);
-            angle = sad / sd;
-            const double fixed = angle - (D.angle_of_zero / 360.0);
-            pos = py_fmod(10.0 * fixed, 10.0);  // _reading.py:95-96
         }
     }
     DSTAMP(5);
