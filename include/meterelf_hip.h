@@ -207,7 +207,7 @@ int melf_jpeg_process_batch(melf_ctx* ctx, const uint8_t* const* data, const siz
  * returns per-kernel accumulated milliseconds and launch counts. */
 enum { MELF_K_LPLANE = 0, MELF_K_MATCH = 1, MELF_K_DIALS = 2, MELF_K_FUSED_MASK = 3, MELF_K_HLS = 4,
        MELF_K_JPEG_HUFF = 5, MELF_K_JPEG_IDCT = 6, MELF_K_JPEG_COLOR = 7, MELF_K_COUNT = 8 };
-int melf_ctx_set_profiling(melf_ctx* ctx, int on);
+int melf_ctx_set_profiling(melf_ctx* ctx, int on);  /* 0 off, 1 every kernel, 2 only the match kernel (two event records per batch instead of eight) */
 int melf_ctx_timings(melf_ctx* ctx, double ms[MELF_K_COUNT], int64_t launches[MELF_K_COUNT]);
 const char* melf_kernel_name(int k);
 

@@ -347,7 +347,7 @@ class Context:
         return out, status
 
     def set_profiling(self, on):
-        check(self._L.melf_ctx_set_profiling(self._h, 1 if on else 0))
+        check(self._L.melf_ctx_set_profiling(self._h, int(on)))  # False/0 off, True/1 every kernel, 2 only k_match
 
     def timings(self):
         ms = np.zeros(K_COUNT, np.float64)

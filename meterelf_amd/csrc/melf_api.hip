@@ -245,7 +245,7 @@ struct melf_ctx {
     JpegWorkspace* jpeg = nullptr;     // created by the first JPEG batch
     // profiling
     bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
-    bool profiling = false;
+    int profiling = 0;                // 0 off, 1 every kernel, 2 only the dominant kernel (k_match)
     std::vector<TimedEvent> events;
     double acc_ms[MELF_K_COUNT] = {0};
     int64_t acc_n[MELF_K_COUNT] = {0};
@@ -268,7 +268,7 @@ struct KernelTimer {
     hipStream_t s;
     TimedEvent ev;
     bool on;
-    KernelTimer(melf_ctx* ctx, int k, hipStream_t st) : c(ctx), s(st), on(ctx->profiling)
+    KernelTimer(melf_ctx* ctx, int k, hipStream_t st) : c(ctx), s(st), on(ctx->profiling == 1 || (ctx->profiling == 2 && k == MELF_K_MATCH))
     {
         if (!on) return;
         ev.kernel = k;
@@ -492,7 +492,7 @@ extern "C" int melf_ctx_fused_table_ties(const melf_ctx* c, int* count)
 extern "C" int melf_ctx_set_profiling(melf_ctx* c, int on)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
-    c->profiling = on != 0;
+    c->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
     return MELF_SUCCESS;
 }
 
@@ -848,7 +848,7 @@ struct JpegTimers {
 void jpeg_timer_hook(void* arg, int k, int stop)
 {
     JpegTimers* t = (JpegTimers*)arg;
-    if (!t->c->profiling) return;
+    if (t->c->profiling != 1) return;
     if (!stop) {
         t->ev[k].kernel = MELF_K_JPEG_HUFF + k;
         t->on[k] = hipEventCreate(&t->ev[k].start) == hipSuccess && hipEventCreate(&t->ev[k].stop) == hipSuccess;
