@@ -1,5 +1,7 @@
+"""Step time of the full pipeline with and without per-kernel event profiling (each hipEventRecord is a
+barrier packet in the queue): why bench.py times with events around the dominant kernel only."""
 import glob, os, sys, time
-ROOT = '/root/repo' if os.path.exists('/root/repo/bench.py') else os.getcwd()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch, bench
 from meterelf_amd import _engine, _hip, _params
