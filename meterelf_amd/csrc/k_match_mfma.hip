@@ -266,12 +266,18 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                     // image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD
 #pragma unroll
                     for (int kb = d; kb < (d == ND - 1 ? NKB : d + 1); ++kb)
+#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 4)
+                        if (i < 0)  // diagnostic: no image loads in the loop at all (wrong results)
+#endif
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 2)
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)((i + NBUF - 1) & 3) * ROWV + kb * 64];  // diagnostic: four image rows only
 #else
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
 #endif
                     // template fragments of step i + PD (the table carries PD extra all-zero rows)
+#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 4)
+                    if (i < 0)  // diagnostic: no template loads in the loop either
+#endif
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 1)
                     a[(s + PD) % NA][d] = Ap[((size_t)((i + PD) & 1) * ND + d) * 64];  // diagnostic: template rows 0/1 only (wrong results)
 #else
@@ -283,8 +289,12 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #pragma unroll
                         for (int xb = 0; xb < NXB; ++xb)
                             if (on(r, xb))
+#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 8)
+                                acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], buf[0][0], acc[r][xb], 0, 0, 0);  // diagnostic: one A / B register set
+#else
                                 acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
                                                                                    acc[r][xb], 0, 0, 0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
