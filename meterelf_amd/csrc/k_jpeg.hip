@@ -526,6 +526,14 @@ __device__ __forceinline__ void unpack_dsum(int64_t d, int& a, int& b, int& c)
     c = (int)(int16_t)(d & 0xffff);
 }
 
+#ifdef MELF_JPEG_ROUNDS
+__device__ uint32_t g_jpeg_rounds[8192];
+extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_rounds(uint32_t* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jpeg_rounds), sizeof(uint32_t) * (size_t)(n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 template <int T>
 __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const HuffSlow* __restrict__ g_slow,
                                                  const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
@@ -597,13 +605,16 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
     }
     e_p[tid] = ex.p;
     e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
+    int rounds = 0, redone = 0;
     for (;;) {
         __syncthreads();
         SegState ne = {0, 0, 0};
         if (tid > 0) { ne.p = e_p[tid - 1]; ne.blk = (int)(e_s[tid - 1] >> 8); ne.k = (int)(e_s[tid - 1] & 255u); }
         const bool ch = mine && (ne.p != entry.p || ne.blk != entry.blk || ne.k != entry.k);
         if (!__syncthreads_or(ch)) break;
+        ++rounds;
         if (ch) {
+            ++redone;
             entry = ne;
             ex = ne;
             jpeg_decode_segment<false>(W, look, slow, nat, L, ex, p_end, nblk, dsum, 0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
@@ -636,7 +647,19 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
                                   bxs1, c0, c1, c2, bad);
     }
     const int anybad = __syncthreads_or(bad);
+#ifdef MELF_JPEG_ROUNDS  // diagnostic build: rounds and re-decoded segments per image (tools/jpeg_rounds.py)
+    {
+        __shared__ int s_redone;
+        if (tid == 0) s_redone = 0;
+        __syncthreads();
+        atomicAdd(&s_redone, redone);
+        __syncthreads();
+        if (tid == 0 && img < 8192) g_jpeg_rounds[img] = ((uint32_t)rounds << 16) | (uint32_t)min(s_redone * 100 / max(nseg, 1), 65535);
+    }
     if (tid == 0) status[img] = (anybad || done_blocks < total_blocks) ? 2 : 0;
+#else
+    if (tid == 0) status[img] = (anybad || done_blocks < total_blocks) ? 2 : 0;
+#endif
 }
 
 // ------------------------------------------------------------------ J2: IDCT ----

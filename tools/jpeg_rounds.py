@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""How many synchronisation rounds the segment-parallel Huffman kernel needs, and how many segment decodes it
+repeats (diagnostic build `make -C meterelf_amd/csrc stamp`, which returns them in the status word's high bits)."""
+import ctypes as C
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('MELF_LIB_PATH', os.path.join(ROOT, 'meterelf_amd', 'csrc', 'libmeterelf_hip_stamp.so'))
+import numpy as np
+
+from meterelf_amd import MeterReader, _hip, _params
+
+sd = sys.argv[1] if len(sys.argv) > 1 else 'sample-images2'
+d = os.path.join(ROOT, 'tests', 'golden', sd)
+reader = MeterReader(_params.load(os.path.join(d, 'params.yml')))
+blobs = [open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(d, '*.jpg')))]
+(H, W, ok, _) = _hip.jpeg_probe(blobs[-1])
+blobs = [b for b in blobs if _hip.jpeg_probe(b)[:2] == (H, W)]
+n = len(blobs)
+out = np.zeros((n, H, W, 3), np.uint8)
+status = np.zeros(n, np.int32)
+(ptrs, sizes, keep) = _hip._file_table(blobs)
+L = _hip.lib()
+_hip.check(L.melf_jpeg_decode_batch(reader.ctx._h, ptrs, sizes, n, H, W, out.ctypes.data_as(C.c_void_p), 0, status.ctypes.data_as(C.c_void_p)))
+assert (status == 0).all()
+st = np.zeros(n, np.uint32)
+assert L.melf_debug_jpeg_rounds(st.ctypes.data_as(C.c_void_p), n) == 0
+rounds = (st >> 16).astype(int)
+redo = (st & 0xffff).astype(int)
+print('%s: %d files | rounds after the first pass: min %d median %d max %d | segments decoded again (%% of segments, summed over rounds): median %d max %d'
+      % (sd, n, rounds.min(), int(np.median(rounds)), rounds.max(), int(np.median(redo)), redo.max()))
+print('  histogram of rounds:', dict(zip(*np.unique(rounds, return_counts=True))))
