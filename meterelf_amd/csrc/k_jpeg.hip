@@ -8,10 +8,13 @@
 // the algorithm descriptions in the libjpeg documentation (jidctint / jdsample / jdcolor) and
 // pinned bit-for-bit against Pillow on the reference's 304 fixture files plus synthetic files.
 //
-//   host   parse markers, build Huffman lookup tables, strip byte stuffing / RSTn markers
-//   J1     k_jpeg_huff   one lane per image: Huffman decode -> int16 coefficient blocks
-//   J2     k_jpeg_idct   one thread per 8x8 block: dequantise + ISLOW IDCT -> u8 planes
-//   J3     k_jpeg_color  one thread per 4 pixels: fancy upsample + YCC->BGR -> NHWC frame
+//   host   parse markers, canonical Huffman data, strip byte stuffing / RSTn markers (recording where the
+//          restart intervals begin)
+//   J1     k_jpeg_huff      one workgroup per image, one lane per bit-stream segment (speculative decode until
+//                           the segments' exit states reach a fixed point) -> int16 coefficient blocks
+//          k_jpeg_huff_rst  streams with restart intervals: one lane per interval, no speculation needed
+//   J2     k_jpeg_idct      one thread per 8x8 block: dequantise + ISLOW IDCT -> u8 planes
+//   J3     k_jpeg_color420  8 pixels per thread: fancy upsample + YCC->BGR -> NHWC frame (k_jpeg_color: other modes)
 #include "melf_internal.h"
 
 #include <algorithm>
@@ -197,6 +200,8 @@ struct JpegImageDev {
     uint8_t ncomp, hs0, vs0, ok;
     uint8_t tq[3], td[3], ta[3];
     uint8_t pad[3];
+    uint32_t rst_off, rst_cnt;    // restart intervals: table of their byte offsets in the clean scan (relative to the
+                                  // scan area), number of intervals
 };
 static_assert(sizeof(JpegImageDev) % 4 == 0, "record must stay dword aligned");
 
@@ -212,31 +217,28 @@ struct HuffSlow {  // canonical decode data (JPEG spec F.2.2.3) for code lengths
 constexpr int SLOW_DW = 96;
 static_assert(sizeof(HuffSlow) == SLOW_DW * 4, "HuffSlow is copied to LDS as dwords");
 
-static void build_huff(const HuffSpec& t, uint16_t* look /* 256 */, HuffSlow* slow)
+static void build_huff(const HuffSpec& t, HuffSlow* slow)
 {
-    memset(look, 0, 256 * sizeof(uint16_t));
     memset(slow, 0, sizeof(*slow));
     memcpy(slow->huffval, t.vals, t.nvals);
     int code = 0, p = 0;
     for (int l = 1; l <= 16; ++l) {
         slow->valoff[l - 1] = p - code;
-        for (int k = 0; k < t.bits[l]; ++k, ++p, ++code) {
-            if (l <= 8 && p < 256) {
-                const int first = (code << (8 - l)) & 255, cnt = 1 << (8 - l);
-                for (int q = 0; q < cnt; ++q) look[(first + q) & 255] = (uint16_t)((l << 8) | t.vals[p]);
-            }
-        }
+        p += t.bits[l];
+        code += t.bits[l];
         slow->limit[l - 1] = (uint32_t)code;
         code <<= 1;
     }
 }
 
 // Copies the entropy-coded segment without byte stuffing (FF 00 -> FF), fill bytes and RSTn markers;
-// stops at any other marker (normally EOI).  Restart boundaries stay recognisable to the decoder as
-// "discard the rest of the current byte after every restart_interval MCUs".
-static size_t clean_scan(const uint8_t* s, size_t n, uint8_t* out)
+// stops at any other marker (normally EOI).  rst[k] receives the offset (in the clean stream) at which
+// restart interval k begins (rst[0] = 0); *rst_found counts the intervals seen.
+static size_t clean_scan(const uint8_t* s, size_t n, uint8_t* out, uint32_t* rst, int rst_cap, int* rst_found)
 {
     size_t o = 0, i = 0;
+    *rst_found = 1;
+    if (rst && rst_cap > 0) rst[0] = 0;
     while (i < n) {
         const uint8_t* f = (const uint8_t*)memchr(s + i, 0xFF, n - i);
         const size_t run = f ? (size_t)(f - (s + i)) : n - i;
@@ -248,7 +250,11 @@ static size_t clean_scan(const uint8_t* s, size_t n, uint8_t* out)
         const uint8_t m = s[i + 1];
         if (m == 0x00) { out[o++] = 0xFF; i += 2; }
         else if (m == 0xFF) { i += 1; }                   // fill byte
-        else if (m >= 0xD0 && m <= 0xD7) { i += 2; }       // RSTn
+        else if (m >= 0xD0 && m <= 0xD7) {                // RSTn: the next interval starts here, byte aligned
+            if (rst && *rst_found < rst_cap) rst[*rst_found] = (uint32_t)o;
+            ++*rst_found;
+            i += 2;
+        }
         else break;                                        // EOI or another marker: end of scan
     }
     return o;
@@ -259,147 +265,6 @@ __device__ __constant__ uint8_t c_zz2nat[64] = {
     0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-// Sequential fallback (streams with restart intervals, scans too long for LDS): one lane per image.
-// The loop is a flat state machine -- one Huffman symbol per iteration whatever
-// block or coefficient the lane is at -- so lanes stay busy although their images differ.  All decode
-// tables of the workgroup's images live in LDS (8-bit first-level lookup, canonical limits for longer
-// codes); the bit stream is read as aligned dwords two words ahead of the bit buffer.
-template <int IPB>
-__global__ __launch_bounds__(IPB) void k_jpeg_huff_seq(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_look,
-                                                   const HuffSlow* __restrict__ g_slow, const uint8_t* __restrict__ scan,
-                                                   int n, int16_t* __restrict__ coefs, int32_t* __restrict__ status)
-{
-    __shared__ uint16_t look[IPB * 1024];   // [image in block][table dc0, dc1, ac0, ac1][256]
-    __shared__ uint32_t slow[IPB * 4 * SLOW_DW];  // [image in block][table] HuffSlow
-    __shared__ uint8_t nat[64];
-    __shared__ __attribute__((aligned(16))) uint32_t sbuf[IPB * 16];  // 64 bytes of bit stream per lane
-    const int lane = threadIdx.x;
-    const int img = blockIdx.x * IPB + lane;
-    {
-        const int here = min(IPB, n - blockIdx.x * IPB);
-        const uint32_t* src = (const uint32_t*)(g_look + (size_t)blockIdx.x * IPB * 1024);
-        uint32_t* dst = (uint32_t*)look;
-        for (int i = lane; i < IPB * 512; i += IPB) dst[i] = i < here * 512 ? src[i] : 0u;
-        const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)blockIdx.x * IPB * 4);
-        for (int i = lane; i < IPB * 4 * SLOW_DW; i += IPB) slow[i] = i < here * 4 * SLOW_DW ? ssrc[i] : 0u;
-        for (int i = lane; i < 64; i += IPB) nat[i] = c_zz2nat[i];
-    }
-    __syncthreads();
-    if (img >= n) return;
-    // every field goes into its own register: indexing the record by component would put it in scratch
-    const JpegImageDev* R = imgs + img;
-    if (R->ok != 2) return;  // 1: the segment-parallel kernel's image, 0: not decodable
-    const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x, restart_interval = R->restart_interval;
-    const uint32_t cblk0 = R->coef_blk[0], cblk1 = R->coef_blk[1], cblk2 = R->coef_blk[2];
-    const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
-    const int td0 = R->td[0], td1 = R->td[1], td2 = R->td[2];
-    const int ta0 = 2 + R->ta[0], ta1 = 2 + R->ta[1], ta2 = 2 + R->ta[2];
-    const uint4* p = (const uint4*)(scan + R->scan_off);  // 64-byte aligned, zero-padded by >= 128 bytes
-    const uint32_t nchunks = R->scan_len / 64 + 2;         // 64-byte chunks inside the padded area
-    const uint16_t* mylook = look + lane * 1024;
-    const uint32_t* myslow = slow + lane * 4 * SLOW_DW;
-
-    const int total_mcus = mcus_x * (int)R->mcus_y;
-    const int yblocks = ncomp == 1 ? 1 : hs0 * vs0;
-    const int blocks_per_mcu = ncomp == 1 ? 1 : yblocks + 2;
-    int mcu = 0, mx = 0, my = 0, blk = 0, k = 0, comp = 0;
-    int pred0 = 0, pred1 = 0, pred2 = 0;
-    int restarts_left = restart_interval;
-    int16_t* cblock = coefs + (size_t)cblk0 * 64;
-    int tdc = td0, tac = ta0;
-    int32_t st = 0;
-
-    // Bit buffer: the top `bitcnt` bits are valid.  The stream comes in 64-byte chunks, loaded on demand
-    // into the lane's LDS slot and consumed a dword per refill.  No load stays in flight across loop
-    // iterations: gfx9 counts loads and stores in one vmcnt, so a pending load would make every iteration
-    // wait for the coefficient stores; this way the wait comes once per 64 bytes (~100 symbols).
-    uint32_t* mybuf = sbuf + lane * 16;
-    uint32_t chunk = 0;
-    int sub = 16;
-    uint64_t bitbuf = 0;
-    int bitcnt = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the record's fields are in registers before the loop starts
-
-    while (mcu < total_mcus) {
-        if (bitcnt <= 32) {
-            if (sub == 16) {
-                if (chunk >= nchunks) { st = 2; break; }  // ran past the data: truncated or corrupt
-                const uint4* q = p + (size_t)chunk * 4;
-                const uint4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
-                ((uint4*)mybuf)[0] = c0; ((uint4*)mybuf)[1] = c1; ((uint4*)mybuf)[2] = c2; ((uint4*)mybuf)[3] = c3;
-                ++chunk;
-                sub = 0;
-            }
-            const uint32_t raw32 = mybuf[sub++];
-            bitbuf |= (uint64_t)__builtin_bswap32(raw32) << (32 - bitcnt);
-            bitcnt += 32;
-        }
-        const uint32_t w = (uint32_t)(bitbuf >> 32);  // the next 32 bits: code + magnitude fit (<= 16 + 15)
-        const int t = k == 0 ? tdc : tac;
-        const uint32_t e = mylook[t * 256 + (w >> 24)];
-        int len = e >> 8, sym = e & 255;
-        if (!e) {
-            const uint32_t* s = myslow + t * SLOW_DW;
-            const uint32_t code16 = w >> 16;
-            len = 9;
-#pragma unroll
-            for (int l = 9; l <= 16; ++l) len += (code16 >> (16 - l)) >= s[l - 1] ? 1 : 0;
-            if (len > 16) { st = 2; break; }
-            const int idx = (int)s[16 + len - 1] + (int)(code16 >> (16 - len));
-            sym = ((const uint8_t*)(s + 32))[idx & 255];
-        }
-        const int sbits = sym & 15;
-        const int run = sym >> 4;
-        const uint32_t raw = (uint32_t)(((uint64_t)(w << len)) >> (32 - sbits));  // sbits = 0 -> 0
-        const int v = (sbits && !(raw >> (sbits - 1))) ? (int)raw - (1 << sbits) + 1 : (int)raw;  // EXTEND (F.2.2.1)
-        bitbuf <<= len + sbits;
-        bitcnt -= len + sbits;
-        if (k == 0) {
-            int pr = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
-            pr += v;
-            if (comp == 0) pred0 = pr; else if (comp == 1) pred1 = pr; else pred2 = pr;
-            cblock[0] = (int16_t)pr;
-            k = 1;
-        } else if (sbits) {
-            k += run;
-            if (k < 64) cblock[nat[k]] = (int16_t)v;
-            ++k;
-        } else if (run == 15) {
-            k += 16;
-        } else {
-            k = 64;  // EOB
-        }
-        if (k >= 64) {  // next block
-            k = 0;
-            if (++blk == blocks_per_mcu) {
-                blk = 0;
-                ++mcu;
-                if (++mx == mcus_x) { mx = 0; ++my; }
-                if (restart_interval && --restarts_left == 0) {
-                    restarts_left = restart_interval;
-                    const int drop = bitcnt & 7;  // the restart marker (stripped on the host) was byte aligned
-                    bitbuf <<= drop;
-                    bitcnt -= drop;
-                    pred0 = pred1 = pred2 = 0;
-                }
-            }
-            if (blk < yblocks) {
-                comp = 0;
-                const int sub_y = blk >= hs0 ? 1 : 0;  // hs0, vs0 <= 2
-                const int bx = mx * hs0 + (blk - sub_y * hs0), by = my * vs0 + sub_y;
-                cblock = coefs + ((size_t)cblk0 + (size_t)(by * bxs0 + bx)) * 64;
-                tdc = td0; tac = ta0;
-            } else {
-                comp = 1 + blk - yblocks;
-                cblock = coefs + ((size_t)(comp == 1 ? cblk1 : cblk2) + (size_t)(my * bxs1 + mx)) * 64;
-                tdc = comp == 1 ? td1 : td2;
-                tac = comp == 1 ? ta1 : ta2;
-            }
-        }
-    }
-    status[img] = st;
-}
 
 // ------------------------------------------------- J1: Huffman, segment-parallel ----
 // One workgroup per image, one lane per bit-stream segment.  A Huffman stream can only be decoded from
@@ -662,6 +527,77 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
 #endif
 }
 
+// Streams with restart intervals need no speculation: every interval starts byte aligned with the DC
+// predictors at zero.  One workgroup per image, lanes stride over the intervals (the host recorded where
+// each begins while stripping the markers) and write their coefficients directly.
+template <int T>
+__global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restrict__ imgs, const HuffSlow* __restrict__ g_slow,
+                                                     const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
+                                                     int32_t* __restrict__ status)
+{
+    __shared__ uint16_t look[4 << LOOK_BITS];
+    __shared__ uint32_t slow[4 * SLOW_DW];
+    __shared__ uint8_t nat[64];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x;
+    const JpegImageDev* R = imgs + img;
+    if (R->ok != 2) return;
+    const uint32_t* W = (const uint32_t*)(scan + R->scan_off);
+    const uint32_t* rst = (const uint32_t*)(scan + R->rst_off);
+    {
+        const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)img * 4);
+        for (int i = tid; i < 4 * SLOW_DW; i += T) slow[i] = ssrc[i];
+        for (int i = tid; i < 64; i += T) nat[i] = c_zz2nat[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < (4 << LOOK_BITS); i += T) {
+        const uint32_t* sl = slow + (i >> LOOK_BITS) * SLOW_DW;
+        const uint32_t x = (uint32_t)i & ((1u << LOOK_BITS) - 1u);
+        int len = 1;
+#pragma unroll
+        for (int l = 1; l <= LOOK_BITS; ++l) len += (x >> (LOOK_BITS - l)) >= sl[l - 1] ? 1 : 0;
+        uint32_t e = 0;
+        if (len <= LOOK_BITS) {
+            const int idx = (int)sl[16 + len - 1] + (int)(x >> (LOOK_BITS - len));
+            e = ((uint32_t)len << 8) | ((const uint8_t*)(sl + 32))[idx & 255];
+        }
+        look[i] = (uint16_t)e;
+    }
+    const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
+    McuLayout L;
+    L.yblocks = ncomp == 1 ? 1 : hs0 * vs0;
+    L.bpm = ncomp == 1 ? 1 : L.yblocks + 2;
+    L.dc_bits = L.ac_bits = L.comp_bits = 0;
+    for (int b = 0; b < L.bpm; ++b) {
+        const int c = b < L.yblocks ? 0 : 1 + b - L.yblocks;
+        L.dc_bits |= (uint32_t)(R->td[c] & 1) << b;
+        L.ac_bits |= (uint32_t)(R->ta[c] & 1) << b;
+        L.comp_bits |= (uint32_t)c << (2 * b);
+    }
+    const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
+    const int per_interval = (int)R->restart_interval * L.bpm;
+    const int nint = (int)R->rst_cnt;
+    const int expected = (total_blocks + per_interval - 1) / per_interval;
+    const uint32_t bits = R->scan_len * 8u;
+    const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
+    int16_t* c0 = coefs + (size_t)R->coef_blk[0] * 64;
+    int16_t* c1 = coefs + (size_t)R->coef_blk[1] * 64;
+    int16_t* c2 = coefs + (size_t)R->coef_blk[2] * 64;
+    __syncthreads();
+    int bad = nint != expected ? 1 : 0;  // markers missing or surplus: corrupt stream
+    for (int it = tid; it < min(nint, expected); it += T) {
+        SegState st = {rst[it] * 8u, 0, 0};
+        const int nb0 = it * per_interval, nb1 = min(nb0 + per_interval, total_blocks);
+        int n2;
+        int64_t d2;
+        jpeg_decode_segment<true>(W, look, slow, nat, L, st, bits + 32u, n2, d2, nb0, nb1, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0,
+                                  c1, c2, bad);
+        if (n2 < nb1 - nb0) bad = 1;  // ran out of data before the interval's last block
+    }
+    const int anybad = __syncthreads_or(bad);
+    if (tid == 0) status[img] = anybad ? 2 : 0;
+}
+
 // ------------------------------------------------------------------ J2: IDCT ----
 // The "accurate integer" inverse DCT (libjpeg jidctint: Loeffler-Ligtenberg-Moschytz, 13-bit
 // constants, 2 extra bits kept between the passes).  Every shift below is part of the result.
@@ -883,10 +819,10 @@ struct JpegWorkspace {
     int32_t* d_status = nullptr;
     size_t status_cap = 0;
     // layout of the current batch inside the stage buffers
-    size_t off_imgs = 0, off_qt = 0, off_look = 0, off_slow = 0, off_scan = 0, total = 0;
+    size_t off_imgs = 0, off_qt = 0, off_slow = 0, off_scan = 0, total = 0;
     size_t coef_elems = 0, plane_bytes = 0;
     int max_blocks = 0;
-    int n_par = 0, n_seq = 0;   // images for the segment-parallel / the sequential Huffman kernel
+    int n_par = 0, n_seq = 0;   // images for the segment-parallel / the restart-interval Huffman kernel
     int n_420 = 0;              // three-component 4:2:0 images (fast colour kernel)
     size_t max_par_scan = 0;    // longest clean scan among the former (bytes)
 };
@@ -968,7 +904,14 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
             blocks += (int)nb;
         }
         max_blocks = std::max(max_blocks, blocks);
-        scan_off[i + 1] = scan_off[i] + align_up(sizes[i] - h.scan_begin + 128, 64);
+        size_t region = align_up(sizes[i] - h.scan_begin + 128, 64);
+        if (h.restart_interval) {  // room for the table of interval offsets behind the scan
+            const size_t mcus = (size_t)r.mcus_x * r.mcus_y;
+            r.rst_cnt = (uint32_t)((mcus + h.restart_interval - 1) / h.restart_interval);  // expected; replaced by the number found
+            r.rst_off = (uint32_t)region;                                                   // relative for now
+            region += align_up(((size_t)r.rst_cnt + 1) * sizeof(uint32_t), 64);
+        }
+        scan_off[i + 1] = scan_off[i] + region;
     }
     if (coef_blocks >= (1ull << 32) / 64 || plane_bytes >= (1ull << 32) || scan_off[n] >= (1ull << 32)) {
         if (err) *err = "JPEG batch too large for 32-bit offsets; decode in smaller batches";
@@ -976,8 +919,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
     }
     w->off_imgs = 0;
     w->off_qt = align_up(w->off_imgs + (size_t)n * sizeof(JpegImageDev), 256);
-    w->off_look = align_up(w->off_qt + (size_t)n * 4 * 64 * sizeof(uint16_t), 256);
-    w->off_slow = align_up(w->off_look + (size_t)n * 4 * 256 * sizeof(uint16_t), 256);
+    w->off_slow = align_up(w->off_qt + (size_t)n * 4 * 64 * sizeof(uint16_t), 256);
     w->off_scan = align_up(w->off_slow + (size_t)n * 4 * sizeof(HuffSlow), 256);
     w->total = w->off_scan + scan_off[n] + 64;
     w->coef_elems = coef_blocks * 64;
@@ -997,25 +939,28 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
     par_for([&](int i) {
         JpegImageDev& r = rec[i];
         uint16_t* qt = (uint16_t*)(base + w->off_qt) + (size_t)i * 256;
-        uint16_t* look = (uint16_t*)(base + w->off_look) + (size_t)i * 1024;
         HuffSlow* slow = (HuffSlow*)(base + w->off_slow) + (size_t)i * 4;
-        if (host_status[i] != 0) {
-            memset(look, 0, 1024 * sizeof(uint16_t));
-            return;
-        }
+        if (host_status[i] != 0) return;
         const JpegHeader& h = hdr[i];
         for (int t = 0; t < 4; ++t) {
             if (h.qt_set[t]) memcpy(qt + t * 64, h.qt[t], 128); else memset(qt + t * 64, 0, 128);
         }
         for (int t = 0; t < 2; ++t) {
-            if (h.dc[t].set) build_huff(h.dc[t], look + t * 256, slow + t); else { memset(look + t * 256, 0, 512); memset(slow + t, 0, sizeof(HuffSlow)); }
-            if (h.ac[t].set) build_huff(h.ac[t], look + (2 + t) * 256, slow + 2 + t); else { memset(look + (2 + t) * 256, 0, 512); memset(slow + 2 + t, 0, sizeof(HuffSlow)); }
+            if (h.dc[t].set) build_huff(h.dc[t], slow + t); else memset(slow + t, 0, sizeof(HuffSlow));
+            if (h.ac[t].set) build_huff(h.ac[t], slow + 2 + t); else memset(slow + 2 + t, 0, sizeof(HuffSlow));
         }
         uint8_t* dst = base + w->off_scan + scan_off[i];
-        const size_t len = clean_scan(data[i] + h.scan_begin, sizes[i] - h.scan_begin, dst);
-        memset(dst + len, 0, scan_off[i + 1] - scan_off[i] - len);
+        uint32_t* rst = h.restart_interval ? (uint32_t*)(dst + r.rst_off) : nullptr;
+        int found = 0;
+        const size_t len = clean_scan(data[i] + h.scan_begin, sizes[i] - h.scan_begin, dst, rst, (int)r.rst_cnt + 1, &found);
+        const size_t scan_region = h.restart_interval ? r.rst_off : scan_off[i + 1] - scan_off[i];
+        memset(dst + len, 0, scan_region - len);
         r.scan_off = (uint32_t)scan_off[i];
         r.scan_len = (uint32_t)len;
+        if (h.restart_interval) {
+            r.rst_off = (uint32_t)(scan_off[i] + r.rst_off);
+            r.rst_cnt = (uint32_t)found;
+        }
         r.ok = h.restart_interval != 0 ? 2 : 1;
     });
     w->n_par = w->n_seq = w->n_420 = 0;
@@ -1050,7 +995,6 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
     JTRY(hipMemsetAsync(w->d_status, 0, (size_t)n * sizeof(int32_t), stream));
     const JpegImageDev* imgs = (const JpegImageDev*)(w->d_stage + w->off_imgs);
     const uint16_t* qt = (const uint16_t*)(w->d_stage + w->off_qt);
-    const uint16_t* look = (const uint16_t*)(w->d_stage + w->off_look);
     const HuffSlow* slow = (const HuffSlow*)(w->d_stage + w->off_slow);
     const uint8_t* scan = w->d_stage + w->off_scan;
     if (timer) timer(timer_arg, 0, 0);
@@ -1065,8 +1009,8 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
         else LAUNCH_HUFF(512);
 #undef LAUNCH_HUFF
     }
-    if (w->n_seq > 0) {  // restart intervals / very long scans: 16 images per workgroup, one lane each
-        hipLaunchKernelGGL(k_jpeg_huff_seq<16>, dim3((n + 15) / 16), dim3(16), 0, stream, imgs, look, slow, scan, n, w->d_coefs, w->d_status);
+    if (w->n_seq > 0) {  // streams with restart intervals: one lane per interval
+        hipLaunchKernelGGL(k_jpeg_huff_rst<256>, dim3(n), dim3(256), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status);
     }
     if (timer) timer(timer_arg, 0, 1);
     JTRY(hipGetLastError());
