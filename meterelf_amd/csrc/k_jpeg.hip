@@ -599,6 +599,12 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
 }
 
 // ------------------------------------------------------------------ J2: IDCT ----
+// The pixel window J2 / J3 produce (x0, y0 multiples of 16): the whole frame, or -- when the caller only reads the
+// meter_rect crop -- that crop plus one MCU of context for the chroma filter.
+struct JpegWindow {
+    int x0, y0, x1, y1;
+};
+
 // The "accurate integer" inverse DCT (libjpeg jidctint: Loeffler-Ligtenberg-Moschytz, 13-bit
 // constants, 2 extra bits kept between the passes).  Every shift below is part of the result.
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -632,19 +638,25 @@ __device__ __forceinline__ void idct_1d(const int in[8], int out[8], const int s
 
 __global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImageDev* __restrict__ imgs, const uint16_t* __restrict__ g_qt,
                                                    const int16_t* __restrict__ coefs, const int32_t* __restrict__ status,
-                                                   uint8_t* __restrict__ planes)
+                                                   uint8_t* __restrict__ planes, JpegWindow win)
 {
     const int img = blockIdx.y;
     const JpegImageDev I = imgs[img];
     if (!I.ok || status[img] != 0) return;
-    const int nb0 = I.blocks_x[0] * I.blocks_y[0];
-    const int nbc = I.ncomp == 3 ? I.blocks_x[1] * I.blocks_y[1] : 0;
+    // blocks of the MCUs that overlap the pixel window (16-aligned, so whole MCUs in every sampling mode)
+    const int mw = 8 * I.hs0, mh = 8 * I.vs0;
+    const int mx0 = win.x0 / mw, mx1 = min((win.x1 + mw - 1) / mw, (int)I.mcus_x);
+    const int my0 = win.y0 / mh, my1 = min((win.y1 + mh - 1) / mh, (int)I.mcus_y);
+    const int w0 = (mx1 - mx0) * I.hs0, h0 = (my1 - my0) * I.vs0, wc = mx1 - mx0, hc = my1 - my0;
+    const int nb0 = w0 * h0;
+    const int nbc = I.ncomp == 3 ? wc * hc : 0;
     int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nb0 + 2 * nbc) return;
     int c = 0;
     if (j >= nb0) { j -= nb0; c = 1; if (j >= nbc) { j -= nbc; c = 2; } }
-    const int by = j / I.blocks_x[c], bx = j - by * I.blocks_x[c];
-    const int16_t* src = coefs + ((size_t)I.coef_blk[c] + j) * 64;
+    const int ww = c == 0 ? w0 : wc;
+    const int by = (c == 0 ? my0 * I.vs0 : my0) + j / ww, bx = (c == 0 ? mx0 * I.hs0 : mx0) + j % ww;
+    const int16_t* src = coefs + ((size_t)I.coef_blk[c] + (size_t)by * I.blocks_x[c] + bx) * 64;
     const uint16_t* q = g_qt + ((size_t)img * 4 + I.tq[c]) * 64;
     int ws[64];
     // pass 1: columns
@@ -714,11 +726,11 @@ __device__ __forceinline__ uint32_t ycc_to_bgr(int y, int cb, int cr)
 // replaced by the sample itself ((4t + 8) >> 4 == (3t + t + 8) >> 4), i.e. clamped indices.
 __global__ __launch_bounds__(256) void k_jpeg_color420(const JpegImageDev* __restrict__ imgs, const int32_t* __restrict__ status,
                                                        const uint8_t* __restrict__ planes, int H, int W,
-                                                       uint8_t* __restrict__ frames)
+                                                       uint8_t* __restrict__ frames, JpegWindow win)
 {
-    const int img = blockIdx.z, y = blockIdx.y;
-    const int g = blockIdx.x * 256 + threadIdx.x;  // group of 8 pixels
-    if (g * 8 >= W) return;
+    const int img = blockIdx.z, y = win.y0 + blockIdx.y;
+    const int g = win.x0 / 8 + blockIdx.x * 256 + threadIdx.x;  // group of 8 pixels
+    if (g * 8 >= win.x1) return;
     const JpegImageDev* R = imgs + img;
     if (!(R->ok && R->ncomp == 3 && R->hs0 == 2 && R->vs0 == 2)) return;  // the generic kernel's image
     if (status[img] != 0) {  // failed in the entropy decoder: zero frame
@@ -764,11 +776,11 @@ __global__ __launch_bounds__(256) void k_jpeg_color420(const JpegImageDev* __res
 
 __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImageDev* __restrict__ imgs, const int32_t* __restrict__ status,
                                                     const uint8_t* __restrict__ planes, int H, int W,
-                                                    uint8_t* __restrict__ frames, int fast420)
+                                                    uint8_t* __restrict__ frames, int fast420, JpegWindow win)
 {
-    const int img = blockIdx.z, y = blockIdx.y;
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x0 >= W) return;
+    const int img = blockIdx.z, y = win.y0 + blockIdx.y;
+    const int x0 = win.x0 + (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= win.x1) return;
     const JpegImageDev I = imgs[img];
     if (fast420 && I.ok && I.ncomp == 3 && I.hs0 == 2 && I.vs0 == 2) return;  // k_jpeg_color420 did it
     uint8_t* out = frames + ((size_t)img * H + y) * W * 3 + (size_t)x0 * 3;
@@ -976,8 +988,16 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
 
 // Device half: H2D of the stage buffer, then J1..J3.  `timer(k)` brackets kernel k (0..2) when profiling.
 int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
-                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg)
+                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg, const int* rect)
 {
+    // window: the caller's rectangle grown by one MCU (chroma filter context) and aligned to 16, or the frame
+    JpegWindow win = {0, 0, W, H};
+    if (rect) {
+        win.x0 = std::max(0, (rect[0] - 16) & ~15); win.y0 = std::max(0, (rect[1] - 16) & ~15);
+        win.x1 = std::min(W, (rect[2] + 16 + 15) & ~15); win.y1 = std::min(H, (rect[3] + 16 + 15) & ~15);
+        if (win.x1 <= win.x0 || win.y1 <= win.y0) win = {0, 0, W, H};
+    }
+    const int win_w = win.x1 - win.x0, win_h = win.y1 - win.y0;
 #define JTRY(expr)                                                               \
     do {                                                                         \
         hipError_t e_ = (expr);                                                  \
@@ -1016,15 +1036,18 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
     JTRY(hipGetLastError());
     if (w->max_blocks > 0) {
         if (timer) timer(timer_arg, 1, 0);
-        hipLaunchKernelGGL(k_jpeg_idct, dim3((w->max_blocks + 255) / 256, n), dim3(256), 0, stream, imgs, qt, w->d_coefs, w->d_status, w->d_planes);
+        // at most (window / 8)^2 luma blocks + two chroma planes of up to the same count (4:4:4)
+        const int wblocks = 3 * ((win_w + 15) / 8 + 2) * ((win_h + 15) / 8 + 2);
+        const int nblk = std::min(w->max_blocks, wblocks);
+        hipLaunchKernelGGL(k_jpeg_idct, dim3((nblk + 255) / 256, n), dim3(256), 0, stream, imgs, qt, w->d_coefs, w->d_status, w->d_planes, win);
         if (timer) timer(timer_arg, 1, 1);
         JTRY(hipGetLastError());
     }
     if (timer) timer(timer_arg, 2, 0);
     const int fast420 = (W % 8 == 0 && w->n_420 > 0) ? 1 : 0;
-    if (fast420) hipLaunchKernelGGL(k_jpeg_color420, dim3((W / 8 + 255) / 256, H, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames);
+    if (fast420) hipLaunchKernelGGL(k_jpeg_color420, dim3((win_w / 8 + 255) / 256, win_h, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, win);
     if (!fast420 || w->n_420 < n)
-        hipLaunchKernelGGL(k_jpeg_color, dim3((W + 1023) / 1024, H, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, fast420);
+        hipLaunchKernelGGL(k_jpeg_color, dim3((win_w + 1023) / 1024, win_h, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, fast420, win);
     if (timer) timer(timer_arg, 2, 1);
     JTRY(hipGetLastError());
     if (status_out_host) {

@@ -861,7 +861,7 @@ void jpeg_timer_hook(void* arg, int k, int stop)
 
 // decode into device memory `d_frames` (n*H*W*3 bytes) on the context's stream; fills status (host)
 int jpeg_decode_to_device(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
-                          uint8_t* d_frames, int32_t* status)
+                          uint8_t* d_frames, int32_t* status, const int* rect)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned stage buffer of the previous batch is free again
     static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
@@ -872,7 +872,7 @@ int jpeg_decode_to_device(melf_ctx* c, const uint8_t* const* data, const size_t*
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<int32_t> dstat(n);
     JpegTimers t{c, c->stream, {}, {false, false, false}};
-    if (int rc = jpeg_launch_batch(c->jpeg, n, H, W, d_frames, dstat.data(), c->stream, &err, jpeg_timer_hook, &t)) return fail(rc, err);
+    if (int rc = jpeg_launch_batch(c->jpeg, n, H, W, d_frames, dstat.data(), c->stream, &err, jpeg_timer_hook, &t, rect)) return fail(rc, err);
     if (trace) {
         const auto t2 = std::chrono::steady_clock::now();
         fprintf(stderr, "[melf jpeg] n=%d host prepare %.2f ms, H2D + kernels + status %.2f ms\n", n,
@@ -897,7 +897,7 @@ extern "C" int melf_jpeg_decode_batch(melf_ctx* c, const uint8_t* const* data, c
         if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
         d = c->d_stage_in;
     }
-    if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, d, status)) return rc;
+    if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, d, status, nullptr)) return rc;
     if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -915,6 +915,8 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)n * H * W * 3;
     if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
-    if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, c->d_stage_in, status)) return rc;
+    // the reading path only looks at the meter_rect crop: IDCT and colour conversion are limited to it
+    const int rect[4] = {c->P.rect_x0, c->P.rect_y0, c->P.rect_x1, c->P.rect_y1};
+    if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, c->d_stage_in, status, rect)) return rc;
     return melf_process_batch_dev(c, c->d_stage_in, n, H, W, (size_t)H * W * 3, nullptr, out_host, c->stream);
 }

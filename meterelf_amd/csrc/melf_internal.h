@@ -105,7 +105,8 @@ int jpeg_probe(const uint8_t* data, size_t size, int* H, int* W, int* supported,
 int jpeg_prepare_batch(JpegWorkspace** ws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
                        int32_t* host_status, std::string* err);
 int jpeg_launch_batch(JpegWorkspace* ws, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
-                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg);
+                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg,
+                      const int* rect /* x0, y0, x1, y1: only this part of each frame is needed; NULL = all */);
 void jpeg_workspace_free(JpegWorkspace* ws);
 
 }  // namespace melf
