@@ -285,6 +285,16 @@ constexpr int LOOK_BITS = 11;  // first-level lookup of the segment-parallel ker
 
 // Per-MCU-position tables packed into registers: 1 bit of DC table id, 1 bit of AC table id and 2 bits
 // of component per block position (an MCU has at most 6 blocks here).
+// The pixel window the decoder produces (x0, y0 multiples of 16): the whole frame, or -- when the caller only
+// reads the meter_rect crop -- that crop plus one MCU of context for the chroma filter.  Coefficients outside it
+// are neither zeroed nor stored, J2 / J3 do not run there.
+struct JpegWindow {
+    int x0, y0, x1, y1;
+};
+struct McuWindow {  // the same in MCUs of one image
+    int mx0, mx1, my0, my1;
+};
+
 struct McuLayout {
     uint32_t dc_bits, ac_bits, comp_bits;
     int bpm, yblocks;
@@ -296,14 +306,17 @@ __device__ __forceinline__ void jpeg_decode_segment(
     const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk, int64_t& dsum,
     // WRITE only:
     int nb, const int total_blocks, int pred0, int pred1, int pred2, const int hs0, const int vs0, const int mcus_x,
-    const int bxs0, const int bxs1, int16_t* __restrict__ c0, int16_t* __restrict__ c1, int16_t* __restrict__ c2, int& bad)
+    const int bxs0, const int bxs1, int16_t* __restrict__ c0, int16_t* __restrict__ c1, int16_t* __restrict__ c2, int& bad,
+    const McuWindow mw = McuWindow{0, 1 << 30, 0, 1 << 30})
 {
     uint32_t p = s.p;
     int blk = s.blk, k = s.k;
     int mx = 0, my = 0;
     int16_t* cb = nullptr;
     auto block_ptr = [&]() {
-        if (blk < L.yblocks) {
+        if (mx < mw.mx0 || mx >= mw.mx1 || my < mw.my0 || my >= mw.my1) {
+            cb = nullptr;  // outside the window: decoded (the DC predictors need it) but not stored
+        } else if (blk < L.yblocks) {
             const int sub_y = blk >= hs0 ? 1 : 0;
             cb = c0 + (size_t)((my * vs0 + sub_y) * bxs0 + mx * hs0 + (blk - sub_y * hs0)) * 64;
         } else {
@@ -362,8 +375,8 @@ __device__ __forceinline__ void jpeg_decode_segment(
             if (isdc) {
                 int pr;
                 if (comp == 0) pr = (pred0 += v); else if (comp == 1) pr = (pred1 += v); else pr = (pred2 += v);
-                cb[0] = (int16_t)pr;
-            } else if (sbits && pos < 64) {
+                if (cb) cb[0] = (int16_t)pr;
+            } else if (sbits && pos < 64 && cb) {
                 cb[nat[pos]] = (int16_t)v;
             }
         }
@@ -399,10 +412,33 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_rounds(uin
 }
 #endif
 
+// Zeroes the coefficient blocks of the image's window (the rest of the buffer is never read) and returns the
+// window in MCUs.  Called by all threads of the image's workgroup; a __syncthreads() must follow before stores.
+template <int T>
+__device__ __forceinline__ McuWindow jpeg_zero_window(const JpegImageDev* R, const JpegWindow win, int16_t* __restrict__ coefs, int tid)
+{
+    const int hs0 = R->hs0, vs0 = R->vs0, ncomp = R->ncomp;
+    const int mwid = 8 * hs0, mhei = 8 * vs0;
+    McuWindow m;
+    m.mx0 = win.x0 / mwid; m.mx1 = min((win.x1 + mwid - 1) / mwid, (int)R->mcus_x);
+    m.my0 = win.y0 / mhei; m.my1 = min((win.y1 + mhei - 1) / mhei, (int)R->mcus_y);
+    for (int c = 0; c < ncomp; ++c) {
+        const int fx = c == 0 ? hs0 : 1, fy = c == 0 ? vs0 : 1;
+        const int bx0 = m.mx0 * fx, by0 = m.my0 * fy, w16 = (m.mx1 - m.mx0) * fx * 8, rows = (m.my1 - m.my0) * fy;
+        uint4* base = (uint4*)(coefs + (size_t)R->coef_blk[c] * 64);
+        const int bxs = R->blocks_x[c];
+        for (int i = tid; i < rows * w16; i += T) {
+            const int r = i / w16, q = i - r * w16;
+            base[((size_t)(by0 + r) * bxs + bx0) * 8 + q] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    return m;
+}
+
 template <int T>
 __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const HuffSlow* __restrict__ g_slow,
                                                  const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
-                                                 int32_t* __restrict__ status)
+                                                 int32_t* __restrict__ status, JpegWindow win)
 {
     __shared__ uint16_t look[4 << LOOK_BITS];
     __shared__ uint32_t slow[4 * SLOW_DW];
@@ -416,6 +452,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
     const JpegImageDev* R = imgs + img;
     if (R->ok != 1) return;
     const uint32_t* W = (const uint32_t*)(scan + R->scan_off);  // zero-padded by 128 bytes; read through L1/L2
+    const McuWindow mwin = jpeg_zero_window<T>(R, win, coefs, tid);  // visible to the output pass: barriers in between
     const uint32_t scan_len = R->scan_len;
     const uint32_t bits = scan_len * 8u;
     // segment length: a multiple of 32 bits with an odd dword count, so that the lanes' stream reads fall into
@@ -509,7 +546,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
         int n2;
         int64_t d2;
         jpeg_decode_segment<true>(W, look, slow, nat, L, st, p_end, n2, d2, nb_in, total_blocks, p0, p1, p2, hs0, vs0, mcus_x, bxs0,
-                                  bxs1, c0, c1, c2, bad);
+                                  bxs1, c0, c1, c2, bad, mwin);
     }
     const int anybad = __syncthreads_or(bad);
 #ifdef MELF_JPEG_ROUNDS  // diagnostic build: rounds and re-decoded segments per image (tools/jpeg_rounds.py)
@@ -533,7 +570,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
 template <int T>
 __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restrict__ imgs, const HuffSlow* __restrict__ g_slow,
                                                      const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
-                                                     int32_t* __restrict__ status)
+                                                     int32_t* __restrict__ status, JpegWindow win)
 {
     __shared__ uint16_t look[4 << LOOK_BITS];
     __shared__ uint32_t slow[4 * SLOW_DW];
@@ -544,6 +581,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
     if (R->ok != 2) return;
     const uint32_t* W = (const uint32_t*)(scan + R->scan_off);
     const uint32_t* rst = (const uint32_t*)(scan + R->rst_off);
+    const McuWindow mwin = jpeg_zero_window<T>(R, win, coefs, tid);
     {
         const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)img * 4);
         for (int i = tid; i < 4 * SLOW_DW; i += T) slow[i] = ssrc[i];
@@ -591,7 +629,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
         int n2;
         int64_t d2;
         jpeg_decode_segment<true>(W, look, slow, nat, L, st, bits + 32u, n2, d2, nb0, nb1, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0,
-                                  c1, c2, bad);
+                                  c1, c2, bad, mwin);
         if (n2 < nb1 - nb0) bad = 1;  // ran out of data before the interval's last block
     }
     const int anybad = __syncthreads_or(bad);
@@ -599,12 +637,6 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
 }
 
 // ------------------------------------------------------------------ J2: IDCT ----
-// The pixel window J2 / J3 produce (x0, y0 multiples of 16): the whole frame, or -- when the caller only reads the
-// meter_rect crop -- that crop plus one MCU of context for the chroma filter.
-struct JpegWindow {
-    int x0, y0, x1, y1;
-};
-
 // The "accurate integer" inverse DCT (libjpeg jidctint: Loeffler-Ligtenberg-Moschytz, 13-bit
 // constants, 2 extra bits kept between the passes).  Every shift below is part of the result.
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -1011,7 +1043,6 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
     JTRY(grow_dev(&w->d_planes, &w->plane_cap, w->plane_bytes + 64));
     JTRY(grow_dev(&w->d_status, &w->status_cap, (size_t)n));
     JTRY(hipMemcpyAsync(w->d_stage, w->h_stage, w->total, hipMemcpyHostToDevice, stream));
-    JTRY(hipMemsetAsync(w->d_coefs, 0, w->coef_elems * sizeof(int16_t), stream));
     JTRY(hipMemsetAsync(w->d_status, 0, (size_t)n * sizeof(int32_t), stream));
     const JpegImageDev* imgs = (const JpegImageDev*)(w->d_stage + w->off_imgs);
     const uint16_t* qt = (const uint16_t*)(w->d_stage + w->off_qt);
@@ -1022,7 +1053,7 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
         static int tsel = -1;
         if (tsel < 0) { const char* e = getenv("MELF_JPEG_T"); tsel = e ? atoi(e) : 512; }
 #define LAUNCH_HUFF(TT) \
-    hipLaunchKernelGGL(k_jpeg_huff<TT>, dim3(n), dim3(TT), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status)
+    hipLaunchKernelGGL(k_jpeg_huff<TT>, dim3(n), dim3(TT), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status, win)
         if (tsel == 128) LAUNCH_HUFF(128);
         else if (tsel == 256) LAUNCH_HUFF(256);
         else if (tsel == 1024) LAUNCH_HUFF(1024);
@@ -1030,7 +1061,7 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
 #undef LAUNCH_HUFF
     }
     if (w->n_seq > 0) {  // streams with restart intervals: one lane per interval
-        hipLaunchKernelGGL(k_jpeg_huff_rst<256>, dim3(n), dim3(256), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status);
+        hipLaunchKernelGGL(k_jpeg_huff_rst<256>, dim3(n), dim3(256), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status, win);
     }
     if (timer) timer(timer_arg, 0, 1);
     JTRY(hipGetLastError());
