@@ -181,7 +181,8 @@ int melf_inrange(melf_ctx* ctx, const uint8_t* img_host, int rows, int cols, con
  * defaults (ISLOW IDCT, fancy upsampling), i.e. what cv2.imread returns: H x W x 3 BGR u8.
  * Per-file status: 0 decoded, 1 valid JPEG outside that subset (decode it on the host instead),
  * 2 unreadable / corrupt, 3 its size is not H x W.  Frames with a non-zero status are zero-filled. */
-enum { MELF_JPEG_OK = 0, MELF_JPEG_UNSUPPORTED = 1, MELF_JPEG_CORRUPT = 2, MELF_JPEG_SIZE_MISMATCH = 3 };
+enum { MELF_JPEG_OK = 0, MELF_JPEG_UNSUPPORTED = 1, MELF_JPEG_CORRUPT = 2, MELF_JPEG_SIZE_MISMATCH = 3,
+       MELF_JPEG_UNREADABLE = 4 /* melf_jpeg_process_files: the file could not be opened or read */ };
 
 /* Header check only (no GPU, no context): image size and whether the GPU decoder handles the file. */
 int melf_jpeg_probe(const uint8_t* data, size_t size, int32_t* H, int32_t* W, int32_t* supported);
@@ -199,6 +200,13 @@ int melf_jpeg_decode_batch(melf_ctx* ctx, const uint8_t* const* data, const size
  * straight into HBM, then the same path as melf_process_batch.  Records of files whose status is
  * non-zero are meaningless. */
 int melf_jpeg_process_batch(melf_ctx* ctx, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                            melf_result* out_host, int32_t* status);
+
+/* The same for n file names (the loop of get_meter_values, meterelf/_api.py:22-33): the library reads the files
+ * (on threads), takes the frame size of the first file its decoder accepts as the batch's size (returned in
+ * H_used / W_used) and processes every file of that size; the others come back with status 1 / 2 / 3 / 4 for the
+ * caller to route (another call for another size, host decode for another format). */
+int melf_jpeg_process_files(melf_ctx* ctx, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                             melf_result* out_host, int32_t* status);
 
 /* ---- measurement ---------------------------------------------------------

@@ -4,11 +4,11 @@
 
 Lazy, yields in input order, per-image ImageProcessingError becomes the `error`
 field (re-raised only when DEBUG is set).  Unlike the reference's one-at-a-time
-loop, files go to the GPU in chunks (METERELF_BATCH, default 256), so up to one
+loop, files go to the GPU in chunks (METERELF_BATCH, default 1024), so up to one
 chunk is read ahead of the consumer.
 
-cv2.imread of the reference (meterelf/_image.py:49): baseline JPEG files are decoded on the
-GPU (METERELF_DECODE=gpu, the default; bit-identical to libjpeg's defaults); any other file, and
+cv2.imread of the reference (meterelf/_image.py:49): baseline JPEG files are read (on threads, inside the
+library) and decoded on the GPU (METERELF_DECODE=gpu, the default; bit-identical to libjpeg's defaults); any other file, and
 everything when METERELF_DECODE=host, is decoded on the host by Pillow on a small thread pool
 (METERELF_DECODE_THREADS, default min(8, cpu count); Pillow releases the GIL).
 """
@@ -43,7 +43,7 @@ def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
 def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[MeterImageData]:
     params = _params.load(params_file)
     gpu_decode = os.getenv('METERELF_DECODE', 'gpu') != 'host'
-    batch = max(1, int(os.getenv('METERELF_BATCH', '256' if gpu_decode else '64')))
+    batch = max(1, int(os.getenv('METERELF_BATCH', '1024' if gpu_decode else '64')))
     if _debug.DEBUG:
         batch = 1  # DEBUG re-raises at the failing file, before any later file is touched
     reader: Optional[MeterReader] = None
@@ -56,13 +56,6 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         except ImageProcessingError as e:
             return e
 
-    def _read_bytes(filename: str) -> Optional[bytes]:
-        try:
-            with open(filename, 'rb') as fp:
-                return fp.read()
-        except OSError:
-            return None
-
     try:
         for chunk in _chunks(filenames, batch):
             if reader is None:
@@ -72,10 +65,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
             by_index: Dict[int, object] = {}
             on_host = list(range(len(chunk)))
             if gpu_decode:
-                blobs = [_read_bytes(f) for f in chunk]  # sequential: a thread pool costs more per small file than it overlaps
-                have = [i for (i, b) in enumerate(blobs) if b]
-                recs = reader.read_jpeg_files([blobs[i] for i in have]) if have else []
-                for (i, rec) in zip(have, recs):
+                for (i, rec) in enumerate(reader.read_jpeg_paths(chunk)):  # files are read inside the library
                     if rec is not None:
                         by_index[i] = rec
                 on_host = [i for i in range(len(chunk)) if i not in by_index]

@@ -94,6 +94,24 @@ class MeterReader:
                     out[i] = recs[k]
         return out
 
+    def read_jpeg_paths(self, paths: List[str]) -> List[Optional[np.void]]:
+        """File names -> records (melf_jpeg_process_files: the library reads the files itself).  None for a
+        file the GPU decoder does not take (unreadable, not a baseline JPEG, corrupt): the caller's host branch."""
+        out: List[Optional[np.void]] = [None] * len(paths)
+        todo = list(range(len(paths)))
+        while todo:
+            (recs, status, _hw) = self.ctx.jpeg_process_files([paths[i] for i in todo])
+            again = []
+            for (k, i) in enumerate(todo):
+                if status[k] == _hip.JPEG_OK:
+                    out[i] = recs[k]
+                elif status[k] == _hip.JPEG_SIZE_MISMATCH:
+                    again.append(i)
+            if len(again) == len(todo):
+                break  # cannot happen (the first accepted file defines the size); never loop forever
+            todo = again
+        return out
+
     def read_many(self, images: List[np.ndarray], cropped: Optional[List[bool]] = None) -> List[np.void]:
         """Heterogeneous list of frames: grouped by shape, one batched call per group."""
         cropped = cropped or [False] * len(images)

@@ -20,7 +20,7 @@ FRAME_NEEDLE_CONTOURS_NOT_FOUND = 2
 FRAME_ANGLE_UNDETERMINED = 3
 
 K_LPLANE, K_MATCH, K_DIALS, K_FUSED_MASK, K_HLS, K_JPEG_HUFF, K_JPEG_IDCT, K_JPEG_COLOR, K_COUNT = range(9)
-JPEG_OK, JPEG_UNSUPPORTED, JPEG_CORRUPT, JPEG_SIZE_MISMATCH = 0, 1, 2, 3
+JPEG_OK, JPEG_UNSUPPORTED, JPEG_CORRUPT, JPEG_SIZE_MISMATCH, JPEG_UNREADABLE = 0, 1, 2, 3, 4
 
 
 class MelfDial(C.Structure):
@@ -65,6 +65,7 @@ EXPORTS = [
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
+    'melf_jpeg_process_files',
 ]
 
 _lib = None
@@ -112,6 +113,7 @@ def lib():
     L.melf_jpeg_probe_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.melf_jpeg_decode_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
     L.melf_jpeg_process_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.melf_jpeg_process_files.argtypes = [vp, vp, C.c_int, i32p, i32p, vp, vp]
     if L.melf_abi_version() != ABI_VERSION:
         raise HipError('libmeterelf_hip.so ABI version mismatch')
     _lib = L
@@ -345,6 +347,19 @@ class Context:
             (ptrs, sizes, keep) = _file_table(files)
             check(self._L.melf_jpeg_process_batch(self._h, ptrs, sizes, n, H, W, _ptr(out), _ptr(status)))
         return out, status
+
+    def jpeg_process_files(self, paths):
+        """File names -> (records, status, (H, W) of the batch): files are read, decoded and read out inside the
+        library; status 3 = another frame size (call again with those), 1 / 2 / 4 = not for the GPU decoder."""
+        n = len(paths)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        status = np.zeros(n, np.int32)
+        (H, W) = (C.c_int32(0), C.c_int32(0))
+        if n:
+            enc = [os.fsencode(p) for p in paths]
+            arr = (C.c_char_p * n)(*enc)
+            check(self._L.melf_jpeg_process_files(self._h, arr, n, C.byref(H), C.byref(W), _ptr(out), _ptr(status)))
+        return out, status, (H.value, W.value)
 
     def set_profiling(self, on):
         check(self._L.melf_ctx_set_profiling(self._h, int(on)))  # False/0 off, True/1 every kernel, 2 only k_match

@@ -5,8 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "melf_device.h"
@@ -919,4 +921,62 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     const int rect[4] = {c->P.rect_x0, c->P.rect_y0, c->P.rect_x1, c->P.rect_y1};
     if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, c->d_stage_in, status, rect)) return rc;
     return melf_process_batch_dev(c, c->d_stage_in, n, H, W, (size_t)H * W * 3, nullptr, out_host, c->stream);
+}
+
+// get_meter_values' inner loop for file names (meterelf/_api.py:22-33): the files are read here, on threads,
+// so that a scripting host pays one call per chunk instead of an open/read per file.
+extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
+                                       melf_result* out_host, int32_t* status)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (n == 0) return MELF_SUCCESS;
+    if (!paths || !out_host || !status || !H_used || !W_used || n < 0 || n > 32768) return fail(MELF_ERR_INVALID, "bad argument");
+    std::vector<std::vector<uint8_t>> blobs(n);
+    std::vector<int> hs(n, 0), ws(n, 0), oks(n, 0);
+    {
+        const int nthreads = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, n / 8 + 1}));
+        auto work = [&](int t) {
+            for (int i = t; i < n; i += nthreads) {
+                FILE* fp = paths[i] ? fopen(paths[i], "rb") : nullptr;
+                if (!fp) { status[i] = MELF_JPEG_UNREADABLE; continue; }
+                fseek(fp, 0, SEEK_END);
+                const long sz = ftell(fp);
+                fseek(fp, 0, SEEK_SET);
+                if (sz <= 0 || sz > (1L << 30)) { fclose(fp); status[i] = MELF_JPEG_UNREADABLE; continue; }
+                blobs[i].resize((size_t)sz);
+                const size_t got = fread(blobs[i].data(), 1, (size_t)sz, fp);
+                fclose(fp);
+                if (got != (size_t)sz) { blobs[i].clear(); status[i] = MELF_JPEG_UNREADABLE; continue; }
+                status[i] = MELF_JPEG_OK;
+                jpeg_probe(blobs[i].data(), blobs[i].size(), &hs[i], &ws[i], &oks[i], nullptr);
+            }
+        };
+        if (nthreads == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        }
+    }
+    // the batch shape: that of the first file the decoder takes
+    int H = 0, W = 0;
+    for (int i = 0; i < n && !H; ++i)
+        if (status[i] == MELF_JPEG_OK && oks[i]) { H = hs[i]; W = ws[i]; }
+    *H_used = H; *W_used = W;
+    std::vector<const uint8_t*> ptr;
+    std::vector<size_t> len;
+    std::vector<int> where;
+    for (int i = 0; i < n; ++i) {
+        if (status[i] != MELF_JPEG_OK) continue;
+        if (!oks[i]) { status[i] = hs[i] > 0 ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_CORRUPT; continue; }
+        if (hs[i] != H || ws[i] != W) { status[i] = MELF_JPEG_SIZE_MISMATCH; continue; }
+        ptr.push_back(blobs[i].data()); len.push_back(blobs[i].size()); where.push_back(i);
+    }
+    if (ptr.empty()) return MELF_SUCCESS;
+    const int m = (int)ptr.size();
+    std::vector<melf_result> res(m);
+    std::vector<int32_t> st(m);
+    if (int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data())) return rc;
+    for (int k = 0; k < m; ++k) { out_host[where[k]] = res[k]; status[where[k]] = st[k]; }
+    return MELF_SUCCESS;
 }

@@ -40,6 +40,9 @@ class OracleReader:
         """No GPU decoder here: every file goes back to the caller's host-decode branch."""
         return [None] * len(files)
 
+    def read_jpeg_paths(self, paths):
+        return [None] * len(paths)
+
     def read_many(self, images, cropped=None):
         return [self.read_frames(img[None])[0] for img in images]
 

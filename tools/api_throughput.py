@@ -14,7 +14,7 @@ from meterelf_amd import MeterReader, _hip, _params, get_meter_values
 
 d = os.path.join(ROOT, 'tests', 'golden', 'sample-images2')
 pfile = os.path.join(d, 'params.yml')
-files = sorted(glob.glob(os.path.join(d, '*.jpg'))) * 8
+files = sorted(glob.glob(os.path.join(d, '*.jpg'))) * 32
 
 
 def run(label):
@@ -41,7 +41,7 @@ for batch in (64, 256, 1024):
 reader = MeterReader(_params.load(pfile))
 blobs = [open(f, 'rb').read() for f in files]
 (H, W, ok, _) = _hip.jpeg_probe(blobs[0])
-for n in (256, 1024, len(blobs)):
+for n in (256, 1024, 4096):
     reader.ctx.jpeg_process_batch(blobs[:n], H, W)
     reader.ctx.set_profiling(True)
     reader.ctx.timings()
