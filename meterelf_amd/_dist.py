@@ -142,25 +142,21 @@ class ShardedMeterReader:
         n = len(filenames)
         out = np.zeros(n, _hip.RESULT_DTYPE)
         todo = list(range(n))
-        if self._ctx is not None:
-            blobs = []
-            for f in filenames:
-                try:
-                    with open(f, 'rb') as fp:
-                        blobs.append(fp.read())
-                except OSError:
-                    blobs.append(b'')
-            groups = {}
-            (hs, ws, oks) = _hip.jpeg_probe_batch(blobs)
-            for i in np.flatnonzero(oks):
-                groups.setdefault((int(hs[i]), int(ws[i])), []).append(int(i))
+        if self._ctx is not None:  # files are read and decoded inside the library (melf_jpeg_process_files)
             done = set()
-            for ((h, w), idxs) in groups.items():
-                (recs, status) = self._ctx.jpeg_process_batch([blobs[i] for i in idxs], h, w)
-                for (k, i) in enumerate(idxs):
+            pending = list(range(n))
+            while pending:
+                (recs, status, _hw) = self._ctx.jpeg_process_files([filenames[i] for i in pending])
+                again = []
+                for (k, i) in enumerate(pending):
                     if status[k] == _hip.JPEG_OK:
                         out[i] = recs[k]
                         done.add(i)
+                    elif status[k] == _hip.JPEG_SIZE_MISMATCH:
+                        again.append(i)
+                if len(again) == len(pending):
+                    break
+                pending = again
             todo = [i for i in range(n) if i not in done]
         by_shape = {}
         for i in todo:
