@@ -236,7 +236,11 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // while its output rows are only R lower, so neighbouring blocks are PERIOD - R image rows apart.
     // start so that image row y0 + i is roughly the same for every block at any moment (rounded to the
     // rotation period)
+#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 32)
+    const int istart = 0;  // diagnostic: no rotation of the template-row order (one priming phase)
+#else
     const int istart = (((g.th_pad - y0 % g.th_pad) % g.th_pad) / PERIOD) * PERIOD;
+#endif
     i32x4 buf[NBUF][NKB];
     i32x4 a[NA][ND];
     for (int phase = 0; phase < 2; ++phase) {
@@ -269,19 +273,23 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 4)
                         if (i < 0)  // diagnostic: no image loads in the loop at all (wrong results)
 #endif
+#if !(defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 16))  // 16: loads compiled out, no branch clutter
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 2)
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)((i + NBUF - 1) & 3) * ROWV + kb * 64];  // diagnostic: four image rows only
 #else
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
 #endif
+#endif
                     // template fragments of step i + PD (the table carries PD extra all-zero rows)
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 4)
                     if (i < 0)  // diagnostic: no template loads in the loop either
 #endif
+#if !(defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 16))
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 1)
                     a[(s + PD) % NA][d] = Ap[((size_t)((i + PD) & 1) * ND + d) * 64];  // diagnostic: template rows 0/1 only (wrong results)
 #else
                     a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
+#endif
 #endif
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
