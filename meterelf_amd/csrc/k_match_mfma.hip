@@ -280,30 +280,39 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
 #endif
 #endif
-                    // template fragments of step i + PD (the table carries PD extra all-zero rows)
+                    // The image fragment is requested before the sub-block's first MFMAs, the template fragment of
+                    // step i + PD (the table carries PD extra all-zero rows) in the middle of them: each load then
+                    // issues in the shadow of a running MFMA instead of two loads, their address arithmetic and the
+                    // waits piling up between two sub-blocks.
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        if (half == 1) {
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 4)
-                    if (i < 0)  // diagnostic: no template loads in the loop either
+                            if (i < 0)  // diagnostic: no template loads in the loop either
 #endif
 #if !(defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 16))
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 1)
-                    a[(s + PD) % NA][d] = Ap[((size_t)((i + PD) & 1) * ND + d) * 64];  // diagnostic: template rows 0/1 only (wrong results)
+                            a[(s + PD) % NA][d] = Ap[((size_t)((i + PD) & 1) * ND + d) * 64];  // diagnostic: template rows 0/1 only (wrong results)
 #else
-                    a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
+                            a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
 #endif
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
+                        for (int r = half ? R / 2 : 0; r < (half ? R : R / 2); ++r)
 #pragma unroll
-                        for (int xb = 0; xb < NXB; ++xb)
-                            if (on(r, xb))
+                            for (int xb = 0; xb < NXB; ++xb)
+                                if (on(r, xb))
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 8)
-                                acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], buf[0][0], acc[r][xb], 0, 0, 0);  // diagnostic: one A / B register set
+                                    acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], buf[0][0], acc[r][xb], 0, 0, 0);  // diagnostic: one A / B register set
 #else
-                                acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
-                                                                                   acc[r][xb], 0, 0, 0);
+                                    acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
+                                                                                       acc[r][xb], 0, 0, 0);
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
