@@ -405,6 +405,12 @@ __device__ __forceinline__ void unpack_dsum(int64_t d, int& a, int& b, int& c)
 }
 
 #ifdef MELF_JPEG_ROUNDS
+__device__ uint64_t g_jpeg_stamps[8 * 8192];  // per image: start, tables built, round 0 done, rounds done, scan done, end
+extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_stamps(uint64_t* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jpeg_stamps), sizeof(uint64_t) * 8 * (size_t)(n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1;
+}
+#define JSTAMP(k) do { if (tid == 0 && img < 8192) g_jpeg_stamps[8 * img + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ uint32_t g_jpeg_rounds[8192];
 extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_rounds(uint32_t* out, int n)
 {
@@ -435,6 +441,10 @@ __device__ __forceinline__ McuWindow jpeg_zero_window(const JpegImageDev* R, con
     return m;
 }
 
+#ifndef MELF_JPEG_ROUNDS
+#define JSTAMP(k) do { } while (0)
+#endif
+
 template <int T>
 __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const HuffSlow* __restrict__ g_slow,
                                                  const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
@@ -443,15 +453,18 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
     __shared__ uint16_t look[4 << LOOK_BITS];
     __shared__ uint32_t slow[4 * SLOW_DW];
     __shared__ uint8_t nat[64];
-    __shared__ uint32_t e_p[T];
-    __shared__ uint32_t e_s[T];
-    __shared__ int sc_n[T];
-    __shared__ int64_t sc_d[T];
+    __shared__ uint32_t e_p[T], e_s[T];  // exit state of each segment: bit position, blk << 8 | k
+    __shared__ uint32_t n_p[T], n_s[T];  // entry state its last decode started from
+    __shared__ int sc_n[T];              // blocks completed in the segment (then: prefix sums)
+    __shared__ int64_t sc_d[T];          // packed DC-difference sums (then: prefix sums)
+    __shared__ uint16_t todo[T];         // segments to decode again this round, compacted
+    __shared__ int wcount[T / 64];
     const int tid = threadIdx.x;
     const int img = blockIdx.x;
     const JpegImageDev* R = imgs + img;
     if (R->ok != 1) return;
     const uint32_t* W = (const uint32_t*)(scan + R->scan_off);  // zero-padded by 128 bytes; read through L1/L2
+    JSTAMP(0);
     const McuWindow mwin = jpeg_zero_window<T>(R, win, coefs, tid);  // visible to the output pass: barriers in between
     const uint32_t scan_len = R->scan_len;
     const uint32_t bits = scan_len * 8u;
@@ -497,36 +510,77 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
     int16_t* c2 = coefs + (size_t)R->coef_blk[2] * 64;
     __syncthreads();
 
+    JSTAMP(1);
+    // Per-segment state lives in LDS (entry used by the segment's last decode, exit state, blocks completed, DC
+    // sums): in the synchronisation rounds the few segments whose entry changed are COMPACTED onto the first lanes,
+    // so that a round occupies one or two waves instead of a lane here and there in all of them (a wave64
+    // instruction costs the same issue slot however few lanes are active, and five workgroups share the SIMDs).
     const bool mine = tid < nseg;
-    const uint32_t p_end = min((uint32_t)(tid + 1) * S, bits + 32u);
-    SegState entry = {(uint32_t)tid * S, 0, 0}, ex = entry;
-    int nblk = 0, bad = 0;
-    int64_t dsum = 0;
-    if (mine) {
-        jpeg_decode_segment<false>(W, look, slow, nat, L, ex, p_end, nblk, dsum, 0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+    int bad = 0;
+    {
+        SegState ex = {(uint32_t)tid * S, 0, 0};
+        int nblk = 0;
+        int64_t dsum = 0;
+        if (mine)
+            jpeg_decode_segment<false>(W, look, slow, nat, L, ex, min((uint32_t)(tid + 1) * S, bits + 32u), nblk, dsum, 0, 0, 0, 0, 0, hs0,
+                                       vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+        n_p[tid] = (uint32_t)tid * S;  // entry of the last decode
+        n_s[tid] = 0;
+        e_p[tid] = ex.p;
+        e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
+        sc_n[tid] = mine ? nblk : 0;
+        sc_d[tid] = mine ? dsum : 0;
     }
-    e_p[tid] = ex.p;
-    e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
+    __syncthreads();
+    JSTAMP(2);
     int rounds = 0, redone = 0;
     for (;;) {
+        // which segments see a new entry state?
+        uint32_t np = 0, ns = 0;
+        if (tid > 0) { np = e_p[tid - 1]; ns = e_s[tid - 1]; }
+        const bool ch = mine && (np != n_p[tid] || ns != n_s[tid]);
+        // compact them: position = number of changed segments before this one
+        const uint64_t bal = __ballot(ch);
+        const int wave = tid >> 6, lane = tid & 63;
+        if (lane == 0) wcount[wave] = __popcll(bal);
         __syncthreads();
-        SegState ne = {0, 0, 0};
-        if (tid > 0) { ne.p = e_p[tid - 1]; ne.blk = (int)(e_s[tid - 1] >> 8); ne.k = (int)(e_s[tid - 1] & 255u); }
-        const bool ch = mine && (ne.p != entry.p || ne.blk != entry.blk || ne.k != entry.k);
-        if (!__syncthreads_or(ch)) break;
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) {
+            const int c = wcount[w];
+            before += w < wave ? c : 0;
+            total += c;
+        }
+        if (total == 0) break;
         ++rounds;
         if (ch) {
-            ++redone;
-            entry = ne;
-            ex = ne;
-            jpeg_decode_segment<false>(W, look, slow, nat, L, ex, p_end, nblk, dsum, 0, 0, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
-            e_p[tid] = ex.p;
-            e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
+            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+            todo[pos] = (uint16_t)tid;
+            n_p[tid] = np;  // the entry this segment is about to be decoded from
+            n_s[tid] = ns;
         }
+        __syncthreads();
+        for (int q = tid; q < total; q += T) {
+            const int i = todo[q];
+            ++redone;
+            SegState ex = {n_p[i], (int)(n_s[i] >> 8), (int)(n_s[i] & 255u)};
+            int nblk;
+            int64_t dsum;
+            jpeg_decode_segment<false>(W, look, slow, nat, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, dsum, 0, 0, 0, 0, 0, hs0, vs0,
+                                       mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+            e_p[i] = ex.p;  // nobody reads exit states before the next barrier
+            e_s[i] = (uint32_t)(ex.blk << 8 | ex.k);
+            sc_n[i] = nblk;
+            sc_d[i] = dsum;
+        }
+        __syncthreads();
     }
+    JSTAMP(3);
     // exclusive prefix over the segments: blocks completed, packed DC differences per component
-    sc_n[tid] = mine ? nblk : 0;
-    sc_d[tid] = mine ? dsum : 0;
+    const int nblk = sc_n[tid];
+    const int64_t dsum = sc_d[tid];
+    const SegState entry = {n_p[tid], (int)(n_s[tid] >> 8), (int)(n_s[tid] & 255u)};
+    const uint32_t p_end = min((uint32_t)(tid + 1) * S, bits + 32u);
     __syncthreads();
     for (int off = 1; off < T; off <<= 1) {
         const int a = tid >= off ? sc_n[tid - off] : 0;
@@ -536,6 +590,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
         sc_d[tid] += b;
         __syncthreads();
     }
+    JSTAMP(4);
     const int done_blocks = sc_n[T - 1];
     const int nb_in = sc_n[tid] - (mine ? nblk : 0);
     int p0, p1, p2;
@@ -549,6 +604,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
                                   bxs1, c0, c1, c2, bad, mwin);
     }
     const int anybad = __syncthreads_or(bad);
+    JSTAMP(5);
 #ifdef MELF_JPEG_ROUNDS  // diagnostic build: rounds and re-decoded segments per image (tools/jpeg_rounds.py)
     {
         __shared__ int s_redone;

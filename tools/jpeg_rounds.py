@@ -19,6 +19,7 @@ reader = MeterReader(_params.load(os.path.join(d, 'params.yml')))
 blobs = [open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(d, '*.jpg')))]
 (H, W, ok, _) = _hip.jpeg_probe(blobs[-1])
 blobs = [b for b in blobs if _hip.jpeg_probe(b)[:2] == (H, W)]
+blobs = (blobs * 16)[:1024]  # a full batch, so that the phase times include the contention of a real launch
 n = len(blobs)
 out = np.zeros((n, H, W, 3), np.uint8)
 status = np.zeros(n, np.int32)
@@ -33,3 +34,14 @@ redo = (st & 0xffff).astype(int)
 print('%s: %d files | rounds after the first pass: min %d median %d max %d | segments decoded again (%% of segments, summed over rounds): median %d max %d'
       % (sd, n, rounds.min(), int(np.median(rounds)), rounds.max(), int(np.median(redo)), redo.max()))
 print('  histogram of rounds:', dict(zip(*np.unique(rounds, return_counts=True))))
+
+n2 = min(n, 8192)
+stamps = np.zeros((n2, 8), np.uint64)
+assert L.melf_debug_jpeg_stamps(stamps.ctypes.data_as(C.c_void_p), n2) == 0
+t = stamps[:, :6].astype(np.float64)
+names = ['zero window + tables', 'round 0 (speculative decode)', 'synchronisation rounds', 'prefix scan', 'output pass']
+tot = t[:, 5] - t[:, 0]
+print('cycles per workgroup: median %.0f max %.0f' % (np.median(tot), tot.max()))
+for k in range(5):
+    dlt = t[:, k + 1] - t[:, k]
+    print('  %-30s median %8.0f (%4.1f %%)  max %8.0f' % (names[k], np.median(dlt), 100 * np.median(dlt) / np.median(tot), dlt.max()))
