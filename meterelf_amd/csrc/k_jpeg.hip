@@ -819,9 +819,12 @@ __global__ __launch_bounds__(256) void k_jpeg_color420(const JpegImageDev* __res
     const int img = blockIdx.z, y = win.y0 + blockIdx.y;
     const int g = win.x0 / 8 + blockIdx.x * 256 + threadIdx.x;  // group of 8 pixels
     if (g * 8 >= win.x1) return;
-    const JpegImageDev* R = imgs + img;
-    if (!(R->ok && R->ncomp == 3 && R->hs0 == 2 && R->vs0 == 2)) return;  // the generic kernel's image
-    if (status[img] != 0) {  // failed in the entropy decoder: zero frame
+    // the record and the status in one round trip (field by field, each && waited for its own load)
+    const JpegImageDev rec = imgs[img];
+    const int32_t st = status[img];
+    const JpegImageDev* R = &rec;
+    if (!(rec.ok && rec.ncomp == 3 && rec.hs0 == 2 && rec.vs0 == 2)) return;  // the generic kernel's image
+    if (st != 0) {  // failed in the entropy decoder: zero frame
         uint2* z = (uint2*)(frames + ((size_t)img * H + y) * W * 3 + (size_t)g * 24);
         z[0] = z[1] = z[2] = make_uint2(0u, 0u);
         return;
