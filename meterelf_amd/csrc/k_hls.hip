@@ -330,7 +330,7 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
             const uint32_t mn = min(Q, S);
             // lsI row P: address bytes {lane*4, P, base, 0}
             const uint32_t lso = __builtin_amdgcn_perm(d[iP >> 2], ls_lane, 0x0c020000u | ((4u + (iP & 3)) << 8));
-            const uint32_t lse = *(lds_u32)lso;
+            const uint32_t lse = *(lds_u32)(uintptr_t)lso;
             // hI row (P - mn) & 255, written into byte 1 of the address register.  Negative differences
             // alias onto real rows, which is harmless: then mn > P and no lsI row P holds a minimum above P.
             switch (iP & 3) {
@@ -339,7 +339,7 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
                 case 2: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
                 default: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
             }
-            const uint32_t hie = *(lds_u32)haddr[k & 3];
+            const uint32_t hie = *(lds_u32)(uintptr_t)haddr[k & 3];
             // compares straight into lane masks (v_cmp -> SGPR pair), combined on the scalar unit
             const uint64_t m_ls = __builtin_amdgcn_uicmp((uint32_t)((int)mn - (int)(int16_t)(lse & 0xffffu)), lse >> 16, 36 /* ult */);
             const uint64_t m_h = __builtin_amdgcn_uicmp((uint32_t)((int)Q - ((int)S + (int)(int16_t)(hie & 0xffffu))), hie >> 16, 36);
