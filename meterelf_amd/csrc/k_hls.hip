@@ -644,7 +644,10 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
             case 1: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 3: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            default: launch_lut_t<V, 512, 0, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            default:
+                if constexpr (V == 4) launch_lut_t<V, 512, 0, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);  // the tie path needs > 80 VGPRs
+                else launch_lut_t<V, 512, 0, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
+                break;
         }
     }
 }
