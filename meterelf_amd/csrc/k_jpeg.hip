@@ -16,8 +16,11 @@
 //   J2     k_jpeg_idct      one thread per 8x8 block: dequantise + ISLOW IDCT -> u8 planes
 //   J3     k_jpeg_color420  8 pixels per thread: fancy upsample + YCC->BGR -> NHWC frame (k_jpeg_color: other modes)
 #include "melf_internal.h"
+#include "melf_threads.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -962,16 +965,12 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
 {
     if (!*pws) *pws = new JpegWorkspace();
     JpegWorkspace* w = *pws;
+    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     std::vector<JpegHeader> hdr(n);
     std::vector<size_t> scan_off(n + 1, 0);
-    const int nthreads = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, n / 16 + 1}));
-    auto par_for = [&](auto fn) {
-        if (nthreads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t)
-            th.emplace_back([&, t]() { for (int i = t; i < n; i += nthreads) fn(i); });
-        for (auto& x : th) x.join();
-    };
+    const int nthreads = host_pool().size() + 1;
+    auto par_for = [&](const std::function<void(int)>& fn) { host_pool().run(n, fn); };
     par_for([&](int i) {
         JpegHeader& h = hdr[i];
         if (!data[i] || parse_headers(data[i], sizes[i], h) != 0) { host_status[i] = 2; return; }
@@ -979,6 +978,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         if (h.H != H || h.W != W) { host_status[i] = 3; return; }
         host_status[i] = 0;
     });
+    const auto tp1 = std::chrono::steady_clock::now();
     // layout
     size_t coef_blocks = 0, plane_bytes = 0;
     int max_blocks = 0;
@@ -1038,6 +1038,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         }
         w->h_cap = want;
     }
+    const auto tp2 = std::chrono::steady_clock::now();
     uint8_t* base = w->h_stage;
     par_for([&](int i) {
         JpegImageDev& r = rec[i];
@@ -1074,6 +1075,12 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         if (rec[i].ok && rec[i].ncomp == 3 && rec[i].hs0 == 2 && rec[i].vs0 == 2) ++w->n_420;
     }
     memcpy(base + w->off_imgs, rec.data(), (size_t)n * sizeof(JpegImageDev));
+    if (trace) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[melf jpeg] prepare: parse %.2f ms, layout %.2f ms, tables + clean scans %.2f ms (%d threads)\n", ms(tp0, tp1), ms(tp1, tp2),
+                ms(tp2, tp3), nthreads);
+    }
     return MELF_SUCCESS;
 }
 

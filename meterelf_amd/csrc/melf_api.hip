@@ -13,6 +13,7 @@
 
 #include "melf_device.h"
 #include "melf_internal.h"
+#include "melf_threads.h"
 
 using namespace melf;
 
@@ -934,29 +935,20 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
     std::vector<std::vector<uint8_t>> blobs(n);
     std::vector<int> hs(n, 0), ws(n, 0), oks(n, 0);
     {
-        const int nthreads = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, n / 8 + 1}));
-        auto work = [&](int t) {
-            for (int i = t; i < n; i += nthreads) {
-                FILE* fp = paths[i] ? fopen(paths[i], "rb") : nullptr;
-                if (!fp) { status[i] = MELF_JPEG_UNREADABLE; continue; }
-                fseek(fp, 0, SEEK_END);
-                const long sz = ftell(fp);
-                fseek(fp, 0, SEEK_SET);
-                if (sz <= 0 || sz > (1L << 30)) { fclose(fp); status[i] = MELF_JPEG_UNREADABLE; continue; }
-                blobs[i].resize((size_t)sz);
-                const size_t got = fread(blobs[i].data(), 1, (size_t)sz, fp);
-                fclose(fp);
-                if (got != (size_t)sz) { blobs[i].clear(); status[i] = MELF_JPEG_UNREADABLE; continue; }
-                status[i] = MELF_JPEG_OK;
-                jpeg_probe(blobs[i].data(), blobs[i].size(), &hs[i], &ws[i], &oks[i], nullptr);
-            }
-        };
-        if (nthreads == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
-            for (auto& x : th) x.join();
-        }
+        host_pool().run(n, [&](int i) {
+            FILE* fp = paths[i] ? fopen(paths[i], "rb") : nullptr;
+            if (!fp) { status[i] = MELF_JPEG_UNREADABLE; return; }
+            fseek(fp, 0, SEEK_END);
+            const long sz = ftell(fp);
+            fseek(fp, 0, SEEK_SET);
+            if (sz <= 0 || sz > (1L << 30)) { fclose(fp); status[i] = MELF_JPEG_UNREADABLE; return; }
+            blobs[i].resize((size_t)sz);
+            const size_t got = fread(blobs[i].data(), 1, (size_t)sz, fp);
+            fclose(fp);
+            if (got != (size_t)sz) { blobs[i].clear(); status[i] = MELF_JPEG_UNREADABLE; return; }
+            status[i] = MELF_JPEG_OK;
+            jpeg_probe(blobs[i].data(), blobs[i].size(), &hs[i], &ws[i], &oks[i], nullptr);
+        });
     }
     // the batch shape: that of the first file the decoder takes
     int H = 0, W = 0;
