@@ -61,6 +61,9 @@ def main():
     ap.add_argument('--sample-dir', default='sample-images1')
     ap.add_argument('--cpu-sample', type=int, default=256, help='frames timed through the CPU oracle (0 = skip)')
     ap.add_argument('--no-fused-mask', action='store_true')
+    ap.add_argument('--overlap', action='store_true',
+                    help='the K steps as ONE melf_process_stream_dev call (steps overlap on two lanes: more frames/s, but the '
+                         'match kernel then shares the SIMDs and its own launch time -- the roofline figure -- stretches)')
     ap.add_argument('--no-jpeg', action='store_true', help='skip the JPEG-files-in block (SURVEY 8 f1)')
     args = ap.parse_args()
 
@@ -135,8 +138,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if not args.overlap:
+        for _ in range(args.steps):
+            step()
+    else:
+        # the K steps as one stream of K batches (melf_process_stream_dev): consecutive steps alternate between the
+        # context's two pipeline lanes, so one step's prep / dials kernels run in the tail of the other's match kernel
+        ctx.process_stream_dev(frames.data_ptr(), args.steps, 0, B, H, W, d_results.data_ptr(), 0, stream=stream)
     recs = d_results.cpu().numpy().view(_hip.RESULT_DTYPE)   # D2H of the last step's records: inside the timed region
     torch.cuda.synchronize()
     if dist is not None:

@@ -175,6 +175,13 @@ int melf_aligned_average(melf_ctx* ctx, const uint8_t* frames_host, int n, int H
 int melf_inrange(melf_ctx* ctx, const uint8_t* img_host, int rows, int cols, const int32_t lo[3],
                  const int32_t hi[3], uint8_t* mask_host);
 
+/* nbatches batches of n frames each, already in HBM (batch b at d_frames + b * batch_stride bytes, its records at
+ * d_results + b * results_stride records; a stride of 0 re-reads / overwrites the same batch), enqueued from
+ * `stream`: consecutive batches run on the context's two pipeline lanes, so that their kernels overlap; `stream`
+ * continues when all of them are done.  Results as melf_process_batch_dev. */
+int melf_process_stream_dev(melf_ctx* ctx, const void* d_frames, int nbatches, size_t batch_stride, int n, int H, int W,
+                            size_t frame_stride, void* d_results, size_t results_stride, void* stream);
+
 /* ---- JPEG decode (reference: cv2.imread in ImageFile.get_bgr_image, meterelf/_image.py:46-51) ----
  * Baseline sequential 8-bit Huffman JPEGs (one interleaved scan; YCbCr 4:2:0 / 4:2:2 / 4:4:4 or
  * greyscale; restart intervals allowed) are decoded on the GPU to the bytes libjpeg produces with its

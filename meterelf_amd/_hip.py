@@ -61,7 +61,7 @@ class HipError(RuntimeError):
 EXPORTS = [
     'melf_last_error', 'melf_abi_version', 'melf_device_count', 'melf_build_dial_masks',
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
-    'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev',
+    'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
@@ -98,6 +98,7 @@ def lib():
     L.melf_ctx_get_masks.argtypes = [vp, vp]
     L.melf_process_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp]
     L.melf_process_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]
+    L.melf_process_stream_dev.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, vp]
     L.melf_bgr2hls.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp]
     L.melf_hls_inrange_close.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.melf_hls_inrange_close_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -246,6 +247,13 @@ class Context:
         return out
 
     # --- stages ---
+    def process_stream_dev(self, d_frames_ptr, nbatches, batch_stride, n, H, W, d_results_ptr, results_stride, frame_stride=None,
+                           stream=None):
+        """nbatches batches of n device-resident frames in one call; consecutive batches overlap on two lanes."""
+        check(self._L.melf_process_stream_dev(self._h, C.c_void_p(d_frames_ptr), nbatches, batch_stride, n, H, W,
+                                              frame_stride or H * W * 3, C.c_void_p(d_results_ptr), results_stride,
+                                              C.c_void_p(stream) if stream else None))
+
     def bgr2hls(self, bgr):
         bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
         rows, cols, _ = bgr.shape

@@ -223,6 +223,7 @@ struct melf_ctx {
     // two pipeline lanes: a batch is split in halves that run on separate streams, so that one
     // half's VALU-bound kernels (prep, dials) overlap the other half's matrix-core-bound match
     static const int NLANES = 2;
+    int active_lane = 0;                 // melf_process_stream_dev: which lane's work buffers the next batch uses
     int lanes = 1;                       // MELF_LANES=2 enables the split (measured slower on MI355X: the two
                                          // half-batch match kernels do not overlap usefully; kept for experiments)
     hipStream_t lane_stream[NLANES] = {nullptr, nullptr};
@@ -565,6 +566,7 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
             const int m = l == nl - 1 ? f0 + mtot - g0 : per;
             if (m <= 0) continue;
             hipStream_t ls = split ? c->lane_stream[l] : st;
+            const int bl = split ? l : c->active_lane;  // whose work buffers
             const uint8_t* base = (const uint8_t*)d_frames + (size_t)g0 * frame_stride;
             MatchSrc ms;
             ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = W * 3;
@@ -574,18 +576,18 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
             if (mfma) {
                 const MfmaPlan pl = mfma_plan(P.th, P.tw, crows, ccols, m);
                 nparts = pl.nparts;
-                if (int rc = grow(&c->d_lg[l], &c->lg_cap[l], pl.lg_bytes)) return rc;
-                if (int rc = grow(&c->d_rsum[l], &c->rsum_cap[l], pl.r_bytes / sizeof(uint16_t))) return rc;
-                if (int rc = grow(&c->d_wsum[l], &c->wsum_cap[l], pl.ws_bytes / sizeof(uint32_t))) return rc;
-                if (int rc = grow(&c->d_lpart[l], &c->lpart_cap[l], (size_t)m * nparts)) return rc;
-                parts = c->d_lpart[l];
+                if (int rc = grow(&c->d_lg[bl], &c->lg_cap[bl], pl.lg_bytes)) return rc;
+                if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
+                if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
+                if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * nparts)) return rc;
+                parts = c->d_lpart[bl];
                 {
                     KernelTimer t(c, MELF_K_LPLANE, ls);
-                    launch_mfma_prep(ms, true, m, pl, P.th, P.tw, c->d_lg[l], c->d_rsum[l], c->d_wsum[l], ls);
+                    launch_mfma_prep(ms, true, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ls);
                 }
                 {
                     KernelTimer t(c, MELF_K_MATCH, ls);
-                    launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[l], c->d_wsum[l],
+                    launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl],
                                       nullptr, parts, ls);
                 }
             } else {
@@ -616,6 +618,43 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
         HIP_TRY(hipStreamSynchronize(st));
     }
     return MELF_SUCCESS;
+}
+
+// A stream of batches in one call (frames resident in HBM): consecutive batches alternate between the context's
+// two pipeline lanes (own work buffers and stream each), so that one batch's prep / dials kernels run in the
+// tail of the other batch's match kernel, whose last waves leave three quarters of the SIMDs idle.
+extern "C" int melf_process_stream_dev(melf_ctx* c, const void* d_frames, int nbatches, size_t batch_stride, int n, int H,
+                                       int W, size_t frame_stride, void* d_results, size_t results_stride, void* stream_)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (nbatches < 0 || n < 0) return fail(MELF_ERR_INVALID, "bad batch shape");
+    if (nbatches == 0 || n == 0) return MELF_SUCCESS;
+    if (!d_frames || !d_results) return fail(MELF_ERR_INVALID, "NULL device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+    if (nbatches == 1 || n > MAX_FRAMES_PER_LAUNCH)  // nothing to overlap / too large for one set of lane buffers
+    {
+        for (int b = 0; b < nbatches; ++b)
+            if (int rc = melf_process_batch_dev(c, (const uint8_t*)d_frames + (size_t)b * batch_stride, n, H, W, frame_stride,
+                                                (melf_result*)d_results + (size_t)b * results_stride, nullptr, st))
+                return rc;
+        return MELF_SUCCESS;
+    }
+    HIP_TRY(hipEventRecord(c->ev_fork, st));
+    for (int l = 0; l < melf_ctx::NLANES; ++l) HIP_TRY(hipStreamWaitEvent(c->lane_stream[l], c->ev_fork, 0));
+    const int saved = c->active_lane;
+    int rc = MELF_SUCCESS;
+    for (int b = 0; b < nbatches && rc == MELF_SUCCESS; ++b) {
+        c->active_lane = b % melf_ctx::NLANES;
+        rc = melf_process_batch_dev(c, (const uint8_t*)d_frames + (size_t)b * batch_stride, n, H, W, frame_stride,
+                                    (melf_result*)d_results + (size_t)b * results_stride, nullptr, c->lane_stream[c->active_lane]);
+    }
+    c->active_lane = saved;
+    for (int l = 0; l < melf_ctx::NLANES; ++l) {
+        HIP_TRY(hipEventRecord(c->ev_join[l], c->lane_stream[l]));
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_join[l], 0));
+    }
+    return rc;
 }
 
 extern "C" int melf_process_batch(melf_ctx* c, const uint8_t* frames_host, int n, int H, int W, size_t frame_stride,

@@ -647,3 +647,31 @@ def test_edge_cases(env):
     vals2 = get_meter_value(ImageFile(f, p))
     assert vals2 == vals
     _readers.pop(id(p)).close()
+
+
+def test_stream_of_batches_matches_single_calls(env):
+    """melf_process_stream_dev (batches alternating between the two pipeline lanes) gives the records of one
+    melf_process_batch call per batch."""
+    import ctypes as C
+    from meterelf_amd import _hip
+    e = env['sample-images1']
+    frames = synth_frames(_good(e['files']), 96, 31)
+    ctx = e['reader'].ctx
+    ref = ctx.process_batch(frames)
+    L = _hip.lib()
+    hip = C.CDLL('libamdhip64.so')
+    nbytes = frames.nbytes
+    (d_frames, d_res) = (C.c_void_p(), C.c_void_p())
+    assert hip.hipMalloc(C.byref(d_frames), C.c_size_t(nbytes)) == 0
+    assert hip.hipMalloc(C.byref(d_res), C.c_size_t(len(frames) * _hip.RESULT_DTYPE.itemsize)) == 0
+    try:
+        assert hip.hipMemcpy(d_frames, frames.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes), 1) == 0
+        (n, H, W) = (32, frames.shape[1], frames.shape[2])
+        ctx.process_stream_dev(d_frames.value, 3, n * H * W * 3, n, H, W, d_res.value, n)
+        assert hip.hipDeviceSynchronize() == 0
+        got = np.zeros(len(frames), _hip.RESULT_DTYPE)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d_res, C.c_size_t(got.nbytes), 2) == 0
+        assert got.tobytes() == ref.tobytes()
+    finally:
+        hip.hipFree(d_frames)
+        hip.hipFree(d_res)
