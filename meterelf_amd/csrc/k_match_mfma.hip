@@ -25,6 +25,8 @@
 #include <limits.h>
 
 #include "melf_device.h"
+#include <hip/hip_ext.h>
+
 #include "melf_internal.h"
 
 namespace melf {
@@ -517,7 +519,7 @@ void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan&
 
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
-                       hipStream_t stream)
+                       hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     MfmaGeom g;
     g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
@@ -526,10 +528,14 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
     g.k1 = (int)(128 * (tsum - 128L * th * tw));
     g.tmean = tmean;
     dim3 grid(p.nparts * p.groups), block(64);
+    // ev_start / ev_stop (optional): time stamps taken by the dispatch itself (hipExtLaunchKernelGGL) -- no
+    // hipEventRecord barrier packets in the queue around the kernel
     if (p.nxb == 2)
-        hipLaunchKernelGGL((k_match_mfma<MM_ND, 2, MM_R, MM_PD>), grid, block, 0, stream, d_lg, d_atab, d_ws, g, d_result_map, d_partials);
+        hipExtLaunchKernelGGL((k_match_mfma<MM_ND, 2, MM_R, MM_PD>), grid, block, 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
+                              d_result_map, d_partials);
     else
-        hipLaunchKernelGGL((k_match_mfma<MM_ND, 1, MM_R, MM_PD>), grid, block, 0, stream, d_lg, d_atab, d_ws, g, d_result_map, d_partials);
+        hipExtLaunchKernelGGL((k_match_mfma<MM_ND, 1, MM_R, MM_PD>), grid, block, 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
+                              d_result_map, d_partials);
 }
 
 }  // namespace melf

@@ -585,8 +585,15 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
                     KernelTimer t(c, MELF_K_LPLANE, ls);
                     launch_mfma_prep(ms, true, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ls);
                 }
-                {
-                    KernelTimer t(c, MELF_K_MATCH, ls);
+                if (c->profiling) {  // timed by the dispatch itself: no event-record packets around the kernel
+                    TimedEvent ev;
+                    ev.kernel = MELF_K_MATCH;
+                    HIP_TRY(hipEventCreate(&ev.start));
+                    HIP_TRY(hipEventCreate(&ev.stop));
+                    launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl],
+                                      nullptr, parts, ls, ev.start, ev.stop);
+                    c->events.push_back(ev);
+                } else {
                     launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl],
                                       nullptr, parts, ls);
                 }

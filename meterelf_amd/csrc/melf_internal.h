@@ -56,7 +56,7 @@ void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan&
                       uint16_t* d_r, uint32_t* d_ws, hipStream_t stream);
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
-                       hipStream_t stream);
+                       hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- K3: per-dial reading ---------------------------------------------------
 struct DialGeom {
