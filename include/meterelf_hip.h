@@ -15,8 +15,14 @@
  * by one host thread at a time.  The caller owns every buffer it passes in; the
  * context owns its device memory.  "_dev" entry points take device pointers
  * (e.g. torch tensors' data_ptr()) and enqueue on `stream` (a hipStream_t passed
- * as void*, NULL = the context's own stream) without synchronising it unless
- * stated.
+ * as void*; NULL = the null / legacy default stream, exactly as in a HIP launch,
+ * which is also what torch's default stream handle 0 means) without synchronising
+ * it unless stated: work the caller enqueued on `stream` before the call is seen
+ * by the kernels, and whatever the caller enqueues on it afterwards sees the
+ * records.  The work buffers belong to the context: if consecutive *_dev calls
+ * arrive on different streams, the library orders the later stream after the
+ * earlier call by an event, so a context can be moved between streams but never
+ * runs two batches' kernels against the same buffers at once.
  */
 #ifndef METERELF_HIP_H
 #define METERELF_HIP_H

@@ -8,7 +8,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from . import _hip
+from . import _debug, _hip
 from ._params import Params
 from ._types import Rect
 from .exceptions import (
@@ -45,8 +45,15 @@ def result_to_python(rec, dial_names: List[str], filename: str = '') -> Tuple[Di
     if status == _hip.FRAME_NEEDLE_CONTOURS_NOT_FOUND:
         return {}, NeedleContoursNotFoundError(extra_info={'dial': dial_names[int(rec['failed_dial'])]})
     if status == _hip.FRAME_ANGLE_UNDETERMINED:
-        bad = [name for (i, name) in enumerate(dial_names) if int(rec['unreadable_mask']) >> i & 1]
-        return {}, DialAngleDeterminingError(filename, extra_info={'unreadable dials': ', '.join(bad)})
+        mask = int(rec['unreadable_mask'])
+        bad = [name for (i, name) in enumerate(dial_names) if mask >> i & 1]
+        extra_info = {}
+        if _debug.DEBUG:
+            # meterelf/_reading.py:98-104: the dials that WERE read, sorted by name, before 'unreadable dials'
+            read = sorted((name, float(rec['pos'][i])) for (i, name) in enumerate(dial_names) if not mask >> i & 1)
+            extra_info['dial positions'] = ' (' + ' | '.join('{}: {:.2f}'.format(k, v) for (k, v) in read) + ')'
+        extra_info['unreadable dials'] = ', '.join(bad)
+        return {}, DialAngleDeterminingError(filename, extra_info=extra_info)
     raise RuntimeError('unknown frame status {}'.format(status))
 
 

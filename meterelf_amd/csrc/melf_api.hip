@@ -250,10 +250,29 @@ struct melf_ctx {
     // profiling
     bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
     int profiling = 0;                // 0 off, 1 every kernel, 2 only the dominant kernel (k_match)
+    // the work buffers belong to the context, not to a stream: when a *_dev call arrives on another stream than the
+    // previous one, the new stream first waits for everything the previous call enqueued (enter_stream)
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t ev_order = nullptr;
     std::vector<TimedEvent> events;
     double acc_ms[MELF_K_COUNT] = {0};
     int64_t acc_n[MELF_K_COUNT] = {0};
 };
+
+// Orders the caller's stream after the context's previous *_dev call when that one ran on a different stream (the
+// calls share the context's work buffers).  Costs nothing while the caller stays on one stream.
+static int enter_stream(melf_ctx* c, hipStream_t st)
+{
+    if (c->last_stream_valid && c->last_stream != st) {
+        if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_order, c->last_stream));
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_order, 0));
+    }
+    c->last_stream = st;
+    c->last_stream_valid = true;
+    return MELF_SUCCESS;
+}
 
 template <class T>
 static int grow(T** ptr, size_t* cap, size_t need)
@@ -465,6 +484,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
         if (c->ev_join[l]) hipEventDestroy(c->ev_join[l]);
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_order) hipEventDestroy(c->ev_order);
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
     jpeg_workspace_free(c->jpeg);
@@ -490,7 +510,7 @@ extern "C" int melf_ctx_fused_table_ties(const melf_ctx* c, int* count)
 {
     if (!c || !count) return fail(MELF_ERR_INVALID, "NULL argument");
     *count = c->fused_ambiguous;
-    return c->fused_variant * 16 + c->fused_active_sectors >= 0 ? MELF_SUCCESS : MELF_SUCCESS;
+    return MELF_SUCCESS;
 }
 
 extern "C" int melf_ctx_set_profiling(melf_ctx* c, int on)
@@ -526,6 +546,9 @@ extern "C" int melf_ctx_timings(melf_ctx* c, double ms[MELF_K_COUNT], int64_t la
 // ------------------------------------------------------------ full path ----
 static const int MAX_FRAMES_PER_LAUNCH = 32768;
 
+static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
+                            void* d_results, melf_result* out_host, hipStream_t st);
+
 extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
                                       void* d_results, melf_result* out_host, void* stream_)
 {
@@ -535,7 +558,14 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
     if (!d_frames) return fail(MELF_ERR_INVALID, "d_frames is NULL");
     if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+    hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
+    if (int rc = enter_stream(c, st)) return rc;
+    return process_batch_on(c, d_frames, n, H, W, frame_stride, d_results, out_host, st);
+}
+
+static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
+                            void* d_results, melf_result* out_host, hipStream_t st)
+{
     const melf_params& P = c->P;
     // numpy slicing img[y0:y1, x0:x1] clamps to the image (meterelf/_image.py:54-55)
     const int x0 = P.rect_x0 < W ? P.rect_x0 : W, x1 = P.rect_x1 < W ? P.rect_x1 : W;
@@ -638,12 +668,14 @@ extern "C" int melf_process_stream_dev(melf_ctx* c, const void* d_frames, int nb
     if (nbatches == 0 || n == 0) return MELF_SUCCESS;
     if (!d_frames || !d_results) return fail(MELF_ERR_INVALID, "NULL device pointer");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+    if (H <= 0 || W <= 0 || frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "bad frame shape / stride");
+    hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
+    if (int rc = enter_stream(c, st)) return rc;
     if (nbatches == 1 || n > MAX_FRAMES_PER_LAUNCH)  // nothing to overlap / too large for one set of lane buffers
     {
         for (int b = 0; b < nbatches; ++b)
-            if (int rc = melf_process_batch_dev(c, (const uint8_t*)d_frames + (size_t)b * batch_stride, n, H, W, frame_stride,
-                                                (melf_result*)d_results + (size_t)b * results_stride, nullptr, st))
+            if (int rc = process_batch_on(c, (const uint8_t*)d_frames + (size_t)b * batch_stride, n, H, W, frame_stride,
+                                          (melf_result*)d_results + (size_t)b * results_stride, nullptr, st))
                 return rc;
         return MELF_SUCCESS;
     }
@@ -653,8 +685,8 @@ extern "C" int melf_process_stream_dev(melf_ctx* c, const void* d_frames, int nb
     int rc = MELF_SUCCESS;
     for (int b = 0; b < nbatches && rc == MELF_SUCCESS; ++b) {
         c->active_lane = b % melf_ctx::NLANES;
-        rc = melf_process_batch_dev(c, (const uint8_t*)d_frames + (size_t)b * batch_stride, n, H, W, frame_stride,
-                                    (melf_result*)d_results + (size_t)b * results_stride, nullptr, c->lane_stream[c->active_lane]);
+        rc = process_batch_on(c, (const uint8_t*)d_frames + (size_t)b * batch_stride, n, H, W, frame_stride,
+                              (melf_result*)d_results + (size_t)b * results_stride, nullptr, c->lane_stream[c->active_lane]);
     }
     c->active_lane = saved;
     for (int l = 0; l < melf_ctx::NLANES; ++l) {
@@ -705,7 +737,7 @@ extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int
     if (n == 0) return MELF_SUCCESS;
     if (!d_frames || !d_masks) return fail(MELF_ERR_INVALID, "NULL device pointer");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+    hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
         const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
         KernelTimer t(c, MELF_K_FUSED_MASK, st);

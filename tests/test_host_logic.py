@@ -160,6 +160,22 @@ def test_result_to_python_all_statuses():
         'Cannot determine angle of a dial (unreadable dials = 0.001, 0.1)'
 
 
+def test_result_to_python_debug_dial_positions(monkeypatch):
+    """DEBUG only: 'dial positions' (the dials that were read, sorted by name, '{:.2f}') comes before
+    'unreadable dials' (reference: meterelf/_reading.py:98-106)."""
+    from meterelf_amd import _debug
+    monkeypatch.setattr(_debug, 'DEBUG', {'masks'})
+    names = ['0.0001', '0.001', '0.01', '0.1']
+    r = np.zeros(1, _hip.RESULT_DTYPE)[0]
+    r['pos'][:4] = [6.2306, 3.3, 5.105, 2.4]
+    r['status'] = _hip.FRAME_ANGLE_UNDETERMINED
+    r['unreadable_mask'] = 0b1010
+    err = _engine.result_to_python(r, names, 'f')[1]
+    assert list(err.extra_info) == ['dial positions', 'unreadable dials']
+    assert err.get_message() == ('Cannot determine angle of a dial (dial positions =  (0.0001: 6.23 | 0.01: 5.11), '
+                                 'unreadable dials = 0.001, 0.1)')
+
+
 def test_no_gpu_means_loud_failure():
     if _hip.device_count() > 0:
         pytest.skip('a GPU is visible')
