@@ -2,27 +2,39 @@
 """bench.py -- frames/sec of the meterelf hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the whole per-frame path (template match -> dial reading
--> digits, BASELINE config "Batch=1024, full pipeline, 4 dials") over one batch
-of synthetic 640x480 frames that are already resident in HBM.  Each rank owns
-one GPU and its own batch (weak scaling); the only collective is the RCCL
-broadcast of the calibration blob at set-up.  Rank 0 prints ONE JSON line.
+With --gpus N > 1 and no torchrun environment the script launches its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process; the parent never touches
+the GPU) -- or run it under torch.distributed.run yourself.  One rank per GPU, rank 0 prints ONE JSON line.
 
-Extra objects on the line:
-  roofline       dominant kernel of the step (k_match), hipEvent-timed inside
-                 the library on the stream it runs on
-  fused_mask     BASELINE config 2 (B=256, fused HLS+inRange+closing kernel) with
-                 its own HBM roofline
-  cpu_baseline   the CPU oracle (restated port, 1 thread) on a bounded sample of
-                 the same frames; the same sample doubles as an in-run parity gate
+A step = one pass of the whole per-frame path (template match -> dial reading -> digits, BASELINE config 3
+"Batch=1024, full pipeline, 4 dials") over one batch of synthetic 640x480 frames already resident in HBM.
+Consecutive steps rotate over --nbuf (default 4) DISTINCT batches (3.8 GB of frames), so the input of a step is
+never what the previous step left in the 256 MB Infinity Cache.  Each rank owns one GPU and its own batches (weak
+scaling); the only collectives are set-up ones (RCCL broadcast of the calibration blob) and the timing barrier.
+
+Objects on the line besides the contract's fields:
+  roofline       dominant kernel of the step (k_match), timed by the dispatch's own start/stop stamps
+                 (hipExtLaunchKernelGGL) on the stream it runs on, over the timed region
+  sustained      >= 2 s of back-to-back steps (DVFS-settled rate) with the same roofline figure
+  cpu_baseline   the CPU oracle (restated port) on a bounded sample of the same frames; doubles as parity gate
+  fused_mask     BASELINE config 2 (B=256, fused HLS+inRange+closing) rotating over 4 buffer pairs, HBM roofline
+  config4        BASELINE config 4 per GPU: sample-images2 params, 1024 frames/GPU, blob via RCCL broadcast
+  config5        BASELINE config 5 per GPU: 1080p, 6 dials, 512 frames/GPU: fused mask (HBM roofline) + full path
+  host_fed       the host-pointer entry point (frames in host memory, PCIe inclusive) -- never `value`
+  jpeg_decode    the same path fed with JPEG files (decode on the GPU)
+  rccl_ranks     all_reduce(1) over the nccl (= RCCL) backend: number of ranks that took part
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,11 +46,29 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 REJECTED = ('20180814021309-01-e01.jpg', '20180814021310-00-e02.jpg')
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 I8_MFMA_PEAK_TOPS = 5000.0     # dense i8 MFMA = 2x the ~2.5 PF bf16 rate (same guide, Matrix cores)
+ALL_BLOCKS = ('sustained', 'fused', 'config4', 'config5', 'cpu', 'hostfed', 'jpeg')
 
 
+# ------------------------------------------------------------------ launcher ----
+def launch_ranks(args):
+    """--gpus N without a torchrun environment: start the N ranks as a child process tree.  Nothing in this
+    (parent) process has touched HIP or torch.cuda; it only waits and passes the exit code on."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------- workloads ----
 def synth_frames_gpu(torch, base_u8, n, seed, device, shift=8, sigma=2.0):
-    """BASELINE config 3 synthesis: fixture (i mod K) circularly
-    shifted by (dx, dy) in [-shift, shift]^2 plus N(0, sigma^2) integer noise."""
+    """BASELINE config 3/4 synthesis: fixture (i mod K) circularly shifted by (dx, dy) in
+    [-shift, shift]^2 plus N(0, sigma^2) integer noise, clipped to u8."""
     rng = np.random.default_rng(seed)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -52,264 +82,540 @@ def synth_frames_gpu(torch, base_u8, n, seed, device, shift=8, sigma=2.0):
     return out
 
 
+def load_fixture_frames(sample_dir):
+    from meterelf_amd._image import imread_bgr
+    files = [f for f in sorted(glob.glob(os.path.join(GOLDEN, sample_dir, '*.jpg')))
+             if os.path.basename(f) not in REJECTED]
+    base = [imread_bgr(f) for f in files]
+    shape = base[0].shape
+    return np.stack([b for b in base if b.shape == shape])
+
+
+def config5_params_dir():
+    """BASELINE config 5: 1920x1080 frames, meter_rect 250x250 inside the frame, six needle_data
+    entries (the four of sample-images1 + two more at slightly moved centres), same template."""
+    import yaml
+    src = os.path.join(GOLDEN, 'sample-images1')
+    with open(os.path.join(src, 'params.yml')) as fp:
+        data = yaml.safe_load(fp)
+    data['meter_rect'] = {'top_left': [1210, 420], 'bottom_right': [1460, 670]}
+    extra = []
+    for (k, nd) in enumerate(data['needle_data'][:2]):
+        nd2 = dict(nd)
+        nd2['name'] = '1.%d' % k
+        nd2['center'] = [nd['center'][0] + 0.4, nd['center'][1] - 0.3]
+        extra.append(nd2)
+    data['needle_data'] = data['needle_data'] + extra
+    d = tempfile.mkdtemp(prefix='melf_cfg5_')
+    with open(os.path.join(d, 'params.yml'), 'w') as fp:
+        yaml.safe_dump(data, fp)
+    shutil.copy(os.path.join(src, 'dials_gray.png'), os.path.join(d, 'dials_gray.png'))
+    return d
+
+
+class Env:
+    """Per-rank state: device, stream, process group."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.args = args
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.under_torchrun = 'RANK' in os.environ
+        self.dist = None
+        self.backend = None
+        from meterelf_amd import _hip
+        ndev = _hip.device_count()
+        if not torch.cuda.is_available() or ndev < 1:
+            raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
+        if args.share_gpu:
+            self.dev_index = self.local_rank % ndev   # rehearsal on a box with fewer GPUs than ranks (gloo only)
+        else:
+            if self.local_rank >= ndev:
+                raise SystemExit('rank %d has no GPU: %d visible (use --share-gpu --backend gloo to rehearse)' % (self.rank, ndev))
+            self.dev_index = self.local_rank
+        torch.cuda.set_device(self.dev_index)
+        self.device = torch.device('cuda', self.dev_index)
+        if self.under_torchrun:
+            import torch.distributed as dist
+            self.backend = args.backend
+            if args.share_gpu and self.backend == 'nccl' and self.world > ndev:
+                raise SystemExit('--share-gpu puts several ranks on one GPU: RCCL cannot do that, use --backend gloo')
+            dist.init_process_group(backend=self.backend)
+            self.dist = dist
+        self.stream_obj = torch.cuda.Stream(device=self.device)   # not torch's default stream: no implicit null-stream syncs
+        self.stream = self.stream_obj.cuda_stream
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def make_context(self, pfile):
+        """Rank 0 reads params.yml and packs the calibration blob; with several ranks it is broadcast (RCCL with the
+        nccl backend, GPU to GPU) and every rank creates its context from the received bytes."""
+        from meterelf_amd import _engine, _hip, _params
+        if self.dist is None:
+            params = _params.load(pfile)
+            return _hip.Context(_engine.make_blob(params), self.dev_index), list(params.dial_names)
+        from meterelf_amd import _dist
+        (blob, names) = (None, None)
+        if self.rank == 0:
+            params = _params.load(pfile)
+            (blob, names) = (_engine.make_blob(params), list(params.dial_names))
+        (blob, dev_blob, names) = _dist.broadcast_blob(blob, names, src=0, device=self.device if self.backend == 'nccl' else None)
+        if dev_blob is not None:
+            return _hip.Context(blob, self.dev_index, blob_device_ptr=dev_blob.data_ptr()), names
+        return _hip.Context(blob, self.dev_index), names
+
+
+def timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=None):
+    """Exactly `steps` steps between barrier + synchronize on both sides; step i reads batch i % nbuf and writes that
+    batch's record slice.  Returns (elapsed seconds of this rank, records of all nbuf batches)."""
+    from meterelf_amd import _hip
+    torch = env.torch
+    fs = frame_stride or H * W * 3
+    rsz = _hip.RESULT_DTYPE.itemsize
+    env.barrier()
+    env.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        b = i % nbuf
+        ctx.process_batch_dev(frames.data_ptr() + b * B * fs, B, H, W, frame_stride=fs,
+                              d_results_ptr=d_results.data_ptr() + b * B * rsz, want_host=False, stream=env.stream)
+    with torch.cuda.stream(env.stream_obj):
+        recs = d_results.cpu()          # D2H of the records: inside the timed region
+    env.sync()
+    env.barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, recs.numpy().view(_hip.RESULT_DTYPE)
+
+
+def max_over_ranks(env, elapsed):
+    """(max over ranks, list of every rank's seconds)"""
+    if env.dist is None:
+        return elapsed, [elapsed]
+    torch = env.torch
+    dev = env.device if env.backend == 'nccl' else torch.device('cpu')
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    allt = [torch.zeros_like(t) for _ in range(env.world)]
+    env.dist.all_gather(allt, t)
+    per = [float(x.item()) for x in allt]
+    return max(per), per
+
+
+def match_roofline(P, H, W, kt, frames_total, traffic_entry):
+    crows = min(P.rect_y1, H) - min(P.rect_y0, H)
+    ccols = min(P.rect_x1, W) - min(P.rect_x0, W)
+    positions = (crows - P.th + 1) * (ccols - P.tw + 1)
+    mac_per_frame = positions * P.th * P.tw            # SURVEY.md 8(d): 186 045 552 (sample-images1), 12 550 692 (sample-images2)
+    (match_ms, match_n) = kt['k_match']
+    match_avg_ms = match_ms / max(match_n, 1)
+    frames_per_launch = frames_total / max(match_n, 1)
+    tops = 2.0 * mac_per_frame * frames_per_launch / (match_avg_ms * 1e-3) / 1e12 if match_n else 0.0
+    (traffic, source) = traffic_entry
+    return {
+        'kernel': 'k_match', 'bound': 'mfma', 'achieved': round(tops, 3), 'peak': I8_MFMA_PEAK_TOPS,
+        'unit': 'TFLOP/s', 'frac': round(tops / I8_MFMA_PEAK_TOPS, 5), 'traffic': traffic, 'traffic_source': source,
+        'avg_launch_ms': round(match_avg_ms, 4), 'launches': match_n,
+        'algorithmic': '%d int MAC/frame x %d frames/launch, 2 ops per MAC' % (mac_per_frame, frames_per_launch),
+        'note': 'exact integer TM_CCOEFF on v_mfma_i32_32x32x32_i8; algorithmic MACs only (Toeplitz zero padding '
+                'is not counted), priced against the dense i8 MFMA peak',
+    }
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'meterelf_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'meterelf_amd', 'csrc', '*.h'))):
+        with open(f, 'rb') as fp:
+            h.update(fp.read())
+    return h.hexdigest()[:16]
+
+
+class Traffic:
+    """HBM bytes per launch from the PMC passes of tools/profile_round.sh (rocprofv3 cannot run inside this
+    process): profiles/rNN/traffic.json = {"kernel_sources_sha16": ..., "per_launch_bytes": {"config3:k_match": N, ...},
+    "files": [...]}.  The file records the kernel sources it was measured on; if they changed since, the figures are
+    reported as stale (null) instead of being silently carried over."""
+
+    def __init__(self):
+        self.table = {}
+        self.source = None
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'traffic.json')), reverse=True)
+        if not cands:
+            return
+        with open(cands[0]) as fp:
+            t = json.load(fp)
+        self.source = os.path.relpath(cands[0], ROOT)
+        if t.get('kernel_sources_sha16') != kernel_sources_sha():
+            self.source += ' (stale: kernel sources changed since those PMC passes)'
+        else:
+            self.table = t.get('per_launch_bytes', {})
+
+    def get(self, key, default=None):
+        return (self.table.get(key), self.source)
+
+
+def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustained_s, traffic, cpu_sample, label):
+    """One context + nbuf distinct batches; the contract's timed region, per-kernel times, optional sustained run and
+    optional CPU-oracle sample.  Returns a dict of raw results."""
+    from meterelf_amd import _hip
+    torch = env.torch
+    (ctx, names) = env.make_context(pfile)
+    P = ctx.params
+    base = load_fixture_frames(sample_dir)
+    (H, W) = base.shape[1:3]
+    base_gpu = torch.from_numpy(base).to(env.device)
+    frames = synth_frames_gpu(torch, base_gpu, B * nbuf, seed + env.rank, env.device)
+    del base_gpu
+    d_results = torch.zeros(B * nbuf * _hip.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=env.device)
+    env.sync()
+
+    def run(k):
+        return timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, k)
+
+    run(max(warmup, 1))
+    # a few steps with every kernel bracketed by events (informational per-kernel times) ...
+    ctx.set_profiling(1)
+    ctx.timings()
+    run(max(3, nbuf))
+    kt_all = ctx.timings()
+    # ... then the timed region with stamps on the dominant kernel only (no extra packets in the queue)
+    ctx.set_profiling(2)
+    (elapsed, recs) = run(steps)
+    kt = ctx.timings()
+    (elapsed_max, per_rank) = max_over_ranks(env, elapsed)
+    out = {'ctx': ctx, 'P': P, 'H': H, 'W': W, 'frames': frames, 'recs': recs, 'elapsed': elapsed_max,
+           'per_rank_ms': [round(t / steps * 1e3, 4) for t in per_rank], 'kt': kt, 'kt_all': kt_all,
+           'roofline': match_roofline(P, H, W, kt, B * steps, traffic.get(label + ':k_match'))}
+    out['kernel_ms'] = {k: round(ms / n, 4) for (k, (ms, n)) in kt_all.items() if n}
+    if sustained_s > 0:
+        est = max(elapsed / steps, 1e-5)
+        k = int(sustained_s / est * 1.15) + nbuf
+        (el, _r) = run(k)
+        kts = ctx.timings()
+        (el_max, _p) = max_over_ranks(env, el)
+        r = match_roofline(P, H, W, kts, B * k, (None, None))
+        out['sustained'] = {'seconds': round(el_max, 3), 'steps': k, 'ms_per_step': round(el_max / k * 1e3, 4),
+                            'frames_per_s': round(env.world * B * k / el_max, 1),
+                            'k_match_avg_launch_ms': r['avg_launch_ms'], 'k_match_frac': r['frac']}
+    ctx.set_profiling(0)
+    if cpu_sample > 0:
+        out['cpu'] = cpu_block(pfile, frames, recs, min(cpu_sample, B))
+    return out
+
+
+def cpu_block(pfile, frames, recs, S):
+    """The CPU oracle (port of the reference's algorithm; the reference itself needs OpenCV 3.4.5, absent here) on
+    the first S frames of batch 0: one thread (the reference is single-threaded) and all of this GPU's host cores.
+    The same sample is the in-run parity gate."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as po
+    sample = frames[:S].cpu().numpy()
+    op = po.Params(pfile)
+    po.process_frames(sample[:2], op)  # warm the library
+    tc0 = time.perf_counter()
+    ores = po.process_frames(sample, op)
+    tc = time.perf_counter() - tc0
+    mism = 0
+    for i in range(S):
+        (r, o) = (recs[i], ores[i])
+        same = int(r['status']) == o.status and int(r['match_x']) == o.match_x and int(r['match_y']) == o.match_y
+        if same and o.status == 0:
+            same = '{:07.3f}'.format(float(r['value'])) == '{:07.3f}'.format(o.value)
+        mism += 0 if same else 1
+    ncores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    ncores = min(ncores, 16, S)  # one GPU's share of the host
+    parts = [sample[i::ncores] for i in range(ncores) if len(sample[i::ncores])]
+    with ThreadPoolExecutor(max_workers=ncores) as pool:
+        tm0 = time.perf_counter()
+        list(pool.map(lambda part: po.process_frames(part, op), parts))
+        tm = time.perf_counter() - tm0
+    return {'value': round(S / tc, 2), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+            'all_cores': {'value': round(S / tm, 2), 'unit': 'frames/s', 'cores': ncores},
+            'sample': 'first %d frames of batch 0 of the same workload through oracle/melf_oracle.c (exact direct '
+                      'correlation, single thread, %.1f s; the reference itself needs OpenCV 3.4.5, absent here)' % (S, tc),
+            'parity_mismatches_vs_gpu': mism}
+
+
+def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=None):
+    """Fused HLS + inRange + closing over nbuf distinct input / output buffer pairs (the pairs together exceed the
+    Infinity Cache several times over).  HBM roofline from the per-launch event times."""
+    torch = env.torch
+    g = torch.Generator(device=env.device)
+    g.manual_seed(1234 + env.rank)
+    if frames is None:
+        frames = torch.randint(0, 256, (nbuf * FB, H, W, 3), dtype=torch.uint8, device=env.device, generator=g)
+    masks = torch.empty((nbuf * FB, H, W), dtype=torch.uint8, device=env.device)
+
+    def launch(i):
+        b = i % nbuf
+        ctx.hls_inrange_close_dev(frames.data_ptr() + b * FB * H * W * 3, FB, H, W, masks.data_ptr() + b * FB * H * W,
+                                  stream=env.stream)
+    for i in range(max(warmup, nbuf)):
+        launch(i)
+    env.sync()
+    ctx.set_profiling(1)
+    ctx.timings()
+    tf0 = time.perf_counter()
+    for i in range(steps):
+        launch(i)
+    env.sync()
+    tf = time.perf_counter() - tf0
+    (fms, fn) = ctx.timings()['k_fused_mask']
+    ctx.set_profiling(0)
+    favg = fms / max(fn, 1)
+    alg_bytes = FB * H * W * 4   # 3 B/px read + 1 B/px written
+    gbs = alg_bytes / (favg * 1e-3) / 1e9
+    (tr, src) = traffic.get(label + ':k_fused_mask')
+    del masks
+    return {
+        'workload': 'B=%d %dx%d uniform-random u8 frames, fused HLS+inRange+closing only, %d distinct buffer pairs '
+                    '(%.2f GB) in rotation' % (FB, W, H, nbuf, nbuf * alg_bytes / 1e9),
+        'frames_per_s': round(FB * steps / tf, 1),
+        'roofline': {'kernel': 'k_fused_mask', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': tr, 'traffic_source': src,
+                     'avg_launch_ms': round(favg, 4), 'launches': fn,
+                     'algorithmic': '%d B/frame x %d frames/launch' % (H * W * 4, FB)},
+    }
+
+
+def config5_block(env, cfg3_frames, steps, warmup, traffic):
+    """BASELINE config 5, one GPU's share: 512 frames of 1920x1080, meter_rect inside the frame, six dials.
+    (a) the fused per-pixel stage over whole frames (the HBM stress), (b) the full path (match on the 250x250
+    meter_rect + six dials)."""
+    from meterelf_amd import _hip
+    torch = env.torch
+    d = config5_params_dir() if env.rank == 0 else None
+    try:
+        (ctx, names) = env.make_context(os.path.join(d, 'params.yml') if d else None)
+    finally:
+        if d:
+            shutil.rmtree(d, ignore_errors=True)
+    (B5, H5, W5) = (env.args.batch5, 1080, 1920)
+    g = torch.Generator(device=env.device)
+    g.manual_seed(1080 + env.rank)
+    frames = torch.randint(0, 256, (B5, H5, W5, 3), dtype=torch.uint8, device=env.device, generator=g)
+    # the meter: config 3's synthesised frames' meter_rect crops pasted at the 1080p meter_rect
+    k = cfg3_frames.shape[0]
+    for i0 in range(0, B5, k):
+        m = min(k, B5 - i0)
+        frames[i0:i0 + m, 420:670, 1210:1460] = cfg3_frames[:m, 160:410, 50:300]
+    env.sync()
+    fused = fused_block(env, ctx, B5, H5, W5, 1, max(3, steps // 4), 2, traffic, 'config5', frames=frames)
+    fused['workload'] = ('B=%d frames of 1920x1080 (%.2f GB in + %.2f GB out per launch), fused HLS+inRange+closing over '
+                         'whole frames' % (B5, B5 * H5 * W5 * 3 / 1e9, B5 * H5 * W5 / 1e9))
+    d_results = torch.zeros(B5 * _hip.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=env.device)
+    timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, max(warmup, 1))
+    ctx.set_profiling(1)
+    ctx.timings()
+    timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, 3)
+    kt_all = ctx.timings()
+    ctx.set_profiling(2)
+    (el, recs) = timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, steps)
+    kt = ctx.timings()
+    ctx.set_profiling(0)
+    (el_max, _p) = max_over_ranks(env, el)
+    P = ctx.params
+    out = {'workload': 'B=%d per GPU, 1920x1080 frames (%d B/frame, %.2f GB per GPU), 6 dials, meter_rect 250x250 inside '
+                       'the frame' % (B5, H5 * W5 * 3, B5 * H5 * W5 * 3 / 1e9),
+           'fused_mask': fused,
+           'full_path': {'frames_per_s': round(env.world * B5 * steps / el_max, 1), 'ms_per_step': round(el_max / steps * 1e3, 4),
+                         'dials': int(P.ndials), 'frames_read_ok': int((recs['status'] == 0).sum()),
+                         'kernel_ms': {k_: round(ms / n, 4) for (k_, (ms, n)) in kt_all.items() if n},
+                         'roofline': match_roofline(P, H5, W5, kt, B5 * steps, (None, None))}}
+    ctx.close()
+    return out
+
+
+def hostfed_block(env, ctx, frames, B, H, W):
+    """melf_process_batch: frames in pageable HOST memory in, records out (PCIe inclusive; never `value`)."""
+    host = frames[:B].cpu().numpy()
+    ctx.process_batch(host[:64])
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        recs = ctx.process_batch(host)
+    dt = (time.perf_counter() - t0) / reps
+    P = ctx.params
+    crop_bytes = (min(P.rect_y1, H) - min(P.rect_y0, H)) * (min(P.rect_x1, W) - min(P.rect_x0, W)) * 3
+    return {'workload': '%d frames %dx%d in pageable host memory -> records on the host, one melf_process_batch call' % (B, W, H),
+            'frames_per_s': round(B / dt, 1), 'ms_per_call': round(dt * 1e3, 3),
+            'pcie_GBps_crop_bytes': round(B * crop_bytes / dt / 1e9, 2),
+            'frame_GBps_equivalent': round(B * H * W * 3 / dt / 1e9, 2),
+            'frames_read_ok': int((recs['status'] == 0).sum())}
+
+
+def jpeg_block(ctx, sample_dir, H, W):
+    from meterelf_amd import _hip
+    from meterelf_amd._image import imread_bgr
+    jfiles = [f for f in sorted(glob.glob(os.path.join(GOLDEN, sample_dir, '*.jpg'))) if os.path.basename(f) not in REJECTED]
+    blobs = [open(f, 'rb').read() for f in jfiles]
+    keep = [i for (i, b) in enumerate(blobs) if _hip.jpeg_probe(b)[:3] == (H, W, True)]
+    (jfiles, blobs) = ([jfiles[i] for i in keep], [blobs[i] for i in keep])
+    if not blobs:
+        return None
+    JB = 1024
+    batch = [blobs[i % len(blobs)] for i in range(JB)]
+    (jf, jst) = ctx.jpeg_decode(blobs[:8], H, W)
+    same = bool((jst == 0).all()) and all(np.array_equal(jf[i], imread_bgr(f)) for (i, f) in enumerate(jfiles[:8]))
+    ctx.jpeg_process_batch(batch, H, W)  # warm-up (allocations)
+    ctx.set_profiling(1)
+    ctx.timings()
+    tj0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        (jrecs, jstatus) = ctx.jpeg_process_batch(batch, H, W)
+    tj = (time.perf_counter() - tj0) / reps
+    jt = ctx.timings()
+    ctx.set_profiling(0)
+    return {'workload': '%d JPEG files (%d distinct %s fixtures, %.1f KB average) -> decode + full reading path, '
+                        'file bytes in host memory to result records' % (JB, len(blobs), sample_dir, sum(map(len, blobs)) / len(blobs) / 1024),
+            'files_per_s': round(JB / tj, 1), 'ms_per_call': round(tj * 1e3, 3),
+            'kernel_ms': {k: round(ms / c, 4) for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
+            'decoded_frames_equal_libjpeg_turbo': same, 'files_ok': int((jstatus == 0).sum())}
+
+
+def dry_run(args):
+    """Launch / rendezvous / collective plumbing without a GPU (CI): no step is run, nothing is measured."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    ranks = 1
+    if 'RANK' in os.environ:
+        dist.init_process_group(backend='gloo')
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        ranks = int(t.item())
+        from meterelf_amd import _dist, _engine, _params
+        (blob, names) = (None, None)
+        if rank == 0:
+            params = _params.load(os.path.join(GOLDEN, args.sample_dir, 'params.yml'))
+            (blob, names) = (_engine.make_blob(params), list(params.dial_names))
+        (blob, _dev, names) = _dist.broadcast_blob(blob, names, src=0)
+        digest = hashlib.sha256(blob.tobytes()).hexdigest()[:16]
+        allsums = [None] * world
+        dist.all_gather_object(allsums, digest)
+        assert len(set(allsums)) == 1, allsums
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'metric': 'none (launch rehearsal, nothing measured)', 'value': None, 'n_gpus': world,
+                          'collective_ranks': ranks, 'backend': 'gloo' if 'RANK' in os.environ else None}))
+        sys.stdout.flush()
+    if 'RANK' in os.environ:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=1024, help='frames per GPU per step')
+    ap.add_argument('--nbuf', type=int, default=4, help='distinct batches the steps rotate over')
+    ap.add_argument('--batch5', type=int, default=512, help='config 5: 1080p frames per GPU')
     ap.add_argument('--sample-dir', default='sample-images1')
-    ap.add_argument('--cpu-sample', type=int, default=256, help='frames timed through the CPU oracle (0 = skip)')
-    ap.add_argument('--no-fused-mask', action='store_true')
-    ap.add_argument('--overlap', action='store_true',
-                    help='the K steps as ONE melf_process_stream_dev call (steps overlap on two lanes: more frames/s, but the '
-                         'match kernel then shares the SIMDs and its own launch time -- the roofline figure -- stretches)')
-    ap.add_argument('--no-jpeg', action='store_true', help='skip the JPEG-files-in block (SURVEY 8 f1)')
+    ap.add_argument('--cpu-sample', type=int, default=768, help='frames timed through the CPU oracle (about 10 s on one core)')
+    ap.add_argument('--sustained', type=float, default=2.0, help='seconds of back-to-back steps in the sustained block')
+    ap.add_argument('--skip', default='', help='comma list of blocks to skip: ' + ','.join(ALL_BLOCKS))
+    ap.add_argument('--only', default='', help='comma list of extra blocks to run (default: all)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (nccl = RCCL)')
+    ap.add_argument('--share-gpu', action='store_true', help='rehearsal: ranks share the visible GPUs (gloo backend only)')
+    ap.add_argument('--dry-run', action='store_true', help='launcher / collective rehearsal without a GPU; measures nothing')
     args = ap.parse_args()
 
-    import torch
-    from meterelf_amd import _engine, _hip, _params
-    from meterelf_amd._image import imread_bgr
-
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs a torch.distributed.run launch with %d ranks' % (args.gpus, args.gpus))
-    if not torch.cuda.is_available() or _hip.device_count() < 1:
-        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args)
 
+    blocks = set(ALL_BLOCKS)
+    if args.only:
+        blocks = set(x for x in args.only.split(',') if x)
+    blocks -= set(x for x in args.skip.split(',') if x)
+
+    env = Env(args)
+    torch = env.torch
+    (rank, world) = (env.rank, env.world)
+    rccl_ranks = None
+    if env.dist is not None:
+        one = torch.ones(1, dtype=torch.int32, device=env.device if env.backend == 'nccl' else 'cpu')
+        env.dist.all_reduce(one)
+        rccl_ranks = int(one.item()) if env.backend == 'nccl' else None
+    traffic = Traffic()
+    single = world == 1
+
+    # ---- headline: BASELINE config 3 ----
     pfile = os.path.join(GOLDEN, args.sample_dir, 'params.yml')
-    dist = None
-    if world > 1 or 'RANK' in os.environ:   # launched by torch.distributed.run (also with one rank)
-        from meterelf_amd import _dist
-        dist = _dist.init_process_group('nccl')
-        (blob, names) = (None, None)
-        if rank == 0:
-            params = _params.load(pfile)
-            blob, names = _engine.make_blob(params), params.dial_names
-        (blob, dev_blob, names) = _dist.broadcast_blob(blob, names, src=0, device=device)
-        ctx = _hip.Context(blob, local_rank, blob_device_ptr=dev_blob.data_ptr())
-    else:
-        params = _params.load(pfile)
-        blob = _engine.make_blob(params)
-        ctx = _hip.Context(blob, local_rank)
-    P = ctx.params
+    main_label = 'config3' if args.sample_dir == 'sample-images1' else 'config4'
+    full = full_path_block(env, pfile, args.sample_dir, 2024, args.steps, args.warmup, args.batch, args.nbuf,
+                           args.sustained if 'sustained' in blocks else 0.0, traffic,
+                           args.cpu_sample if (single and 'cpu' in blocks) else 0, main_label)
+    (ctx, P, H, W, B) = (full['ctx'], full['P'], full['H'], full['W'], args.batch)
+    n_ok = int((full['recs'][:B]['status'] == 0).sum())
+    roofline = full['roofline']
+    roofline['k_dials_avg_launch_ms'] = full['kernel_ms'].get('k_dials')
+    roofline['k_prep_avg_launch_ms'] = full['kernel_ms'].get('k_lplane')
 
-    # ---- synthetic workload, resident in HBM ----
-    files = [f for f in sorted(glob.glob(os.path.join(GOLDEN, args.sample_dir, '*.jpg')))
-             if os.path.basename(f) not in REJECTED]
-    base = [imread_bgr(f) for f in files]
-    shape = base[0].shape
-    base = np.stack([b for b in base if b.shape == shape])
-    (H, W) = shape[:2]
-    base_gpu = torch.from_numpy(base).to(device)
-    B = args.batch
-    frames = synth_frames_gpu(torch, base_gpu, B, 2024 + rank, device)
-    del base_gpu
-    torch.cuda.synchronize()
-    stream = torch.cuda.current_stream().cuda_stream
-
-    # results stay on the device during the timed region (one record buffer per step would do the
-    # same; the path has no step-to-step dependency) and are copied to the host once at the end
-    d_results = torch.empty(B * _hip.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
-
-    def step():
-        ctx.process_batch_dev(frames.data_ptr(), B, H, W, d_results_ptr=d_results.data_ptr(), want_host=False,
-                              stream=stream)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # A few steps with every kernel bracketed by events (informational per-kernel times), then the timed
-    # region with events around the dominant kernel only: each event record is a barrier packet in the
-    # queue, eight of them per step cost ~4 % of the step.
-    ctx.set_profiling(1)
-    ctx.timings()
-    for _ in range(max(3, args.warmup)):
-        step()
-    torch.cuda.synchronize()
-    kt_all = ctx.timings()
-    ctx.set_profiling(2)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if not args.overlap:
-        for _ in range(args.steps):
-            step()
-    else:
-        # the K steps as one stream of K batches (melf_process_stream_dev): consecutive steps alternate between the
-        # context's two pipeline lanes, so one step's prep / dials kernels run in the tail of the other's match kernel
-        ctx.process_stream_dev(frames.data_ptr(), args.steps, 0, B, H, W, d_results.data_ptr(), 0, stream=stream)
-    recs = d_results.cpu().numpy().view(_hip.RESULT_DTYPE)   # D2H of the last step's records: inside the timed region
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kt = ctx.timings()
-    ctx.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    n_ok = int((recs['status'] == 0).sum())
-
-    if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
-
-    # ---- roofline of the dominant kernel (k_match) ----
-    crows = min(P.rect_y1, H) - min(P.rect_y0, H)
-    ccols = min(P.rect_x1, W) - min(P.rect_x0, W)
-    positions = (crows - P.th + 1) * (ccols - P.tw + 1)
-    mac_per_frame = positions * P.th * P.tw            # 186 045 552 for sample-images1
-    (match_ms, match_n) = kt['k_match']
-    (dials_ms, dials_n) = kt_all['k_dials']
-    (prep_ms, prep_n) = kt_all['k_lplane']
-    match_avg_ms = match_ms / max(match_n, 1)
-    frames_per_launch = B * args.steps / max(match_n, 1)   # a step may issue its match as several launches (pipeline lanes)
-    tops = 2.0 * mac_per_frame * frames_per_launch / (match_avg_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
-        with open(tpath) as fp:
-            traffic = json.load(fp)
-    roofline = {
-        'kernel': 'k_match', 'bound': 'mfma', 'achieved': round(tops, 3), 'peak': I8_MFMA_PEAK_TOPS,
-        'unit': 'TFLOP/s', 'frac': round(tops / I8_MFMA_PEAK_TOPS, 5),
-        'traffic': (traffic or {}).get('k_match'),
-        'avg_launch_ms': round(match_avg_ms, 4), 'launches': match_n,
-        'algorithmic': '%d int MAC/frame x %d frames/launch, 2 ops per MAC' % (mac_per_frame, frames_per_launch),
-        'note': 'exact integer TM_CCOEFF on v_mfma_i32_32x32x32_i8; algorithmic MACs (the Toeplitz form issues 1.28x as many), priced against the dense i8 MFMA peak',
-        'k_dials_avg_launch_ms': round(dials_ms / max(dials_n, 1), 4),   # these two from the untimed all-kernel pass
-        'k_prep_avg_launch_ms': round(prep_ms / max(prep_n, 1), 4),
-    }
-
-    # ---- BASELINE config 2: fused HLS + inRange + closing, B=256 ----
     fused = None
-    if not args.no_fused_mask:
-        FB = 256
-        g = torch.Generator(device=device)
-        g.manual_seed(1234)
-        fframes = torch.randint(0, 256, (FB, 640, 480, 3), dtype=torch.uint8, device=device, generator=g)
-        fmasks = torch.empty((FB, 640, 480), dtype=torch.uint8, device=device)
-        for _ in range(args.warmup):
-            ctx.hls_inrange_close_dev(fframes.data_ptr(), FB, 640, 480, fmasks.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
-        ctx.set_profiling(True)
-        ctx.timings()
-        tf0 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.hls_inrange_close_dev(fframes.data_ptr(), FB, 640, 480, fmasks.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
-        tf = time.perf_counter() - tf0
-        (fms, fn) = ctx.timings()['k_fused_mask']
-        ctx.set_profiling(False)
-        favg = fms / max(fn, 1)
-        alg_bytes = FB * 640 * 480 * 4   # 3 B/px read + 1 B/px written
-        gbs = alg_bytes / (favg * 1e-3) / 1e9
-        fused = {
-            'workload': 'B=256 640x480 uniform-random u8 frames, fused HLS+inRange+closing only',
-            'frames_per_s': round(FB * args.steps / tf, 1),
-            'roofline': {'kernel': 'k_fused_mask', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
-                         'traffic': (traffic or {}).get('k_fused_mask'),
-                         'avg_launch_ms': round(favg, 4), 'launches': fn,
-                         'algorithmic': '1 228 800 B/frame x 256 frames/launch'},
+    if 'fused' in blocks:
+        fused = fused_block(env, ctx, 256, 640, 480, 4, args.steps, args.warmup, traffic, 'config2')
+    hostfed = hostfed_block(env, ctx, full['frames'], B, H, W) if (single and 'hostfed' in blocks) else None
+    jpeg = jpeg_block(ctx, args.sample_dir, H, W) if (single and 'jpeg' in blocks) else None
+
+    cfg5 = None
+    if 'config5' in blocks and args.sample_dir == 'sample-images1':
+        cfg5 = config5_block(env, full['frames'], args.steps, args.warmup, traffic)
+    cfg3_frames = full.pop('frames')
+    del cfg3_frames
+    ctx.close()
+
+    cfg4 = None
+    if 'config4' in blocks and args.sample_dir == 'sample-images1':
+        torch.cuda.empty_cache()
+        p4 = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
+        f4 = full_path_block(env, p4, 'sample-images2', 2025, args.steps, args.warmup, args.batch, args.nbuf, 0.0, traffic,
+                             min(args.cpu_sample, 256) if (single and 'cpu' in blocks) else 0, 'config4')
+        cfg4 = {'workload': 'Batch=%d per GPU (%d in total), sample-images2 params (crop 135x220, 561 match positions), '
+                            'calibration blob broadcast from rank 0%s, %d distinct batches in rotation'
+                            % (B, B * world, ' over RCCL' if env.backend == 'nccl' else '', args.nbuf),
+                'frames_per_s': round(world * B * args.steps / f4['elapsed'], 1), 'ms_per_step': round(f4['elapsed'] / args.steps * 1e3, 4),
+                'per_rank_ms_per_step': f4['per_rank_ms'], 'frames_read_ok_batch0': int((f4['recs'][:B]['status'] == 0).sum()),
+                'kernel_ms': f4['kernel_ms'], 'roofline': f4['roofline'], 'cpu_baseline': f4.get('cpu')}
+        f4['ctx'].close()
+
+    if rank == 0:
+        elapsed = full['elapsed']
+        line = {
+            'metric': 'frames/sec (640x480), full pipeline, digits identical to the oracle',
+            'value': round(world * B * args.steps / elapsed, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'config': {'workload': 'Batch=%d per GPU, full pipeline incl. TM_CCOEFF match + needle reading, 4 dials/frame, '
+                                   '%s params, frames %dx%d synthesised from the readable fixtures (shift +-8, noise sigma 2), '
+                                   '%d distinct batches in rotation (%.2f GB of frames per GPU)'
+                                   % (B, args.sample_dir, W, H, args.nbuf, args.nbuf * B * H * W * 3 / 1e9),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'frames_read_ok_batch0': n_ok},
+            'per_rank_ms_per_step': full['per_rank_ms'], 'rccl_ranks': rccl_ranks, 'backend': env.backend,
+            'kernel_ms': full['kernel_ms'],
+            'roofline': roofline, 'sustained': full.get('sustained'), 'cpu_baseline': full.get('cpu'),
+            'fused_mask': fused, 'config4': cfg4, 'config5': cfg5, 'host_fed': hostfed, 'jpeg_decode': jpeg,
         }
-        del fframes, fmasks
-
-    # ---- CPU baseline (oracle port) + in-run parity gate on the same sample ----
-    cpu = None
-    if world == 1 and args.cpu_sample > 0:
-        from oracle import pyoracle as po
-        S = min(args.cpu_sample, B)
-        sample = frames[:S].cpu().numpy()
-        op = po.Params(pfile)
-        po.process_frames(sample[:2], op)  # warm the library
-        tc0 = time.perf_counter()
-        ores = po.process_frames(sample, op)
-        tc = time.perf_counter() - tc0
-        mism = 0
-        for i in range(S):
-            (r, o) = (recs[i], ores[i])
-            same = int(r['status']) == o.status and int(r['match_x']) == o.match_x and int(r['match_y']) == o.match_y
-            if same and o.status == 0:
-                same = '{:07.3f}'.format(float(r['value'])) == '{:07.3f}'.format(o.value)
-            mism += 0 if same else 1
-        # the same sample again on every host core (threads over chunks; the C call releases the GIL)
-        from concurrent.futures import ThreadPoolExecutor
-        ncores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
-        ncores = min(ncores, 16, S)  # one GPU's share of the host
-        parts = [sample[i::ncores] for i in range(ncores) if len(sample[i::ncores])]
-        with ThreadPoolExecutor(max_workers=ncores) as pool:
-            tm0 = time.perf_counter()
-            list(pool.map(lambda part: po.process_frames(part, op), parts))
-            tm = time.perf_counter() - tm0
-        cpu = {'value': round(S / tc, 2), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-               'all_cores': {'value': round(S / tm, 2), 'unit': 'frames/s', 'cores': ncores},
-               'sample': 'first %d frames of the same batch through oracle/melf_oracle.c (exact direct '
-                         'correlation, single thread; the reference itself needs OpenCV 3.4.5, absent here)' % S,
-               'parity_mismatches_vs_gpu': mism}
-
-    # ---- the same path fed with JPEG files (decode on the GPU), fixture files tiled to B ----
-    jpeg = None
-    if world == 1 and not args.no_jpeg:
-        import glob as _glob
-        jfiles = [f for f in sorted(_glob.glob(os.path.join(ROOT, 'tests', 'golden', args.sample_dir, '*.jpg')))
-                  if os.path.basename(f) not in REJECTED]
-        blobs = [open(f, 'rb').read() for f in jfiles]
-        blobs = [b for b in blobs if _hip.jpeg_probe(b)[:3] == (H, W, True)]
-        if blobs:
-            JB = 1024
-            batch = [blobs[i % len(blobs)] for i in range(JB)]
-            (jf, jst) = ctx.jpeg_decode(blobs[:8], H, W)
-            from meterelf_amd._image import imread_bgr
-            same = bool((jst == 0).all()) and all(
-                np.array_equal(jf[i], imread_bgr(f)) for (i, f) in enumerate([f for f in jfiles][:8])
-                if _hip.jpeg_probe(open(f, 'rb').read())[:2] == (H, W))
-            ctx.jpeg_process_batch(batch, H, W)  # warm-up (allocations)
-            ctx.set_profiling(True)
-            ctx.timings()
-            tj0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                (jrecs, jstatus) = ctx.jpeg_process_batch(batch, H, W)
-            tj = (time.perf_counter() - tj0) / reps
-            jt = ctx.timings()
-            ctx.set_profiling(False)
-            jpeg = {'workload': '%d JPEG files (%d distinct %s fixtures, %.1f KB average) -> decode + full reading path, '
-                                'file bytes in host memory to result records' % (JB, len(blobs), args.sample_dir,
-                                                                                 sum(map(len, blobs)) / len(blobs) / 1024),
-                    'files_per_s': round(JB / tj, 1), 'ms_per_call': round(tj * 1e3, 3),
-                    'kernel_ms': {k: round(ms / c, 4) for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
-                    'decoded_frames_equal_libjpeg_turbo': same, 'files_ok': int((jstatus == 0).sum())}
-
-    line = {
-        'metric': 'frames/sec (640x480), full pipeline, digits identical to the oracle',
-        'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'u8', 'data': 'synthetic',
-        'config': {'workload': 'Batch=%d per GPU, full pipeline incl. TM_CCOEFF match + needle reading, 4 dials/frame, '
-                               '%s params, frames %dx%d synthesised from the readable fixtures (shift +-8, noise sigma 2)'
-                               % (B, args.sample_dir, W, H),
-                   'global_batch': B * world, 'parallelism': 'dp%d' % world, 'frames_read_ok_last_step': n_ok},
-        'roofline': roofline, 'cpu_baseline': cpu, 'fused_mask': fused, 'jpeg_decode': jpeg,
-    }
-    print(json.dumps(line))
-    sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if env.dist is not None:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,61 @@
+"""bench.py's launcher: `--gpus N` must start its own N ranks (the driver runs it bare for the scaling bench).
+
+CPU: the launch + rendezvous + blob broadcast rehearsal (`--dry-run`, gloo, measures nothing).
+GPU: two ranks sharing the box's one GPU over gloo with the real kernels, and one rank under
+torch.distributed.run with the nccl (= RCCL) backend: broadcast_blob -> melf_ctx_create(blob_on_device=1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]   # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_gpus_2_self_launch_dry_run():
+    line = _run([sys.executable, BENCH, '--gpus', '2', '--dry-run'])
+    assert line['dry_run'] is True and line['n_gpus'] == 2 and line['collective_ranks'] == 2 and line['value'] is None
+
+
+def test_gpus_flag_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='1')
+    p = subprocess.run([sys.executable, BENCH, '--gpus', '3', '--dry-run'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b'WORLD_SIZE' in p.stderr
+
+
+SMALL = ['--steps', '3', '--warmup', '1', '--batch', '64', '--nbuf', '2']
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_over_gloo():
+    line = _run([sys.executable, BENCH, '--gpus', '2', '--backend', 'gloo', '--share-gpu', '--only', 'none'] + SMALL)
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 128 and line['config']['parallelism'] == 'dp2'
+    assert len(line['per_rank_ms_per_step']) == 2 and line['value'] > 0
+    assert line['config']['frames_read_ok_batch0'] >= 60
+    assert line['roofline']['launches'] == 3
+
+
+@pytest.mark.gpu
+def test_one_rank_nccl_broadcast_and_parity_gate():
+    """RCCL with one rank: all_reduce, broadcast of the calibration blob GPU-side, context from the device-resident
+    bytes; the CPU-oracle sample (checker) must agree with the records."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', BENCH, '--gpus', '1', '--only', 'cpu,config4', '--cpu-sample', '24'] + SMALL
+    line = _run(cmd)
+    assert line['rccl_ranks'] == 1 and line['backend'] == 'nccl' and line['n_gpus'] == 1
+    assert line['cpu_baseline']['parity_mismatches_vs_gpu'] == 0
+    assert line['config4']['cpu_baseline']['parity_mismatches_vs_gpu'] == 0
+    assert line['config4']['frames_read_ok_batch0'] >= 60
