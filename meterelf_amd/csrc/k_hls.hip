@@ -410,7 +410,7 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
 template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */>
 __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const uint8_t* __restrict__ frames, int n, int H, int W, int hue_shift, Bounds B,
-    const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB)
+    const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB, int plain_store)
 {
     constexpr bool PREFETCH = PD > 0;
     constexpr bool AMB = VAR == 4;
@@ -547,7 +547,9 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                     o.y = *(const uint32_t*)((const char*)expand4 + ((h16 >> 2) & 0x3cu));
                     o.z = *(const uint32_t*)((const char*)expand4 + ((h16 >> 6) & 0x3cu));
                     o.w = *(const uint32_t*)((const char*)expand4 + ((h16 >> 10) & 0x3cu));
-                    __builtin_nontemporal_store(o, (u32x4*)(out + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tg)));
+                    u32x4* dstp = (u32x4*)(out + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tg));
+                    if (plain_store) *dstp = o;
+                    else __builtin_nontemporal_store(o, dstp);
                 }
             }
             // no barrier needed here: the rings (NB >= 2*RC + 4 rows) keep this pass's rows apart
@@ -612,7 +614,9 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     while (NB < 2 * RC + 4) NB <<= 1;
     const int per_cu = WPS * 256 / T;          // resident workgroups per CU
     const int target = 256 * (per_cu < 1 ? 1 : per_cu);
-    int segs = (target + n - 1) / n;
+    static const int seg_mult = getenv("MELF_FUSED_SEGMULT") ? atoi(getenv("MELF_FUSED_SEGMULT")) : 1;  // experiments
+    static const int plain_store = getenv("MELF_FUSED_PLAINSTORE") ? atoi(getenv("MELF_FUSED_PLAINSTORE")) : 0;
+    int segs = (target * seg_mult + n - 1) / n;
     int seg_rows = (H + segs - 1) / segs;
     if (seg_rows < 32) seg_rows = H < 32 ? H : 32;
     segs = (H + seg_rows - 1) / seg_rows;
@@ -622,10 +626,15 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+        if (getenv("MELF_FUSED_TRACE")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fused_mask_lut<V, T, PF, WPS>, T, shmem);
+            fprintf(stderr, "[melf fused] V=%d T=%d PD=%d WPS=%d grid=%d shmem=%zu resident blocks/CU=%d\n", V, T, PF, WPS, grid, shmem, nb);
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, d_frames, n, H, W, hue_shift,
-                       B, d_tables, d_masks, segs, seg_rows, NB);
+                       B, d_tables, d_masks, segs, seg_rows, NB, plain_store);
 }
 
 template <int V>
@@ -637,6 +646,8 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
             case 1: launch_lut_t<V, 512, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 3: launch_lut_t<V, 1024, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 4: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 5: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             default: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         }
     } else {
@@ -662,7 +673,7 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
     for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
     static bool env_read = false;
     if (!env_read) {
-        if (const char* e = getenv("MELF_FUSED_CONFIG")) g_fused_config = atoi(e) & 3;
+        if (const char* e = getenv("MELF_FUSED_CONFIG")) g_fused_config = atoi(e) & 7;
         env_read = true;
     }
     switch (variant) {

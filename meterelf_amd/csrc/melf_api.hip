@@ -244,6 +244,13 @@ struct melf_ctx {
     size_t results_cap = 0;
     uint8_t* d_stage_in = nullptr;
     size_t stage_in_cap = 0;
+    // host-fed path (melf_process_batch): two pinned staging buffers, a copy stream and the packed crops in HBM
+    uint8_t* h_pin[2] = {nullptr, nullptr};
+    size_t pin_cap[2] = {0, 0};
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    uint8_t* d_crops = nullptr;
+    size_t crops_cap = 0;
     uint8_t* d_stage_out = nullptr;
     size_t stage_out_cap = 0;
     JpegWorkspace* jpeg = nullptr;     // created by the first JPEG batch
@@ -487,6 +494,12 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     if (c->ev_order) hipEventDestroy(c->ev_order);
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
+    hipFree(c->d_crops);
+    for (int b = 0; b < 2; ++b) {
+        if (c->h_pin[b]) hipHostFree(c->h_pin[b]);
+        if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]);
+    }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     jpeg_workspace_free(c->jpeg);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -546,8 +559,10 @@ extern "C" int melf_ctx_timings(melf_ctx* c, double ms[MELF_K_COUNT], int64_t la
 // ------------------------------------------------------------ full path ----
 static const int MAX_FRAMES_PER_LAUNCH = 32768;
 
+// rect (optional): {x0, y0, x1, y1} of the meter crop inside the H x W frames instead of the context's meter_rect
+// (the host-fed path uploads only the crop: its "frames" are the crops themselves)
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
-                            void* d_results, melf_result* out_host, hipStream_t st);
+                            void* d_results, melf_result* out_host, hipStream_t st, const int* rect = nullptr);
 
 extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
                                       void* d_results, melf_result* out_host, void* stream_)
@@ -564,12 +579,14 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
 }
 
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
-                            void* d_results, melf_result* out_host, hipStream_t st)
+                            void* d_results, melf_result* out_host, hipStream_t st, const int* rect)
 {
     const melf_params& P = c->P;
     // numpy slicing img[y0:y1, x0:x1] clamps to the image (meterelf/_image.py:54-55)
-    const int x0 = P.rect_x0 < W ? P.rect_x0 : W, x1 = P.rect_x1 < W ? P.rect_x1 : W;
-    const int y0 = P.rect_y0 < H ? P.rect_y0 : H, y1 = P.rect_y1 < H ? P.rect_y1 : H;
+    const int rx0 = rect ? rect[0] : P.rect_x0, ry0 = rect ? rect[1] : P.rect_y0;
+    const int rx1 = rect ? rect[2] : P.rect_x1, ry1 = rect ? rect[3] : P.rect_y1;
+    const int x0 = rx0 < W ? rx0 : W, x1 = rx1 < W ? rx1 : W;
+    const int y0 = ry0 < H ? ry0 : H, y1 = ry1 < H ? ry1 : H;
     const int crows = y1 - y0, ccols = x1 - x0;
     if (x0 < 0 || y0 < 0 || crows < P.th || ccols < P.tw)
         return fail(MELF_ERR_INVALID, "meter_rect crop is smaller than the dials template (cv2.matchTemplate would assert)");
@@ -696,18 +713,67 @@ extern "C" int melf_process_stream_dev(melf_ctx* c, const void* d_frames, int nb
     return rc;
 }
 
+// Frames in HOST memory (the reference's get_bgr_image + _crop_meter, meterelf/_image.py:46-55): the path only ever
+// reads the meter_rect crop, so only the crop crosses PCIe -- 187 500 of a 640x480 frame's 921 600 bytes.  Chunks of
+// frames are packed (on the host pool's threads) into one of two pinned staging buffers, copied by DMA on a copy
+// stream and processed on the context's stream, so that packing chunk k+1, the copy of chunk k and the kernels of
+// chunk k-1 overlap.  The kernels see the crops as frames of crop size with the rect at the origin.
 extern "C" int melf_process_batch(melf_ctx* c, const uint8_t* frames_host, int n, int H, int W, size_t frame_stride,
                                   melf_result* out_host)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
     if (n == 0) return MELF_SUCCESS;
-    if (!frames_host || !out_host || n < 0) return fail(MELF_ERR_INVALID, "bad argument");
+    if (!frames_host || !out_host || n < 0 || H <= 0 || W <= 0) return fail(MELF_ERR_INVALID, "bad argument");
     if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bytes = (size_t)n * frame_stride;
-    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_stage_in, frames_host, bytes, hipMemcpyHostToDevice, c->stream));
-    return melf_process_batch_dev(c, c->d_stage_in, n, H, W, frame_stride, nullptr, out_host, c->stream);
+    const melf_params& P = c->P;
+    const int x0 = P.rect_x0 < W ? P.rect_x0 : W, x1 = P.rect_x1 < W ? P.rect_x1 : W;
+    const int y0 = P.rect_y0 < H ? P.rect_y0 : H, y1 = P.rect_y1 < H ? P.rect_y1 : H;
+    const int crows = y1 - y0, ccols = x1 - x0;
+    if (x0 < 0 || y0 < 0 || crows < P.th || ccols < P.tw)
+        return fail(MELF_ERR_INVALID, "meter_rect crop is smaller than the dials template (cv2.matchTemplate would assert)");
+    const size_t row_bytes = (size_t)ccols * 3;
+    // 128 spare bytes per crop: the prep kernel's aligned 100-byte windows may reach past the last pixel
+    const size_t crop_stride = ((size_t)crows * row_bytes + 128 + 63) & ~(size_t)63;
+    const int chunk = 256;  // frames per pipeline stage (a multiple of the 32-frame MFMA group)
+    const size_t pin_need = (size_t)(n < chunk ? n : chunk) * crop_stride;
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        if (!c->ev_h2d[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming));
+        if (c->pin_cap[b] < pin_need && (b == 0 || n > chunk)) {
+            if (c->h_pin[b]) { HIP_TRY(hipStreamSynchronize(c->copy_stream)); HIP_TRY(hipHostFree(c->h_pin[b])); }
+            c->h_pin[b] = nullptr;
+            c->pin_cap[b] = 0;
+            HIP_TRY(hipHostMalloc((void**)&c->h_pin[b], pin_need, hipHostMallocDefault));
+            c->pin_cap[b] = pin_need;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's kernels may still read d_crops
+    if (int rc = grow(&c->d_crops, &c->crops_cap, (size_t)n * crop_stride)) return rc;
+    if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
+    if (int rc = enter_stream(c, c->stream)) return rc;
+    const int rect[4] = {0, 0, ccols, crows};
+    int k = 0;
+    for (int f0 = 0; f0 < n; f0 += chunk, ++k) {
+        const int m = n - f0 < chunk ? n - f0 : chunk;
+        const int b = k & 1;
+        if (k >= 2) HIP_TRY(hipEventSynchronize(c->ev_h2d[b]));  // the copy that last read this staging buffer is done
+        uint8_t* pin = c->h_pin[b];
+        host_pool().run(m, [&](int i) {
+            const uint8_t* src = frames_host + (size_t)(f0 + i) * frame_stride + ((size_t)y0 * W + x0) * 3;
+            uint8_t* dst = pin + (size_t)i * crop_stride;
+            for (int y = 0; y < crows; ++y) memcpy(dst + (size_t)y * row_bytes, src + (size_t)y * W * 3, row_bytes);
+        });
+        uint8_t* d_chunk = c->d_crops + (size_t)f0 * crop_stride;
+        HIP_TRY(hipMemcpyAsync(d_chunk, pin, (size_t)m * crop_stride, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->ev_h2d[b], c->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
+        if (int rc = process_batch_on(c, d_chunk, m, crows, ccols, crop_stride, c->d_results + f0, nullptr, c->stream, rect))
+            return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_results, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MELF_SUCCESS;
 }
 
 // ---------------------------------------------------------- stage entries ----

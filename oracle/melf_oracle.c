@@ -79,13 +79,37 @@ typedef struct {
 /* reference: meterelf/_utils.py:100-102                                */
 /* ------------------------------------------------------------------ */
 
-static int g_hls_variant = 0;
-ORC_API void orc_set_hls_variant(int v) { g_hls_variant = v; }
+/* Sensitivity audit (tests/test_oracle_sensitivity.py): every OpenCV semantic this restatement had to
+ * BELIEVE (OpenCV is absent) can be flipped to its plausible alternative, so that a test can
+ * count how many of the reference's 304 golden lines notice.  Value 0 is always the restatement proper. */
+enum {
+    ORC_OPT_HLS_VARIANT = 0,   /* 1: every pixel through the scalar-tail S formula, 2: every pixel through the SIMD form */
+    ORC_OPT_CONTOUR_TIE = 1,   /* 1: among equal contour areas the LAST discovered wins                              */
+    ORC_OPT_MEAN_FORM = 2,     /* 1: cv::mean as sum / N instead of sum * (1. / N) (dial colour and template mean)   */
+    ORC_OPT_HLS_ROUND = 3,     /* 1: round half away from zero instead of cvRound's half-to-even                     */
+    ORC_OPT_AREA_RULE = 4,     /* 1: contourArea = pixel count of the filled contour instead of the polygon area     */
+    ORC_OPT_NO_HOLE_FILL = 5,  /* 1: drawContours(-1) paints the component only, holes stay open                     */
+    ORC_OPT_ERODE_BORDER = 6,  /* 1: erode sees zeros outside the image instead of the neutral default border        */
+    ORC_OPT_L_INTEGER = 7,     /* 1: L = (max + min + 1) >> 1 instead of the float32 path                            */
+    ORC_OPT_MINMAX_LAST = 8,   /* 1: minMaxLoc returns the last maximum in raster order instead of the first         */
+    ORC_OPT_HUE_G_FIRST = 9,   /* 1: the hue sector test tries vmax == g before vmax == r                            */
+    ORC_OPT_COUNT = 10
+};
+static int g_opt[ORC_OPT_COUNT];
+#define g_hls_variant (g_opt[ORC_OPT_HLS_VARIANT])
+ORC_API void orc_set_hls_variant(int v) { g_opt[ORC_OPT_HLS_VARIANT] = v; }
+ORC_API int orc_set_option(int key, int value)
+{
+    if (key < 0 || key >= ORC_OPT_COUNT) return -1;
+    g_opt[key] = value;
+    return 0;
+}
+ORC_API int orc_option_count(void) { return ORC_OPT_COUNT; }
 
 static inline uint8_t sat_u8_rne(float v)
 {
     /* cvRound (SSE2 cvtss2si, round-half-even) then saturate_cast<uchar> */
-    long r = lrintf(v);
+    long r = g_opt[ORC_OPT_HLS_ROUND] ? (long)floorf(v + 0.5f) : lrintf(v);
     return (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
 }
 
@@ -113,7 +137,9 @@ static inline void hls_pixel(uint8_t b8, uint8_t g8, uint8_t r8, int scalar_tail
         else
             s = diff / (l < 0.5f ? sum : 2.0f - sum);
         float k = 60.f / diff;
-        if (vmax == r)
+        if (g_opt[ORC_OPT_HUE_G_FIRST] && vmax == g)
+            h = (b - r) * k + 120.f;
+        else if (vmax == r)
             h = (g - b) * k + (g < b ? 360.f : 0.f);
         else if (vmax == g)
             h = (b - r) * k + 120.f;
@@ -124,6 +150,11 @@ static inline void hls_pixel(uint8_t b8, uint8_t g8, uint8_t r8, int scalar_tail
     *H = sat_u8_rne(h * hscale);
     *L = sat_u8_rne(l * 255.f);
     *S = sat_u8_rne(s * 255.f);
+    if (g_opt[ORC_OPT_L_INTEGER]) {
+        int mx8 = r8 > g8 ? (r8 > b8 ? r8 : b8) : (g8 > b8 ? g8 : b8);
+        int mn8 = r8 < g8 ? (r8 < b8 ? r8 : b8) : (g8 < b8 ? g8 : b8);
+        *L = (uint8_t)((mx8 + mn8 + 1) >> 1);
+    }
 }
 
 /* OpenCV converts row by row, each row in blocks of 256 px; within a block the
@@ -170,7 +201,7 @@ ORC_API void orc_match_ccoeff(const uint8_t* img, int rows, int cols, long strid
     int rh = rows - th + 1, rw = cols - tw + 1;
     long tsum = 0;
     for (int i = 0; i < th * tw; ++i) tsum += tpl[i];
-    double tmean = (double)tsum * (1.0 / ((double)th * tw));
+    double tmean = g_opt[ORC_OPT_MEAN_FORM] ? (double)tsum / ((double)th * tw) : (double)tsum * (1.0 / ((double)th * tw));
 
     /* integral image for window sums (exact) */
     long* integ = (long*)calloc((size_t)(rows + 1) * (cols + 1), sizeof(long));
@@ -203,7 +234,7 @@ ORC_API void orc_match_ccoeff(const uint8_t* img, int rows, int cols, long strid
             float r = (float)num;
             if (result) result[(long)y * rw + x] = r;
             /* minMaxLoc: strict > in raster order => first maximum */
-            if (bx < 0 || r > best) { best = r; bx = x; by = y; }
+            if (bx < 0 || r > best || (g_opt[ORC_OPT_MINMAX_LAST] && r == best)) { best = r; bx = x; by = y; }
         }
     }
     free(acc);
@@ -326,7 +357,10 @@ static void morph3(const uint8_t* in, int rows, int cols, int is_dilate, uint8_t
             for (int dy = -1; dy <= 1; ++dy)
                 for (int dx = -1; dx <= 1; ++dx) {
                     int yy = y + dy, xx = x + dx;
-                    if (yy < 0 || yy >= rows || xx < 0 || xx >= cols) continue;
+                    if (yy < 0 || yy >= rows || xx < 0 || xx >= cols) {
+                        if (!is_dilate && g_opt[ORC_OPT_ERODE_BORDER]) v = 0;
+                        continue;
+                    }
                     int q = in[(long)yy * cols + xx];
                     if (is_dilate ? q > v : q < v) v = q;
                 }
@@ -506,7 +540,9 @@ static void fill_external_contour(const uint8_t* bin, int rows, int cols, int st
         }
     }
     for (int y = 0; y < rows; ++y)
-        for (int x = 0; x < cols; ++x) out[(long)y * cols + x] = outside[(y + 1) * W + x + 1] ? 0 : 255;
+        for (int x = 0; x < cols; ++x)
+            out[(long)y * cols + x] = g_opt[ORC_OPT_NO_HOLE_FILL] ? (comp[(long)y * cols + x] ? 255 : 0)
+                                                                  : (outside[(y + 1) * W + x + 1] ? 0 : 255);
     free(outside);
     free(stack);
     free(comp);
@@ -534,9 +570,19 @@ ORC_API int orc_largest_contour(const uint8_t* bin, int rows, int cols, double* 
     /* python: sorted(contours, key=contourArea)[-1]; cv2 lists contours in
      * reverse discovery order and sorted() is stable, so among equal areas the
      * earliest discovered (raster-first) wins */
+    if (g_opt[ORC_OPT_AREA_RULE]) { /* audit: area = number of pixels the filled contour paints */
+        uint8_t* tmp = (uint8_t*)malloc((size_t)rows * cols);
+        for (int k = 0; k < n && k < cap; ++k) {
+            fill_external_contour(bin, rows, cols, recs[k].start, tmp);
+            long cnt = 0;
+            for (long q = 0; q < (long)rows * cols; ++q) cnt += tmp[q] != 0;
+            recs[k].area = (double)cnt;
+        }
+        free(tmp);
+    }
     int best = 0;
     for (int k = 1; k < n; ++k)
-        if (recs[k].area > recs[best].area) best = k;
+        if (recs[k].area > recs[best].area || (g_opt[ORC_OPT_CONTOUR_TIE] && recs[k].area == recs[best].area)) best = k;
     *area = recs[best].area;
     if (filled) fill_external_contour(bin, rows, cols, recs[best].start, filled);
     free(recs);
@@ -623,7 +669,7 @@ static int read_one_dial(const uint8_t* dials_hls, int th, int tw, const orc_dia
         }
     int col[3];
     for (int c = 0; c < 3; ++c) {
-        double mean = cnt ? sum[c] * (1.0 / cnt) : 0.0; /* cv::mean: sum * (1./N) */
+        double mean = cnt ? (g_opt[ORC_OPT_MEAN_FORM] ? sum[c] / cnt : sum[c] * (1.0 / cnt)) : 0.0; /* cv::mean: sum * (1./N) */
         col[c] = (int)py_round(mean);
         res->dial_color[d][c] = col[c];
     }

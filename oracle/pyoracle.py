@@ -91,6 +91,17 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# audit switches of melf_oracle.c (ORC_OPT_*): value 0 is the restatement proper
+OPTIONS = ['hls_variant', 'contour_tie', 'mean_form', 'hls_round', 'area_rule', 'no_hole_fill', 'erode_border',
+           'l_integer', 'minmax_last', 'hue_g_first']
+
+
+def set_option(name, value):
+    L = lib()
+    assert L.orc_option_count() == len(OPTIONS)
+    assert L.orc_set_option(OPTIONS.index(name), int(value)) == 0
+
+
 class Params:
     """Independent restatement of meterelf/_params.py:30-81 (fields the hot
     path needs).  PyYAML here is 6.x, so SafeLoader is given explicitly."""

@@ -675,3 +675,32 @@ def test_stream_of_batches_matches_single_calls(env):
     finally:
         hip.hipFree(d_frames)
         hip.hipFree(d_res)
+
+
+def test_host_fed_batches_crop_upload(env):
+    """melf_process_batch uploads only the meter_rect crop, in 256-frame chunks through two pinned staging buffers:
+    600 frames = three chunks (the third re-uses the first buffer), a ragged last chunk, against the oracle and against
+    the same frames processed from HBM (melf_process_batch_dev on whole frames)."""
+    import ctypes as C
+    from meterelf_amd import _hip
+    from oracle import pyoracle as po
+    e = env['sample-images2']
+    frames = synth_frames(_good(e['files']), 600, 77)
+    ctx = e['reader'].ctx
+    recs = ctx.process_batch(frames)
+    ores = po.process_frames(frames, e['oparams'])
+    _compare_records(recs, ores, tag='host-fed')
+    assert sum(int(r['status']) == 0 for r in recs) > 550
+    hip = C.CDLL('libamdhip64.so')
+    d_frames = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_frames), C.c_size_t(frames.nbytes)) == 0
+    try:
+        assert hip.hipMemcpy(d_frames, frames.ctypes.data_as(C.c_void_p), C.c_size_t(frames.nbytes), 1) == 0
+        (n, H, W) = frames.shape[:3]
+        dev = ctx.process_batch_dev(d_frames.value, n, H, W)
+        assert dev.tobytes() == recs.tobytes()
+    finally:
+        hip.hipFree(d_frames)
+    # a second, smaller call re-uses the staging buffers
+    again = ctx.process_batch(frames[5:40])
+    assert again.tobytes() == recs[5:40].tobytes()

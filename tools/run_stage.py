@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--sample-dir', default='sample-images1')
     ap.add_argument('--hw', default='480x640', help='fused stage: frame rows x columns')
+    ap.add_argument('--nbuf', type=int, default=4, help='distinct buffer sets the launches rotate over (beyond the Infinity Cache)')
     a = ap.parse_args()
     import torch
     from meterelf_amd import _engine, _hip, _params
@@ -33,15 +34,20 @@ def main():
     if a.stage == 'fused':
         B = a.batch or 256
         (H, W) = (int(v) for v in a.hw.split('x'))
-        frames = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=dev, generator=g)
-        masks = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        NB = max(1, a.nbuf)
+        frames = torch.randint(0, 256, (NB * B, H, W, 3), dtype=torch.uint8, device=dev, generator=g)
+        masks = torch.empty((NB * B, H, W), dtype=torch.uint8, device=dev)
+
+        def launch(i):
+            b = i % NB
+            ctx.hls_inrange_close_dev(frames.data_ptr() + b * B * H * W * 3, B, H, W, masks.data_ptr() + b * B * H * W, stream=stream)
         ctx.set_profiling(False)
-        for _ in range(10):  # untimed warm-up launches
-            ctx.hls_inrange_close_dev(frames.data_ptr(), B, H, W, masks.data_ptr(), stream=stream)
+        for i in range(10):  # untimed warm-up launches
+            launch(i)
         torch.cuda.synchronize()
         ctx.set_profiling(True)
-        for _ in range(a.iters):
-            ctx.hls_inrange_close_dev(frames.data_ptr(), B, H, W, masks.data_ptr(), stream=stream)
+        for i in range(a.iters):
+            launch(i)
         torch.cuda.synchronize()
     else:
         import bench
@@ -52,10 +58,11 @@ def main():
         files = [f for f in sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', a.sample_dir, '*.jpg')))
                  if os.path.basename(f) not in bench.REJECTED]
         base = np.stack([imread_bgr(f) for f in files if imread_bgr(f).shape == imread_bgr(files[0]).shape])
-        frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), B, 2024, dev)
+        NB = max(1, a.nbuf)
+        frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), NB * B, 2024, dev)
         (H, W) = base.shape[1:3]
-        for _ in range(a.iters):
-            ctx.process_batch_dev(frames.data_ptr(), B, H, W, want_host=True, stream=stream)
+        for i in range(a.iters):
+            ctx.process_batch_dev(frames.data_ptr() + (i % NB) * B * H * W * 3, B, H, W, want_host=True, stream=stream)
     t = ctx.timings()
     for (k, (ms, n)) in t.items():
         if n:
