@@ -599,11 +599,14 @@ bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W)
 }
 
 // launch configuration (MELF_FUSED_CONFIG=0..3 for experiments):
-//   0: 512 threads, 3 workgroups/CU (6 waves/SIMD, <= 80 VGPRs), no prefetch   [default]
+//   0: 512 threads, 3 workgroups/CU (6 waves/SIMD, <= 80 VGPRs), no prefetch   [default of the bit-table variants]
+//   4: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), register prefetch [default of the interval-table
+//      variants: with the launches rotating over buffers beyond the Infinity Cache it is 3-10 % faster than 2 x 512
+//      threads x 4 waves/SIMD, which was the fastest while the working set sat in the cache]
 //   1: 512 threads, 2 workgroups/CU (4 waves/SIMD), register prefetch
 //   2: 1024 threads, 1-2 workgroups/CU (4 waves/SIMD), register prefetch
 //   3: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), no prefetch
-static int g_fused_config = 0;
+static int g_fused_config = -1;  // -1: per-variant default
 
 template <int V, int T, int PF, int WPS>
 static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
@@ -648,7 +651,8 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
             case 3: launch_lut_t<V, 1024, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 4: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 5: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            default: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 0: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            default: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         }
     } else {
         switch (g_fused_config) {

@@ -24,6 +24,8 @@
 // B lane l = B[16 (l >> 5) + j][l & 31], D lane l reg r = D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
 #include <limits.h>
 
+#include <algorithm>
+
 #include "melf_device.h"
 #include <hip/hip_ext.h>
 
@@ -49,90 +51,102 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 
 template <bool FROM_BGR>
-__global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw,
+__global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw, int rwp,
                                                      int8_t* __restrict__ Lg, uint16_t* __restrict__ R)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[8 * 2 * 32 * 4];  // [kb][h][n][16 B]
-    __shared__ int16_t pre[32][256 + 8];                                    // inclusive prefix of L' per frame
+    __shared__ __attribute__((aligned(16))) uint32_t tile[8 * 2 * 32 * 4];  // [kb][h][n][16 B], one chunk of 8 blocks
+    extern __shared__ int16_t pre_dyn[];                                    // [32][nkb * 32 + 8]: inclusive prefix of L' per frame (mod 2^16)
+    const int pstride = nkb * 32 + 8;
     const int y = blockIdx.x, grp = blockIdx.y;
-    const int t = threadIdx.x, n = t >> 3, kb = t & 7;
+    const int t = threadIdx.x, n = t >> 3, kl = t & 7;
     const int f = grp * 32 + n;
-    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 32 output bytes (L' = 0 <=> pad)
-    const bool live = kb < nkb && f < nframes && y < src.rows;  // uniform per wave except the ragged batch tail
-    if (live) {
-        const uint8_t* prow = src.base + (size_t)f * src.frame_stride + (size_t)(src.y0 + y) * src.row_stride;
-        const int xbeg = kb * 32;
-        const int npx = min(32, src.cols - xbeg);  // < 32 only in the last block: masked below, not branched on
-        if (FROM_BGR) {
-            const size_t o = (size_t)(src.x0 + xbeg) * 3;
-            const uint8_t* p = prow + o;
-            const int mis = (int)((size_t)p & 3);
-            // 25 aligned dwords cover the 96 bytes of 32 pixels at any byte alignment; the window may
-            // reach past the crop (never used: masked) but must stay inside the frame buffer
-            if ((size_t)(src.y0 + y) * src.row_stride + o + 100 <= src.frame_stride) {
-                const uint32_t* q = (const uint32_t*)(p - mis);
-                uint32_t d[25];
-#pragma unroll
-                for (int i = 0; i < 25; ++i) d[i] = q[i];
-                uint32_t a[24];
-#pragma unroll
-                for (int i = 0; i < 24; ++i) a[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], (uint32_t)mis * 8u);
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const int j = (3 * k) >> 2, sh = ((3 * k) & 3) * 8;
-                    const uint32_t px = sh <= 8 ? (a[j] >> sh) : __builtin_amdgcn_alignbit(a[j + 1 < 24 ? j + 1 : 23], a[j], sh);
-                    const int L = hls_lightness(px & 255, (px >> 8) & 255, (px >> 16) & 255);
-                    const uint32_t v = k < npx ? (uint32_t)((L - 128) & 255) : 0u;
-                    w[k >> 2] |= v << ((k & 3) * 8);
-                }
-            } else {  // last bytes of the frame buffer: byte loads
-                for (int k = 0; k < npx; ++k) {
-                    const int L = hls_lightness(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
-                    w[k >> 2] |= (uint32_t)((L - 128) & 255) << ((k & 3) * 8);
-                }
-            }
-        } else {
-            const uint8_t* p = prow + src.x0 + xbeg;
-            for (int k = 0; k < npx; ++k) w[k >> 2] |= (uint32_t)(((int)p[k] - 128) & 255) << ((k & 3) * 8);
-        }
-    }
-    // fragment-order image of the row
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
-        *(u32x4m*)(tile + ((kb * 2 + h) * 32 + n) * 4) = v;
-    }
-    // inclusive prefix sums of L' along the row: 32 local sums, then a scan over the frame's 8 lanes
-    int loc[32];
-    int run = 0;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        run += (int)(int8_t)((w[k >> 2] >> ((k & 3) * 8)) & 255u);
-        loc[k] = run;
-    }
-    int off = run;  // inclusive scan of block totals over lanes with equal t >> 3
-#pragma unroll
-    for (int dlt = 1; dlt < 8; dlt <<= 1) {
-        const int o2 = __shfl_up(off, dlt, 8);
-        if (kb >= dlt) off += o2;
-    }
-    off -= run;  // exclusive
-#pragma unroll
-    for (int k = 0; k < 32; k += 2) {
-        const uint32_t two = (uint32_t)((loc[k] + off) & 0xffff) | ((uint32_t)((loc[k + 1] + off) & 0xffff) << 16);
-        *(uint32_t*)&pre[n][kb * 32 + k] = two;
-    }
-    __syncthreads();
-    const int row_dwords = nkb * 256;
+    int carry = 0;  // prefix of the blocks before this chunk (per frame, same in its 8 lanes)
     u32x4m* out = (u32x4m*)(Lg + ((size_t)grp * rows_pad + y) * (size_t)nkb * 1024);
-    for (int i = t; i < row_dwords / 4; i += 256) out[i] = *(const u32x4m*)(tile + i * 4);
-    // window sums: R[x] = P[x + tw - 1] - P[x - 1] + 128 tw   (P = inclusive prefix of L - 128)
+    for (int kc = 0; kc < nkb; kc += 8) {
+        const int kb = kc + kl;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 32 output bytes (L' = 0 <=> pad)
+        const bool live = kb < nkb && f < nframes && y < src.rows && kb * 32 < src.cols;  // uniform per wave except ragged tails
+        if (live) {
+            const uint8_t* prow = src.base + (size_t)f * src.frame_stride + (size_t)(src.y0 + y) * src.row_stride;
+            const int xbeg = kb * 32;
+            const int npx = min(32, src.cols - xbeg);  // < 32 only in the last block: masked below, not branched on
+            if (FROM_BGR) {
+                const size_t o = (size_t)(src.x0 + xbeg) * 3;
+                const uint8_t* p = prow + o;
+                const int mis = (int)((size_t)p & 3);
+                // 25 aligned dwords cover the 96 bytes of 32 pixels at any byte alignment; the window may
+                // reach past the crop (never used: masked) but must stay inside the frame buffer
+                if ((size_t)(src.y0 + y) * src.row_stride + o + 100 <= src.frame_stride) {
+                    const uint32_t* q = (const uint32_t*)(p - mis);
+                    uint32_t d[25];
+#pragma unroll
+                    for (int i = 0; i < 25; ++i) d[i] = q[i];
+                    uint32_t a[24];
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) a[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], (uint32_t)mis * 8u);
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {
+                        const int j = (3 * k) >> 2, sh = ((3 * k) & 3) * 8;
+                        const uint32_t px = sh <= 8 ? (a[j] >> sh) : __builtin_amdgcn_alignbit(a[j + 1 < 24 ? j + 1 : 23], a[j], sh);
+                        const int L = hls_lightness(px & 255, (px >> 8) & 255, (px >> 16) & 255);
+                        const uint32_t v = k < npx ? (uint32_t)((L - 128) & 255) : 0u;
+                        w[k >> 2] |= v << ((k & 3) * 8);
+                    }
+                } else {  // last bytes of the frame buffer: byte loads
+                    for (int k = 0; k < npx; ++k) {
+                        const int L = hls_lightness(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+                        w[k >> 2] |= (uint32_t)((L - 128) & 255) << ((k & 3) * 8);
+                    }
+                }
+            } else {
+                const uint8_t* p = prow + src.x0 + xbeg;
+                for (int k = 0; k < npx; ++k) w[k >> 2] |= (uint32_t)(((int)p[k] - 128) & 255) << ((k & 3) * 8);
+            }
+        }
+        if (kc) __syncthreads();  // the previous chunk's tile has been written out
+        // fragment-order image of the row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
+            *(u32x4m*)(tile + ((kl * 2 + h) * 32 + n) * 4) = v;
+        }
+        // inclusive prefix sums of L' along the row: 32 local sums, then a scan over the frame's 8 lanes
+        int loc[32];
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            run += (int)(int8_t)((w[k >> 2] >> ((k & 3) * 8)) & 255u);
+            loc[k] = run;
+        }
+        int off = run;  // inclusive scan of block totals over lanes with equal t >> 3
+#pragma unroll
+        for (int dlt = 1; dlt < 8; dlt <<= 1) {
+            const int o2 = __shfl_up(off, dlt, 8);
+            if (kl >= dlt) off += o2;
+        }
+        const int chunk_total = __shfl(off, 7, 8);
+        off += carry - run;  // exclusive, including the earlier chunks
+        carry += chunk_total;
+        if (kb < nkb) {
+#pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                const uint32_t two = (uint32_t)((loc[k] + off) & 0xffff) | ((uint32_t)((loc[k + 1] + off) & 0xffff) << 16);
+                *(uint32_t*)&pre_dyn[n * pstride + kb * 32 + k] = two;
+            }
+        }
+        __syncthreads();
+        const int nb = min(8, nkb - kc);
+        for (int i = t; i < nb * 64; i += 256) out[kc * 64 + i] = *(const u32x4m*)(tile + i * 4);
+    }
+    // window sums: R[x] = P[x + tw - 1] - P[x - 1] + 128 tw   (P = inclusive prefix of L - 128, modulo 2^16:
+    // the window sum itself is below 2^16 for tw <= 257)
     if (y < src.rows) {
-        uint16_t* ro = R + (((size_t)grp * src.rows + y) * 64) * 32;
+        uint16_t* ro = R + (((size_t)grp * src.rows + y) * rwp) * 32;
         const int bias = tw * 128;
-        for (int e = t; e < 64 * 32; e += 256) {
+        const int pmax = nkb * 32 - 1;
+        for (int e = t; e < rwp * 32; e += 256) {
             const int x = e >> 5, nn = e & 31;
-            const int hi = (int)pre[nn][x + tw - 1], lo = x > 0 ? (int)pre[nn][x - 1] : 0;
+            const int hi = (int)pre_dyn[nn * pstride + min(x + tw - 1, pmax)], lo = x > 0 ? (int)pre_dyn[nn * pstride + min(x - 1, pmax)] : 0;
             ro[e] = (uint16_t)(hi - lo + bias);
         }
     }
@@ -140,24 +154,35 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
 
 // ---------------------------------------------------------------------------
 // k_colsum: ws[g][y][x][n] = sum_{i < th} R[g][y + i][x][n]  (u32), exact.
-// One workgroup (128 threads) per 128 (x, n) columns of a group: the 128 x `rows` tile of R is
-// fetched with coalesced, deeply pipelined loads into LDS, then every thread slides down its
-// own column.  grid = (16, groups).
+// One workgroup (128 threads) per 128 (x, n) columns of a group and per chunk of output rows: the tile of R is
+// fetched with coalesced, deeply pipelined loads into LDS, then every thread slides down its own column.
+// grid = (rwp * 32 / 128, groups, row chunks).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_colsum(const uint16_t* __restrict__ R, int rows, int th, int rh,
-                                                uint32_t* __restrict__ ws)
+__global__ __launch_bounds__(128) void k_colsum(const uint16_t* __restrict__ R, int rows, int th, int rh, int rowlen /* rwp * 32 */,
+                                                int ychunk, uint32_t* __restrict__ ws)
 {
-    extern __shared__ uint16_t col[];  // [rows][128]
+    extern __shared__ uint16_t col[];  // [rows of the chunk][128]
     const int t = threadIdx.x, grp = blockIdx.y, c0 = blockIdx.x * 128;
-    const uint16_t* r = R + (size_t)grp * rows * 2048 + c0 + t;
-    for (int y = 0; y < rows; ++y) col[y * 128 + t] = r[(size_t)y * 2048];
+    const int y0 = blockIdx.z * ychunk, y1 = min(rh, y0 + ychunk);
+    const int nin = y1 - y0 + th - 1;
+    const uint16_t* r = R + ((size_t)grp * rows + y0) * rowlen + c0 + t;
+    // sixteen independent loads in flight per thread (a loop of single loads waits for each one)
+    int y = 0;
+    for (; y + 16 <= nin; y += 16) {
+        uint16_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = r[(size_t)(y + k) * rowlen];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) col[(y + k) * 128 + t] = v[k];
+    }
+    for (; y < nin; ++y) col[y * 128 + t] = r[(size_t)y * rowlen];
     __syncthreads();
-    uint32_t* o = ws + (size_t)grp * rh * 2048 + c0 + t;
+    uint32_t* o = ws + ((size_t)grp * rh + y0) * rowlen + c0 + t;
     uint32_t s = 0;
-    for (int y = 0; y < th - 1; ++y) s += col[y * 128 + t];
-    for (int y = 0; y < rh; ++y) {
+    for (int yy = 0; yy < th - 1; ++yy) s += col[yy * 128 + t];
+    for (int y = 0; y < y1 - y0; ++y) {
         s += col[(y + th - 1) * 128 + t];
-        o[(size_t)y * 2048] = s;
+        o[(size_t)y * rowlen] = s;
         s -= col[y * 128 + t];
     }
 }
@@ -502,19 +527,35 @@ void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab)
                 }
 }
 
+void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int rh, int th, int tw,
+                       int8_t* d_lg, uint16_t* d_r, uint32_t* d_ws, hipStream_t stream)
+{
+    dim3 grid(rows_pad, groups), block(256);
+    const size_t pre_bytes = (size_t)32 * (nkb * 32 + 8) * sizeof(int16_t);
+    // row chunks of the column-sum pass: at most 96 KiB of LDS per workgroup
+    const int max_in = 96 * 1024 / 256;
+    const int ychunk = rh + th - 1 <= max_in ? rh : std::max(1, max_in - (th - 1));
+    const int nchunks = (rh + ychunk - 1) / ychunk;
+    const size_t col_bytes = (size_t)(std::min(rh, ychunk) + th - 1) * 128 * sizeof(uint16_t);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_set[64] = {false};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {  // once per device: dynamic LDS beyond the 64 KiB default
+        (void)hipFuncSetAttribute((const void*)k_colsum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set[dev] = true;
+    }
+    if (from_bgr) hipLaunchKernelGGL(k_prep_lplane<true>, grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+    else hipLaunchKernelGGL(k_prep_lplane<false>, grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+    hipLaunchKernelGGL(k_colsum, dim3(rwp * 32 / 128, groups, nchunks), dim3(128), col_bytes, stream, d_r, src.rows, th, rh, rwp * 32,
+                       ychunk, d_ws);
+}
+
 void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
                       uint16_t* d_r, uint32_t* d_ws, hipStream_t stream)
 {
-    dim3 grid(p.rows_pad, p.groups), block(256);
-    if (from_bgr) hipLaunchKernelGGL(k_prep_lplane<true>, grid, block, 0, stream, src, n, p.nkb, p.rows_pad, tw, d_lg, d_r);
-    else hipLaunchKernelGGL(k_prep_lplane<false>, grid, block, 0, stream, src, n, p.nkb, p.rows_pad, tw, d_lg, d_r);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_colsum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_colsum, dim3(16, p.groups), dim3(128), (size_t)src.rows * 128 * sizeof(uint16_t), stream, d_r,
-                       src.rows, th, p.rh, d_ws);
+    launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, p.rh, th, tw, d_lg, d_r, d_ws, stream);
 }
 
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,

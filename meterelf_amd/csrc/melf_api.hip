@@ -220,6 +220,17 @@ struct melf_ctx {
     int8_t* d_atab = nullptr;            // Toeplitz template fragments of the MFMA match (NULL: template shape unsupported)
     long tsum = 0;
     bool use_mfma = true;                // MELF_MATCH=dot4 forces the VALU kernel
+    int force_kind = -1;                 // MELF_MATCH=fast / gen: force the tuned / the general matrix-core kernel where it can run
+    // plans of the general matrix-core kernel, one per (crop shape, frame groups) seen; partial tiles and arrival
+    // counters per pipeline lane (two batches may be in flight)
+    struct GenEntry {
+        int rows, cols, groups;
+        GenPlan plan;
+        GenDev dev;
+        void* part[2] = {nullptr, nullptr};
+        int* counters[2] = {nullptr, nullptr};
+    };
+    std::vector<GenEntry*> gen_cache;
     // two pipeline lanes: a batch is split in halves that run on separate streams, so that one
     // half's VALU-bound kernels (prep, dials) overlap the other half's matrix-core-bound match
     static const int NLANES = 2;
@@ -238,8 +249,6 @@ struct melf_ctx {
     int fused_variant = 3;
     hipStream_t stream = nullptr;
     // workspaces (grown on demand)
-    MatchPartial* d_partials = nullptr;
-    size_t partials_cap = 0;
     melf_result* d_results = nullptr;
     size_t results_cap = 0;
     uint8_t* d_stage_in = nullptr;
@@ -339,7 +348,11 @@ static int setup_device_tables(melf_ctx* c)
         HIP_TRY(hipMalloc((void**)&c->d_atab, atab.size()));
         HIP_TRY(hipMemcpy(c->d_atab, atab.data(), atab.size(), hipMemcpyHostToDevice));
     }
-    if (const char* e = getenv("MELF_MATCH")) c->use_mfma = strcmp(e, "dot4") != 0;
+    if (const char* e = getenv("MELF_MATCH")) {
+        c->use_mfma = strcmp(e, "dot4") != 0;
+        if (!strcmp(e, "fast")) c->force_kind = 1;
+        if (!strcmp(e, "gen")) c->force_kind = 2;
+    }
     std::vector<uint32_t> tplT((size_t)g.tw4 * g.trows, 0u);
     for (int i = 0; i < th; ++i)
         for (int jj = 0; jj < g.tw4; ++jj) {
@@ -485,6 +498,11 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     hipFree(c->d_atab);
+    for (auto* ge : c->gen_cache) {
+        hipFree(ge->dev.atab); hipFree(ge->dev.atabv); hipFree(ge->dev.tasks);
+        for (int l = 0; l < 2; ++l) { hipFree(ge->part[l]); hipFree(ge->counters[l]); }
+        delete ge;
+    }
     for (int l = 0; l < melf_ctx::NLANES; ++l) {
         hipFree(c->d_lg[l]); hipFree(c->d_rsum[l]); hipFree(c->d_wsum[l]); hipFree(c->d_lpart[l]);
         if (c->lane_stream[l]) hipStreamDestroy(c->lane_stream[l]);
@@ -493,7 +511,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_order) hipEventDestroy(c->ev_order);
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
-    hipFree(c->d_partials); hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
+    hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
     hipFree(c->d_crops);
     for (int b = 0; b < 2; ++b) {
         if (c->h_pin[b]) hipHostFree(c->h_pin[b]);
@@ -556,6 +574,136 @@ extern "C" int melf_ctx_timings(melf_ctx* c, double ms[MELF_K_COUNT], int64_t la
     return MELF_SUCCESS;
 }
 
+
+// ------------------------------------------------------------ match stage ----
+// Which kernel computes TM_CCOEFF for this shape.  The tuned matrix-core kernel (k_match_mfma) is instantiated for
+// templates of 162..193 columns and maps of up to 64 columns; it is the fastest when its 5-row waves fill the chip.
+// The general matrix-core kernel (k_match_gen) takes every other shape, and the shapes the tuned one handles badly:
+// maps too small to fill the chip (it slices the K loop across waves) and map widths a few columns past 32 (it
+// computes those columns in transposed form instead of a whole extra column block).  The VALU kernel (k_match)
+// remains for templates wider than 256 columns and as an independent formulation in the tests.
+enum { MK_DOT4 = 0, MK_FAST = 1, MK_GEN = 2 };
+static int pick_match_kind(const melf_ctx* c, int rows, int cols, int n)
+{
+    if (!c->use_mfma) return MK_DOT4;
+    const int th = c->P.th, tw = c->P.tw;
+    const bool fast_ok = c->d_atab && mfma_match_ok(th, tw, rows, cols);
+    const bool gen_ok = gen_match_ok(th, tw, rows, cols);
+    if (c->force_kind == MK_FAST && fast_ok) return MK_FAST;
+    if (c->force_kind == MK_GEN && gen_ok) return MK_GEN;
+    if (fast_ok) {
+        // measured on MI355X, map 132 x 63 (tools/gpu_check_gen.sh): tuned / general kernel 175 / 246 us at 1024 frames,
+        // 128 / 161 at 512, 72 / 87 at 256, 62 / 33 at 64; map 17 x 33 at 1024 frames: 67 / 42 us
+        const int rh = rows - th + 1, rw = cols - tw + 1, groups = (n + 31) / 32;
+        const bool few_frames = groups <= 4;                               // the tuned kernel cannot slice its K loop
+        const bool small_map = (long)((rh + 4) / 5) * groups * 2 <= 512;   // ... nor fill the chip with a small map
+        const bool odd_cols = rw > 32 && rw % 32 >= 1 && rw % 32 <= 4;     // a whole column block for <= 4 columns
+        if (!gen_ok || !(few_frames || small_map || odd_cols)) return MK_FAST;
+    }
+    return gen_ok ? MK_GEN : MK_DOT4;
+}
+
+static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry** out)
+{
+    const int groups = (n + 31) / 32;
+    for (auto* ge : c->gen_cache)
+        if (ge->rows == rows && ge->cols == cols && ge->groups == groups) { *out = ge; return MELF_SUCCESS; }
+    if (c->gen_cache.size() >= 16) {  // a caller cycling through many shapes: drop the oldest plan
+        HIP_TRY(hipDeviceSynchronize());
+        auto* old = c->gen_cache.front();
+        hipFree(old->dev.atab); hipFree(old->dev.atabv); hipFree(old->dev.tasks);
+        for (int l = 0; l < 2; ++l) { hipFree(old->part[l]); hipFree(old->counters[l]); }
+        delete old;
+        c->gen_cache.erase(c->gen_cache.begin());
+    }
+    auto* ge = new melf_ctx::GenEntry();
+    ge->rows = rows; ge->cols = cols; ge->groups = groups;
+    ge->plan = gen_plan(c->P.th, c->P.tw, rows, cols, n);
+    const GenPlan& p = ge->plan;
+    c->gen_cache.push_back(ge);
+    if (getenv("MELF_GEN_TRACE"))
+        fprintf(stderr, "[melf gen] crop %dx%d n=%d: map %dx%d nd=%d tile rows %d, %d tiles (%d V columns), %d waves per group x %d groups, partials %zu KiB\n",
+                rows, cols, n, p.rh, p.rw, p.nd, p.rc, p.ntiles, p.vcols, p.ntasks, p.groups, p.part_bytes / 1024);
+    std::vector<int8_t> atab(p.atab_bytes);
+    gen_build_atab(c->h_templ.data(), c->P.th, c->P.tw, p, atab.data());
+    HIP_TRY(hipMalloc((void**)&ge->dev.atab, atab.size()));
+    HIP_TRY(hipMemcpy(ge->dev.atab, atab.data(), atab.size(), hipMemcpyHostToDevice));
+    if (p.atabv_bytes) {
+        std::vector<int8_t> atabv(p.atabv_bytes);
+        gen_build_atabv(c->h_templ.data(), c->P.th, c->P.tw, p, atabv.data());
+        HIP_TRY(hipMalloc((void**)&ge->dev.atabv, atabv.size()));
+        HIP_TRY(hipMemcpy(ge->dev.atabv, atabv.data(), atabv.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void**)&ge->dev.tasks, p.tasks.size() * sizeof(GenTask)));
+    HIP_TRY(hipMemcpy(ge->dev.tasks, p.tasks.data(), p.tasks.size() * sizeof(GenTask), hipMemcpyHostToDevice));
+    *out = ge;
+    return MELF_SUCCESS;
+}
+
+// prep + match of m images on stream ls with lane bl's work buffers; *parts / *nparts: per-frame (max, first arg-max)
+// partials for the consumer (k_dials or the host fold of melf_match_ccoeff)
+static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int bl, hipStream_t ls, float* d_map,
+                     MatchPartial** parts, int* nparts)
+{
+    const melf_params& P = c->P;
+    const int kind = pick_match_kind(c, ms.rows, ms.cols, m);
+    TimedEvent ev;
+    ev.kernel = MELF_K_MATCH;
+    ev.start = ev.stop = nullptr;
+    if (c->profiling && kind != MK_DOT4) {  // the dispatch's own time stamps: no event-record packets around the kernel
+        HIP_TRY(hipEventCreate(&ev.start));
+        HIP_TRY(hipEventCreate(&ev.stop));
+    }
+    if (kind == MK_FAST) {
+        const MfmaPlan pl = mfma_plan(P.th, P.tw, ms.rows, ms.cols, m);
+        *nparts = pl.nparts;
+        if (int rc = grow(&c->d_lg[bl], &c->lg_cap[bl], pl.lg_bytes)) return rc;
+        if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
+        if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
+        if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.nparts)) return rc;
+        *parts = c->d_lpart[bl];
+        {
+            KernelTimer t(c, MELF_K_LPLANE, ls);
+            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ls);
+        }
+        launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls,
+                          ev.start, ev.stop);
+    } else if (kind == MK_GEN) {
+        melf_ctx::GenEntry* ge = nullptr;
+        if (int rc = gen_entry(c, ms.rows, ms.cols, m, &ge)) return rc;
+        const GenPlan& pl = ge->plan;
+        *nparts = pl.ntiles;
+        if (int rc = grow(&c->d_lg[bl], &c->lg_cap[bl], pl.lg_bytes)) return rc;
+        if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
+        if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
+        if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.ntiles)) return rc;
+        if (!ge->counters[bl]) {
+            const size_t cb = (size_t)pl.groups * pl.ntiles * sizeof(int);
+            HIP_TRY(hipMalloc((void**)&ge->counters[bl], cb));
+            HIP_TRY(hipMemsetAsync(ge->counters[bl], 0, cb, ls));
+            if (pl.part_bytes) HIP_TRY(hipMalloc(&ge->part[bl], pl.part_bytes));
+        }
+        *parts = c->d_lpart[bl];
+        {
+            KernelTimer t(c, MELF_K_LPLANE, ls);
+            launch_match_prep(ms, from_bgr, m, pl.groups, pl.rows_pad, pl.nkb, pl.rwp, pl.rh, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl],
+                              c->d_wsum[bl], ls);
+        }
+        GenDev dev = ge->dev;
+        dev.part = ge->part[bl];
+        dev.counters = ge->counters[bl];
+        launch_gen_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls, ev.start, ev.stop);
+    } else {
+        *nparts = match_parts(c->mg, ms.rows, ms.cols);
+        if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * *nparts)) return rc;
+        *parts = c->d_lpart[bl];
+        KernelTimer t(c, MELF_K_MATCH, ls);
+        launch_match(ms, from_bgr, m, c->mg, c->d_tplT, d_map, *parts, nullptr, ls);
+    }
+    if (ev.start) c->events.push_back(ev);
+    return MELF_SUCCESS;
+}
+
 // ------------------------------------------------------------ full path ----
 static const int MAX_FRAMES_PER_LAUNCH = 32768;
 
@@ -590,7 +738,7 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
     const int crows = y1 - y0, ccols = x1 - x0;
     if (x0 < 0 || y0 < 0 || crows < P.th || ccols < P.tw)
         return fail(MELF_ERR_INVALID, "meter_rect crop is smaller than the dials template (cv2.matchTemplate would assert)");
-    const bool mfma = c->use_mfma && c->d_atab && mfma_match_ok(P.th, P.tw, crows, ccols);
+    const bool mfma = pick_match_kind(c, crows, ccols, n) != MK_DOT4;
     const int rw = ccols - P.tw + 1;
     melf_result* res_dev = (melf_result*)d_results;
     if (!res_dev) {
@@ -620,37 +768,7 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
             ms.x0 = x0; ms.y0 = y0; ms.rows = crows; ms.cols = ccols;
             int nparts = 0;
             MatchPartial* parts = nullptr;
-            if (mfma) {
-                const MfmaPlan pl = mfma_plan(P.th, P.tw, crows, ccols, m);
-                nparts = pl.nparts;
-                if (int rc = grow(&c->d_lg[bl], &c->lg_cap[bl], pl.lg_bytes)) return rc;
-                if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
-                if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
-                if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * nparts)) return rc;
-                parts = c->d_lpart[bl];
-                {
-                    KernelTimer t(c, MELF_K_LPLANE, ls);
-                    launch_mfma_prep(ms, true, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ls);
-                }
-                if (c->profiling) {  // timed by the dispatch itself: no event-record packets around the kernel
-                    TimedEvent ev;
-                    ev.kernel = MELF_K_MATCH;
-                    HIP_TRY(hipEventCreate(&ev.start));
-                    HIP_TRY(hipEventCreate(&ev.stop));
-                    launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl],
-                                      nullptr, parts, ls, ev.start, ev.stop);
-                    c->events.push_back(ev);
-                } else {
-                    launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl],
-                                      nullptr, parts, ls);
-                }
-            } else {
-                nparts = match_parts(c->mg, crows, ccols);
-                if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)m * nparts)) return rc;
-                parts = c->d_partials;
-                KernelTimer t(c, MELF_K_MATCH, ls);
-                launch_match(ms, true, m, c->mg, c->d_tplT, nullptr, parts, nullptr, ls);
-            }
+            if (int rc = run_match(c, ms, true, m, bl, ls, nullptr, &parts, &nparts)) return rc;
             DialsSrc ds;
             ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = W * 3;
             ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
@@ -845,36 +963,19 @@ extern "C" int melf_match_ccoeff(melf_ctx* c, const uint8_t* images_host, int n,
     const int rh = rows - c->P.th + 1, rw = cols - c->P.tw + 1;
     const size_t in_bytes = (size_t)n * rows * cols;
     const size_t map_bytes = result_map ? (size_t)n * rh * rw * sizeof(float) : 0;
-    const bool mfma = c->use_mfma && c->d_atab && mfma_match_ok(c->P.th, c->P.tw, rows, cols);
-    MfmaPlan pl = {};
-    if (mfma) pl = mfma_plan(c->P.th, c->P.tw, rows, cols, n);
-    const int nparts = mfma ? pl.nparts : match_parts(c->mg, rows, cols);
     if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, in_bytes)) return rc;
     if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, map_bytes + 16)) return rc;
-    if (int rc = grow(&c->d_partials, &c->partials_cap, (size_t)n * nparts)) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_stage_in, images_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (int rc = enter_stream(c, c->stream)) return rc;
     MatchSrc ms;
     ms.base = c->d_stage_in; ms.frame_stride = (size_t)rows * cols; ms.row_stride = cols;
     ms.x0 = 0; ms.y0 = 0; ms.rows = rows; ms.cols = cols;
-    if (mfma) {
-        if (int rc = grow(&c->d_lg[0], &c->lg_cap[0], pl.lg_bytes)) return rc;
-        if (int rc = grow(&c->d_rsum[0], &c->rsum_cap[0], pl.r_bytes / sizeof(uint16_t))) return rc;
-        if (int rc = grow(&c->d_wsum[0], &c->wsum_cap[0], pl.ws_bytes / sizeof(uint32_t))) return rc;
-        {
-            KernelTimer t(c, MELF_K_LPLANE, c->stream);
-            launch_mfma_prep(ms, false, n, pl, c->P.th, c->P.tw, c->d_lg[0], c->d_rsum[0], c->d_wsum[0], c->stream);
-        }
-        KernelTimer t(c, MELF_K_MATCH, c->stream);
-        launch_mfma_match(n, pl, c->P.th, c->P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[0], c->d_wsum[0],
-                          result_map ? (float*)c->d_stage_out : nullptr, c->d_partials, c->stream);
-    } else {
-        KernelTimer t(c, MELF_K_MATCH, c->stream);
-        launch_match(ms, false, n, c->mg, c->d_tplT, result_map ? (float*)c->d_stage_out : nullptr, c->d_partials,
-                     nullptr, c->stream);
-    }
+    int nparts = 0;
+    MatchPartial* d_parts = nullptr;
+    if (int rc = run_match(c, ms, false, n, 0, c->stream, result_map ? (float*)c->d_stage_out : nullptr, &d_parts, &nparts)) return rc;
     HIP_TRY(hipGetLastError());
     std::vector<MatchPartial> parts((size_t)n * nparts);
-    HIP_TRY(hipMemcpyAsync(parts.data(), c->d_partials, parts.size() * sizeof(MatchPartial), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(parts.data(), d_parts, parts.size() * sizeof(MatchPartial), hipMemcpyDeviceToHost, c->stream));
     if (result_map) HIP_TRY(hipMemcpyAsync(result_map, c->d_stage_out, map_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     // fold the per-tile (max, first-argmax) pairs exactly as K3's prologue does on the device

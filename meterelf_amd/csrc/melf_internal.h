@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <vector>
 #include <stdint.h>
 
 #include "../../include/meterelf_hip.h"
@@ -57,6 +58,42 @@ void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan&
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
                        hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
+// ---- K2, general form (k_match_gen.hip): any template up to 256 columns, any map size ----
+struct GenTask {           // one wave's job
+    int16_t y0;            // first map row of the tile (V form: first of its 32 map rows)
+    int8_t R, Rc;          // map rows of the tile, rows computed (R rounded up to 2/4/6/8); R == 0: V-form tile
+    int8_t nxb;            // column blocks (1 or 2)
+    int8_t pad0;
+    int16_t xb0;           // first column block (V form: index of the remainder column)
+    int16_t tile;          // tile index inside the frame group = slot of its (max, argmax) partial
+    int16_t slice, nslices;
+    int32_t k_lo, k_hi;    // this wave's range of the tile's linearised K space
+    int32_t part_off, part_stride;  // partial-tile storage (units of 1 KiB), per-group stride
+};
+struct GenPlan {
+    int rh, rw, rwp, nd, nkb, rows_pad, groups, ntiles, ntasks, rc;
+    int vcols, vx0, vkb0, ndv, ndelta, part_stride;
+    size_t lg_bytes, r_bytes, ws_bytes, part_bytes, atab_bytes, atabv_bytes;
+    std::vector<GenTask> tasks;
+};
+struct GenDev {            // device copies that belong to one plan
+    int8_t* atab = nullptr;
+    int8_t* atabv = nullptr;
+    GenTask* tasks = nullptr;
+    void* part = nullptr;
+    int* counters = nullptr;
+};
+bool gen_match_ok(int th, int tw, int rows, int cols);
+GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes);
+void gen_build_atab(const uint8_t* templ, int th, int tw, const GenPlan& p, int8_t* atab);
+void gen_build_atabv(const uint8_t* templ, int th, int tw, const GenPlan& p, int8_t* atabv);
+void launch_gen_match(int n, const GenPlan& p, int th, int tw, long tsum, double tmean, const GenDev& dev, const int8_t* d_lg,
+                      const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials, hipStream_t stream,
+                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// prep for either matrix-core kernel: Lg (fragment order), row-window sums, window sums
+void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int rh, int th, int tw,
+                       int8_t* d_lg, uint16_t* d_r, uint32_t* d_ws, hipStream_t stream);
 
 // ---- K3: per-dial reading ---------------------------------------------------
 struct DialGeom {

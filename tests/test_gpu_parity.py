@@ -704,3 +704,97 @@ def test_host_fed_batches_crop_upload(env):
     # a second, smaller call re-uses the staging buffers
     again = ctx.process_batch(frames[5:40])
     assert again.tobytes() == recs[5:40].tobytes()
+
+
+def _reader_with_template(tmp_path, tpl):
+    """A MeterReader whose dials template is `tpl` (the match stage does not look at the dials)."""
+    import yaml
+    from PIL import Image
+    from meterelf_amd import MeterReader, _params
+    (th, tw) = tpl.shape
+    with open(os.path.join(GOLDEN, 'sample-images1', 'params.yml')) as fp:
+        data = yaml.safe_load(fp)
+    data['dials_template_size'] = [tw, th]
+    small = min(th, tw) < 52
+    for nd in data['needle_data']:
+        if small:   # dials that fit a tiny template: radius round(2 / 2) + 0 + 2 - 1 = 2
+            (nd['diameter'], nd['dist_from_center'], nd['circle_thickness']) = (2, 0, 2)
+            nd['center'] = [tw / 2.0, th / 2.0]
+        else:
+            nd['center'] = [max(min(nd['center'][0], tw - 26.0), 26.0), max(min(nd['center'][1], th - 26.0), 26.0)]
+    tmp_path.mkdir(parents=True, exist_ok=True)
+    with open(tmp_path / 'params.yml', 'w') as fp:
+        yaml.safe_dump(data, fp)
+    Image.fromarray(tpl, 'L').save(tmp_path / 'dials_gray.png')
+    return MeterReader(_params.load(str(tmp_path / 'params.yml')))
+
+
+GEN_SHAPES = [
+    # (th, tw, rows, cols, n): what the case exercises
+    (119, 188, 135, 220, 35),   # config 4: 17 x 33 map = one column block + one V-form column, K slices
+    (119, 188, 250, 250, 3),    # config 3 shape at a small batch: sliced tiles
+    (119, 188, 300, 400, 2),    # 182 x 213 map: seven column blocks in strips of two, V-form off (remainder 21)
+    (119, 188, 300, 223, 2),    # 182 x 36 map: V form with 4 remainder columns and 6 row blocks
+    (100, 170, 250, 250, 5),    # other template widths (6 Toeplitz blocks) ...
+    (90, 150, 250, 250, 5),
+    (40, 64, 250, 250, 33),     # ... a narrow one (3 blocks), 211 x 187 map, two frame groups
+    (119, 256, 200, 300, 2),    # the widest template the u16 row sums take (9 blocks)
+    (9, 11, 64, 70, 2),         # tiny template: two Toeplitz blocks per row
+    (119, 188, 119, 188, 2),    # 1 x 1 map
+    (33, 33, 96, 97, 4),        # 64 x 65: two column blocks + 1 V column, rows 64
+]
+
+
+@pytest.mark.parametrize('shape', GEN_SHAPES, ids=lambda s: 't%dx%d_i%dx%d_n%d' % s)
+def test_match_general_matrix_core_kernel(tmp_path, monkeypatch, shape):
+    """k_match_gen (any template up to 256 columns, any map, K slices, V-form remainder columns): the whole float32
+    map and minMaxLoc bit-exact against the oracle, and identical to the VALU kernel's."""
+    from oracle import pyoracle as po
+    (th, tw, rows, cols, n) = shape
+    rng = np.random.default_rng(th * 7 + tw * 3 + rows + cols + n)
+    tpl = rng.integers(0, 256, size=(th, tw), dtype=np.uint8)
+    imgs = rng.integers(0, 256, size=(n, rows, cols), dtype=np.uint8)
+    imgs[-1] = rng.choice(np.array([0, 255], np.uint8), size=(rows, cols))
+    if rows >= th + 5 and cols >= tw + 3:
+        imgs[0, 5:5 + th, 3:3 + tw] = tpl   # an exact occurrence
+    monkeypatch.setenv('MELF_MATCH', 'gen')
+    reader = _reader_with_template(tmp_path / 'gen', tpl)
+    try:
+        (mv, mx, my, rmap) = reader.ctx.match_ccoeff(imgs, want_map=True)
+        (mv2, mx2, my2, _none) = reader.ctx.match_ccoeff(imgs, want_map=False)   # a second launch: counters were reset
+    finally:
+        reader.close()
+    assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mv2.tobytes(), mx2.tobytes(), my2.tobytes())
+    monkeypatch.setenv('MELF_MATCH', 'dot4')
+    r2 = _reader_with_template(tmp_path / 'dot4', tpl)
+    try:
+        (mvd, mxd, myd, rmapd) = r2.ctx.match_ccoeff(imgs, want_map=True)
+    finally:
+        r2.close()
+    assert np.array_equal(rmap, rmapd)
+    for i in range(n):
+        (ev, ex, ey, emap) = po.match_ccoeff(imgs[i], tpl, want_map=True)
+        assert np.array_equal(rmap[i], emap), i
+        assert (float(mv[i]), int(mx[i]), int(my[i])) == (ev, ex, ey), i
+        assert (float(mvd[i]), int(mxd[i]), int(myd[i])) == (ev, ex, ey), i
+    if rows >= th + 5 and cols >= tw + 3:
+        assert (int(mx[0]), int(my[0])) == (3, 5)
+
+
+@pytest.mark.parametrize('sd,kind', [('sample-images1', 'fast'), ('sample-images1', 'gen'), ('sample-images2', 'fast'), ('sample-images2', 'gen')])
+def test_full_path_with_either_matrix_core_kernel(env, monkeypatch, sd, kind):
+    """The whole path with the tuned and with the general matrix-core kernel forced: identical records, equal to the oracle."""
+    from meterelf_amd import MeterReader
+    from oracle import pyoracle as po
+    e = env[sd]
+    frames = synth_frames(_good(e['files']), 70, 99)
+    ores = po.process_frames(frames, e['oparams'])
+    monkeypatch.setenv('MELF_MATCH', kind)
+    r = MeterReader(e['params'])
+    try:
+        recs = r.read_frames(frames)
+        recs2 = r.read_frames(frames[:33])
+    finally:
+        r.close()
+    _compare_records(recs, ores, tag=kind)
+    assert recs2.tobytes() == recs[:33].tobytes()

@@ -1,9 +1,34 @@
-"""Print the headline numbers of a bench.py JSON line (helper for GPU-box runs)."""
+#!/usr/bin/env python3
+"""Short human summary of a bench.py JSON line:   python3 tools/print_bench.py gpurun_out/bench.json"""
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-fm = d.get("fused_mask", {}).get("roofline", {})
-print("value", d["value"], "ms/step", d["ms_per_step"], "k_match frac", d["roofline"]["frac"],
-      "| fused ms", fm.get("avg_launch_ms"), "frac", fm.get("frac"),
-      "| cpu", d.get("cpu_baseline", {}).get("value"), "mism", d.get("cpu_baseline", {}).get("parity_mismatches_vs_gpu"))
+d = json.loads([ln for ln in open(sys.argv[1]).read().splitlines() if ln.startswith('{')][-1])
+r = d.get('roofline') or {}
+print('value %.0f frames/s  ms/step %.4f  n_gpus %s  rccl_ranks %s' % (d['value'], d['ms_per_step'], d['n_gpus'], d.get('rccl_ranks')))
+print('  kernels ms', d.get('kernel_ms'), '| k_match %.4f ms frac %.4f' % (r.get('avg_launch_ms', 0), r.get('frac', 0)))
+s = d.get('sustained')
+if s:
+    print('  sustained %.4f ms/step over %.2f s, k_match %.4f ms frac %.4f' % (s['ms_per_step'], s['seconds'], s['k_match_avg_launch_ms'], s['k_match_frac']))
+f = d.get('fused_mask')
+if f:
+    print('  fused (config 2) %.4f ms  %.0f GB/s  frac %.4f' % (f['roofline']['avg_launch_ms'], f['roofline']['achieved'], f['roofline']['frac']))
+c = d.get('config4')
+if c:
+    print('  config4 %.0f frames/s  %.4f ms/step  kernels %s  k_match frac %.4f  mism %s' % (
+        c['frames_per_s'], c['ms_per_step'], c['kernel_ms'], c['roofline']['frac'], (c.get('cpu_baseline') or {}).get('parity_mismatches_vs_gpu')))
+c = d.get('config5')
+if c:
+    fm = c['fused_mask']['roofline']
+    fp = c['full_path']
+    print('  config5 fused %.4f ms %.0f GB/s frac %.4f | full %.0f frames/s %.4f ms/step kernels %s' % (
+        fm['avg_launch_ms'], fm['achieved'], fm['frac'], fp['frames_per_s'], fp['ms_per_step'], fp['kernel_ms']))
+h = d.get('host_fed')
+if h:
+    print('  host_fed %.0f frames/s  %.2f ms/call  crop PCIe %.1f GB/s' % (h['frames_per_s'], h['ms_per_call'], h['pcie_GBps_crop_bytes']))
+j = d.get('jpeg_decode')
+if j:
+    print('  jpeg %.0f files/s  kernels %s' % (j['files_per_s'], j['kernel_ms']))
+c = d.get('cpu_baseline')
+if c:
+    print('  cpu %.1f frames/s (1 core), %.0f (%d cores), parity mismatches %d' % (c['value'], c['all_cores']['value'], c['all_cores']['cores'], c['parity_mismatches_vs_gpu']))
