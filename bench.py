@@ -145,7 +145,11 @@ class Env:
                 raise SystemExit('--share-gpu puts several ranks on one GPU: RCCL cannot do that, use --backend gloo')
             dist.init_process_group(backend=self.backend)
             self.dist = dist
-        self.stream_obj = torch.cuda.Stream(device=self.device)   # not torch's default stream: no implicit null-stream syncs
+        # not torch's default stream (no implicit null-stream syncs).  With --streams 2 consecutive steps alternate between
+        # two streams: the context runs them on its two pipeline lanes, so one step's prep / dials kernels overlap the
+        # other's match kernel (steps are independent: different batches, different record slices)
+        self.stream_objs = [torch.cuda.Stream(device=self.device) for _ in range(max(1, args.streams))]
+        self.stream_obj = self.stream_objs[0]
         self.stream = self.stream_obj.cuda_stream
 
     def barrier(self):
@@ -173,7 +177,7 @@ class Env:
         return _hip.Context(blob, self.dev_index), names
 
 
-def timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=None):
+def timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=None, nstreams=1):
     """Exactly `steps` steps between barrier + synchronize on both sides; step i reads batch i % nbuf and writes that
     batch's record slice.  Returns (elapsed seconds of this rank, records of all nbuf batches)."""
     from meterelf_amd import _hip
@@ -183,10 +187,14 @@ def timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=
     env.barrier()
     env.sync()
     t0 = time.perf_counter()
+    streams = env.stream_objs[:max(1, min(nstreams, len(env.stream_objs), nbuf))]
     for i in range(steps):
         b = i % nbuf
         ctx.process_batch_dev(frames.data_ptr() + b * B * fs, B, H, W, frame_stride=fs,
-                              d_results_ptr=d_results.data_ptr() + b * B * rsz, want_host=False, stream=env.stream)
+                              d_results_ptr=d_results.data_ptr() + b * B * rsz, want_host=False,
+                              stream=streams[i % len(streams)].cuda_stream)
+    for so in streams[1:]:
+        env.stream_obj.wait_stream(so)
     with torch.cuda.stream(env.stream_obj):
         recs = d_results.cpu()          # D2H of the records: inside the timed region
     env.sync()
@@ -276,8 +284,8 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     d_results = torch.zeros(B * nbuf * _hip.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=env.device)
     env.sync()
 
-    def run(k):
-        return timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, k)
+    def run(k, nstreams=1):
+        return timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, k, nstreams=nstreams)
 
     run(max(warmup, 1))
     # a few steps with every kernel bracketed by events (informational per-kernel times) ...
@@ -287,7 +295,11 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     kt_all = ctx.timings()
     # ... then the timed region with stamps on the dominant kernel only (no extra packets in the queue)
     ctx.set_profiling(2)
-    (elapsed, recs) = run(steps)
+    ns = env.args.streams
+    if ns > 1:
+        run(max(warmup, 2), ns)
+        ctx.timings()
+    (elapsed, recs) = run(steps, ns)
     kt = ctx.timings()
     (elapsed_max, per_rank) = max_over_ranks(env, elapsed)
     out = {'ctx': ctx, 'P': P, 'H': H, 'W': W, 'frames': frames, 'recs': recs, 'elapsed': elapsed_max,
@@ -297,7 +309,7 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     if sustained_s > 0:
         est = max(elapsed / steps, 1e-5)
         k = int(sustained_s / est * 1.15) + nbuf
-        (el, _r) = run(k)
+        (el, _r) = run(k, ns)
         kts = ctx.timings()
         (el_max, _p) = max_over_ranks(env, el)
         r = match_roofline(P, H, W, kts, B * k, (None, None))
@@ -524,6 +536,7 @@ def main():
     ap.add_argument('--sample-dir', default='sample-images1')
     ap.add_argument('--cpu-sample', type=int, default=768, help='frames timed through the CPU oracle (about 10 s on one core)')
     ap.add_argument('--sustained', type=float, default=2.0, help='seconds of back-to-back steps in the sustained block')
+    ap.add_argument('--streams', type=int, default=1, help='caller streams the steps alternate between (2: steps overlap on the context\'s two lanes)')
     ap.add_argument('--skip', default='', help='comma list of blocks to skip: ' + ','.join(ALL_BLOCKS))
     ap.add_argument('--only', default='', help='comma list of extra blocks to run (default: all)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (nccl = RCCL)')

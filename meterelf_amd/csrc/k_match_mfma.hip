@@ -238,7 +238,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     };
     constexpr int NKB = ND + NXB - 1;
     constexpr int NBUF = R + PD;   // image-row register buffers: R live + PD in flight
-    constexpr int NA = PD + 1;     // template-fragment sets: 1 live + PD in flight
+    static_assert(PD == 1, "the template fragments are single-buffered: the next row's fragment d is requested right after this row's last use of fragment d");
     const int lane = threadIdx.x;
 
     const i32x4* Lrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + y0) * (size_t)NKB * 1024) + lane;
@@ -253,9 +253,9 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][xb][e] = 0;
 
-    // Both register rotations have period lcm(NBUF, NA); the loop body covers one period, so every
-    // register index is a constant.  th_pad is a multiple of the period (zero template rows).
-    constexpr int PERIOD = NBUF * NA / (NBUF % NA == 0 ? NA : (NA % 2 == 0 && NBUF % 2 == 0 ? 2 : 1));
+    // The image-row rotation has period NBUF; the loop body covers one period, so every register index is a
+    // constant.  th_pad is a multiple of the period (zero template rows).
+    constexpr int PERIOD = NBUF;
     // The sum over template rows may run in any order: every wave walks the rows cyclically from
     // its own start so that, at any moment, all row blocks of a frame group are reading (nearly) the
     // same image rows -- one L2 miss serves the whole group instead of every wave streaming its own
@@ -269,20 +269,22 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     const int istart = (((g.th_pad - y0 % g.th_pad) % g.th_pad) / PERIOD) * PERIOD;
 #endif
     i32x4 buf[NBUF][NKB];
-    i32x4 a[NA][ND];
+    // ONE set of template fragments (28 registers instead of 56): the request for the next template row's fragment d
+    // is placed behind this row's last MFMA that reads fragment d -- a full step (70 MFMAs) ahead of its use, as
+    // before.  With the two-row epilogue batches this takes the kernel from 492 to ~390 of the SIMD's 512 registers:
+    // a wave of the other pipeline lane's dials kernel (104) or prep kernel (64) fits beside it.
+    i32x4 a[ND];
     for (int phase = 0; phase < 2; ++phase) {
         const int ibeg = phase == 0 ? istart : 0, iend = phase == 0 ? g.th_pad : istart;
         if (ibeg >= iend) continue;
-        // (re-)prime: image rows y0+ibeg .. y0+ibeg+R+PD-2 and template rows ibeg .. ibeg+PD-1
+        // (re-)prime: image rows y0+ibeg .. y0+ibeg+R+PD-2 and template row ibeg
 #pragma unroll
         for (int r = 0; r < NBUF - 1; ++r)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
                 buf[r][kb] = Lrow[(size_t)(ibeg + r) * ROWV + kb * 64];
 #pragma unroll
-        for (int q = 0; q < NA - 1; ++q)
-#pragma unroll
-            for (int d = 0; d < ND; ++d) a[q][d] = Ap[((size_t)(ibeg + q) * ND + d) * 64];
+        for (int d = 0; d < ND; ++d) a[d] = Ap[((size_t)ibeg * ND + d) * 64];
         for (int i0 = ibeg; i0 < iend; i0 += PERIOD) {
 #pragma unroll
             for (int s = 0; s < PERIOD; ++s) {
@@ -297,49 +299,19 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                     // image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD
 #pragma unroll
                     for (int kb = d; kb < (d == ND - 1 ? NKB : d + 1); ++kb)
-#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 4)
-                        if (i < 0)  // diagnostic: no image loads in the loop at all (wrong results)
-#endif
-#if !(defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 16))  // 16: loads compiled out, no branch clutter
-#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 2)
-                        buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)((i + NBUF - 1) & 3) * ROWV + kb * 64];  // diagnostic: four image rows only
-#else
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
-#endif
-#endif
-                    // The image fragment is requested before the sub-block's first MFMAs, the template fragment of
-                    // step i + PD (the table carries PD extra all-zero rows) in the middle of them: each load then
-                    // issues in the shadow of a running MFMA instead of two loads, their address arithmetic and the
-                    // waits piling up between two sub-blocks.
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        if (half == 1) {
-#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 4)
-                            if (i < 0)  // diagnostic: no template loads in the loop either
-#endif
-#if !(defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 16))
-#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 1)
-                            a[(s + PD) % NA][d] = Ap[((size_t)((i + PD) & 1) * ND + d) * 64];  // diagnostic: template rows 0/1 only (wrong results)
-#else
-                            a[(s + PD) % NA][d] = Ap[((size_t)(i + PD) * ND + d) * 64];
-#endif
-#endif
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                    for (int r = 0; r < R; ++r)
 #pragma unroll
-                        for (int r = half ? R / 2 : 0; r < (half ? R : R / 2); ++r)
-#pragma unroll
-                            for (int xb = 0; xb < NXB; ++xb)
-                                if (on(r, xb))
-#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 8)
-                                    acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], buf[0][0], acc[r][xb], 0, 0, 0);  // diagnostic: one A / B register set
-#else
-                                    acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NA][d], buf[(s + r) % NBUF][d + xb],
-                                                                                       acc[r][xb], 0, 0, 0);
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                        for (int xb = 0; xb < NXB; ++xb)
+                            if (on(r, xb))
+                                acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], buf[(s + r) % NBUF][d + xb], acc[r][xb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // fragment d of template row i + 1 (the table carries one extra all-zero row), into the registers the
+                    // MFMAs above have just read: issued in the shadow of the running MFMAs
+                    a[d] = Ap[((size_t)(i + 1) * ND + d) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -354,45 +326,57 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // L2 round trip -- a third of the wave's lifetime.
     const int n = lane & 31, hh = lane >> 5;
     const int f = grp * 32 + n;
-    uint32_t wsr[R][NXB][16];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int yc = min(y0 + r, g.rh - 1);
-        const uint32_t* wrow = ws + ((size_t)grp * g.rh + yc) * 64 * 32 + n;
-#pragma unroll
-        for (int xb = 0; xb < NXB; ++xb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (on(r, xb)) wsr[r][xb][e] = wrow[(32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh) * 32];
-    }
-    __builtin_amdgcn_sched_barrier(0);
     // cc = sum T*L is below 2^31 (119*188*255^2 at most for templates this kernel takes), so the three terms
     // can be added modulo 2^32 and converted with one cvt_f64_u32 (an int64 -> double conversion is four
     // instructions, two of them quarter rate).  A lane visits its elements in increasing raster index, so the
     // first maximum is "strictly greater wins".
+    // Rows in batches of two: a batch's window sums and its accumulators (which leave the accumulator file for the
+    // vector ALU) then fit the 256 architectural VGPRs, and the kernel's register footprint is that of its main loop:
+    // ~400 of 512, which leaves room on every SIMD for a wave of the other pipeline lane's prep or dials kernel.
     const bool lane_ok = f < g.nframes;
     float bestv = -INFINITY;
     int besti = INT_MAX;
+    constexpr int RB = 1;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int y = y0 + r;
-        const bool row_ok = lane_ok && y < g.rh;
+    for (int r0 = 0; r0 < R; r0 += RB) {
+        uint32_t wsr[RB][NXB][16];
 #pragma unroll
-        for (int xb = 0; xb < NXB; ++xb)
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = r0 + rr;
+            if (r >= R) continue;
+            const int yc = min(y0 + r, g.rh - 1);
+            const uint32_t* wrow = ws + ((size_t)grp * g.rh + yc) * 64 * 32 + n;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if (!on(r, xb)) continue;
-                const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const bool valid = row_ok && x < g.rw;
-                const uint32_t wsv = wsr[r][xb][e];
-                const uint32_t cc = (uint32_t)acc[r][xb][e] + 128u * wsv + (uint32_t)g.k1;
-                double num = (double)cc;
-                num -= (double)wsv * g.tmean;
-                const float v = valid ? (float)num : -INFINITY;
-                const int idx = y * g.rw + x;
-                if (result_map && valid) result_map[(size_t)f * g.rh * g.rw + idx] = v;
-                if (v > bestv) { bestv = v; besti = idx; }
-            }
+            for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (on(r, xb)) wsr[rr][xb][e] = wrow[(32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh) * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = r0 + rr;
+            if (r >= R) continue;
+            const int y = y0 + r;
+            const bool row_ok = lane_ok && y < g.rh;
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (!on(r, xb)) continue;
+                    const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const bool valid = row_ok && x < g.rw;
+                    const uint32_t wsv = wsr[rr][xb][e];
+                    const uint32_t cc = (uint32_t)acc[r][xb][e] + 128u * wsv + (uint32_t)g.k1;
+                    double num = (double)cc;
+                    num -= (double)wsv * g.tmean;
+                    const float v = valid ? (float)num : -INFINITY;
+                    const int idx = y * g.rw + x;
+                    if (result_map && valid) result_map[(size_t)f * g.rh * g.rw + idx] = v;
+                    if (v > bestv) { bestv = v; besti = idx; }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     {
         const float ov = __shfl_xor(bestv, 32, 64);
@@ -449,11 +433,11 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
 // host side
 // ---------------------------------------------------------------------------
 constexpr int MM_ND = 7, MM_R = 5, MM_PD = 1;
-constexpr int MM_NBUF = MM_R + MM_PD, MM_NA = MM_PD + 1;
-constexpr int MM_PERIOD = MM_NBUF * MM_NA / (MM_NBUF % MM_NA == 0 ? MM_NA : (MM_NA % 2 == 0 && MM_NBUF % 2 == 0 ? 2 : 1));
-// th_pad: multiple of every wave type's rotation period (R = 5: lcm(6, 2) = 6; R = 4: lcm(5, 2) = 10)
+constexpr int MM_NBUF = MM_R + MM_PD;
+constexpr int MM_PERIOD = MM_NBUF;
+// th_pad: multiple of every wave type's rotation period (R = 5: 6; R = 4: 5; R = 2: 3)
 static int mm_th_pad(int th) { return (th + 29) / 30 * 30; }
-static_assert(MM_PD == 1 && MM_R == 5 && 30 % MM_PERIOD == 0, "th_pad rule assumes PD = 1, R in {4, 5}");
+static_assert(MM_PD == 1 && MM_R == 5 && 30 % MM_PERIOD == 0, "th_pad rule assumes PD = 1, R in {2, 4, 5}");
 
 bool mfma_match_ok(int th, int tw, int rows, int cols)
 {

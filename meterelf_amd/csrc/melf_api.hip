@@ -1,5 +1,6 @@
 // Host side of libmeterelf_hip: calibration blob, per-GPU context, entry points.
 // The C ABI is declared and documented in include/meterelf_hip.h.
+#include <emmintrin.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -266,27 +267,56 @@ struct melf_ctx {
     // profiling
     bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
     int profiling = 0;                // 0 off, 1 every kernel, 2 only the dominant kernel (k_match)
-    // the work buffers belong to the context, not to a stream: when a *_dev call arrives on another stream than the
-    // previous one, the new stream first waits for everything the previous call enqueued (enter_stream)
-    hipStream_t last_stream = nullptr;
-    bool last_stream_valid = false;
+    // The work buffers belong to the context's pipeline lanes, and a lane serves one caller stream at a time: calls that
+    // arrive on two different streams run on the two lanes and overlap on the GPU (one batch's prep / dials kernels in
+    // the shadow of the other's match kernel); a third stream, or a call that needs a particular lane, first waits for
+    // what the lane's previous stream enqueued (claim_lane).
+    hipStream_t lane_owner[NLANES] = {nullptr, nullptr};
+    bool lane_owned[NLANES] = {false, false};
+    uint64_t lane_used[NLANES] = {0, 0};
+    uint64_t use_clock = 0;
     hipEvent_t ev_order = nullptr;
     std::vector<TimedEvent> events;
     double acc_ms[MELF_K_COUNT] = {0};
     int64_t acc_n[MELF_K_COUNT] = {0};
 };
 
-// Orders the caller's stream after the context's previous *_dev call when that one ran on a different stream (the
-// calls share the context's work buffers).  Costs nothing while the caller stays on one stream.
-static int enter_stream(melf_ctx* c, hipStream_t st)
+// Hands lane l to stream st: if another stream used the lane last, st first waits for everything that stream had
+// enqueued by now.  Costs nothing while the lane stays with one stream.
+static int claim_lane(melf_ctx* c, int l, hipStream_t st)
 {
-    if (c->last_stream_valid && c->last_stream != st) {
+    if (c->lane_owned[l] && c->lane_owner[l] != st) {
         if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(c->ev_order, c->last_stream));
-        HIP_TRY(hipStreamWaitEvent(st, c->ev_order, 0));
+        // a stream the caller has destroyed meanwhile has nothing pending: a failed record is not an error
+        if (hipEventRecord(c->ev_order, c->lane_owner[l]) == hipSuccess) HIP_TRY(hipStreamWaitEvent(st, c->ev_order, 0));
+        else (void)hipGetLastError();
     }
-    c->last_stream = st;
-    c->last_stream_valid = true;
+    c->lane_owner[l] = st;
+    c->lane_owned[l] = true;
+    c->lane_used[l] = ++c->use_clock;
+    return MELF_SUCCESS;
+}
+// The lane st already owns, else a free one, else the least recently used one.
+static int acquire_lane(melf_ctx* c, hipStream_t st, int* lane)
+{
+    int pick = -1;
+    for (int l = 0; l < melf_ctx::NLANES; ++l)
+        if (c->lane_owned[l] && c->lane_owner[l] == st) { pick = l; break; }
+    if (pick < 0)
+        for (int l = 0; l < melf_ctx::NLANES; ++l)
+            if (!c->lane_owned[l]) { pick = l; break; }
+    if (pick < 0) {
+        pick = 0;
+        for (int l = 1; l < melf_ctx::NLANES; ++l)
+            if (c->lane_used[l] < c->lane_used[pick]) pick = l;
+    }
+    *lane = pick;
+    return claim_lane(c, pick, st);
+}
+static int claim_all_lanes(melf_ctx* c, hipStream_t st)
+{
+    for (int l = 0; l < melf_ctx::NLANES; ++l)
+        if (int rc = claim_lane(c, l, st)) return rc;
     return MELF_SUCCESS;
 }
 
@@ -710,7 +740,7 @@ static const int MAX_FRAMES_PER_LAUNCH = 32768;
 // rect (optional): {x0, y0, x1, y1} of the meter crop inside the H x W frames instead of the context's meter_rect
 // (the host-fed path uploads only the crop: its "frames" are the crops themselves)
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
-                            void* d_results, melf_result* out_host, hipStream_t st, const int* rect = nullptr);
+                            void* d_results, melf_result* out_host, hipStream_t st, const int* rect = nullptr, int row_stride = 0);
 
 extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
                                       void* d_results, melf_result* out_host, void* stream_)
@@ -722,13 +752,18 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
     if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
-    if (int rc = enter_stream(c, st)) return rc;
+    if (c->lanes > 1) {  // the batch is split over both lanes
+        if (int rc = claim_all_lanes(c, st)) return rc;
+    } else if (int rc = acquire_lane(c, st, &c->active_lane)) {
+        return rc;
+    }
     return process_batch_on(c, d_frames, n, H, W, frame_stride, d_results, out_host, st);
 }
 
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
-                            void* d_results, melf_result* out_host, hipStream_t st, const int* rect)
+                            void* d_results, melf_result* out_host, hipStream_t st, const int* rect, int row_stride)
 {
+    if (row_stride <= 0) row_stride = W * 3;  // packed rows unless the caller's rows are padded (host-fed crops)
     const melf_params& P = c->P;
     // numpy slicing img[y0:y1, x0:x1] clamps to the image (meterelf/_image.py:54-55)
     const int rx0 = rect ? rect[0] : P.rect_x0, ry0 = rect ? rect[1] : P.rect_y0;
@@ -764,13 +799,13 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
             const int bl = split ? l : c->active_lane;  // whose work buffers
             const uint8_t* base = (const uint8_t*)d_frames + (size_t)g0 * frame_stride;
             MatchSrc ms;
-            ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = W * 3;
+            ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = row_stride;
             ms.x0 = x0; ms.y0 = y0; ms.rows = crows; ms.cols = ccols;
             int nparts = 0;
             MatchPartial* parts = nullptr;
             if (int rc = run_match(c, ms, true, m, bl, ls, nullptr, &parts, &nparts)) return rc;
             DialsSrc ds;
-            ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = W * 3;
+            ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = row_stride;
             ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
             {
                 KernelTimer t(c, MELF_K_DIALS, ls);
@@ -805,7 +840,7 @@ extern "C" int melf_process_stream_dev(melf_ctx* c, const void* d_frames, int nb
     HIP_TRY(hipSetDevice(c->device));
     if (H <= 0 || W <= 0 || frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "bad frame shape / stride");
     hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
-    if (int rc = enter_stream(c, st)) return rc;
+    if (int rc = claim_all_lanes(c, st)) return rc;
     if (nbatches == 1 || n > MAX_FRAMES_PER_LAUNCH)  // nothing to overlap / too large for one set of lane buffers
     {
         for (int b = 0; b < nbatches; ++b)
@@ -851,9 +886,12 @@ extern "C" int melf_process_batch(melf_ctx* c, const uint8_t* frames_host, int n
     if (x0 < 0 || y0 < 0 || crows < P.th || ccols < P.tw)
         return fail(MELF_ERR_INVALID, "meter_rect crop is smaller than the dials template (cv2.matchTemplate would assert)");
     const size_t row_bytes = (size_t)ccols * 3;
-    // 128 spare bytes per crop: the prep kernel's aligned 100-byte windows may reach past the last pixel
-    const size_t crop_stride = ((size_t)crows * row_bytes + 128 + 63) & ~(size_t)63;
-    const int chunk = 256;  // frames per pipeline stage (a multiple of the 32-frame MFMA group)
+    // crop rows at a 64-byte pitch, so that the host side can pack them with streaming (non-temporal) 16-byte stores:
+    // a plain memcpy into the staging buffer reads every destination line before writing it, a third of the pack's
+    // memory traffic; + 128 spare bytes per crop (the prep kernel's aligned 100-byte windows reach past the last pixel)
+    const size_t pitch = (row_bytes + 63) & ~(size_t)63;
+    const size_t crop_stride = (size_t)crows * pitch + 128;
+    const int chunk = 128;  // frames per pipeline stage (a multiple of the 32-frame MFMA group)
     const size_t pin_need = (size_t)(n < chunk ? n : chunk) * crop_stride;
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {
@@ -869,28 +907,53 @@ extern "C" int melf_process_batch(melf_ctx* c, const uint8_t* frames_host, int n
     HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's kernels may still read d_crops
     if (int rc = grow(&c->d_crops, &c->crops_cap, (size_t)n * crop_stride)) return rc;
     if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
-    if (int rc = enter_stream(c, c->stream)) return rc;
+    if (c->lanes > 1) {
+        if (int rc = claim_all_lanes(c, c->stream)) return rc;
+    } else if (int rc = acquire_lane(c, c->stream, &c->active_lane)) {
+        return rc;
+    }
+    static const bool trace = getenv("MELF_HOSTFED_TRACE") != nullptr;
+    double pack_ms = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
     const int rect[4] = {0, 0, ccols, crows};
+    const uint8_t* frames_end = frames_host + (size_t)(n - 1) * frame_stride + (size_t)H * W * 3;
     int k = 0;
     for (int f0 = 0; f0 < n; f0 += chunk, ++k) {
         const int m = n - f0 < chunk ? n - f0 : chunk;
         const int b = k & 1;
         if (k >= 2) HIP_TRY(hipEventSynchronize(c->ev_h2d[b]));  // the copy that last read this staging buffer is done
         uint8_t* pin = c->h_pin[b];
-        host_pool().run(m, [&](int i) {
-            const uint8_t* src = frames_host + (size_t)(f0 + i) * frame_stride + ((size_t)y0 * W + x0) * 3;
-            uint8_t* dst = pin + (size_t)i * crop_stride;
-            for (int y = 0; y < crows; ++y) memcpy(dst + (size_t)y * row_bytes, src + (size_t)y * W * 3, row_bytes);
+        const auto tp0 = std::chrono::steady_clock::now();
+        // work items of 32 crop rows: a chunk of 128 frames gives a 16-thread pool ~1000 items
+        const int rblocks = (crows + 31) / 32;
+        host_pool().run(m * rblocks, [&](int item) {
+            const int i = item / rblocks, r0 = (item - i * rblocks) * 32, r1 = r0 + 32 < crows ? r0 + 32 : crows;
+            const uint8_t* src = frames_host + (size_t)(f0 + i) * frame_stride + ((size_t)(y0 + r0) * W + x0) * 3;
+            uint8_t* dst = pin + (size_t)i * crop_stride + (size_t)r0 * pitch;
+            for (int y = r0; y < r1; ++y, src += (size_t)W * 3, dst += pitch) {
+                if (src + pitch <= frames_end) {  // whole 64-byte pitch from the source row (the tail bytes are never looked at)
+                    for (size_t o = 0; o < pitch; o += 16)
+                        _mm_stream_si128((__m128i*)(dst + o), _mm_loadu_si128((const __m128i*)(src + o)));
+                } else {
+                    memcpy(dst, src, row_bytes);
+                }
+            }
+            _mm_sfence();
         });
+        pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
         uint8_t* d_chunk = c->d_crops + (size_t)f0 * crop_stride;
         HIP_TRY(hipMemcpyAsync(d_chunk, pin, (size_t)m * crop_stride, hipMemcpyHostToDevice, c->copy_stream));
         HIP_TRY(hipEventRecord(c->ev_h2d[b], c->copy_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
-        if (int rc = process_batch_on(c, d_chunk, m, crows, ccols, crop_stride, c->d_results + f0, nullptr, c->stream, rect))
+        if (int rc = process_batch_on(c, d_chunk, m, crows, ccols, crop_stride, c->d_results + f0, nullptr, c->stream, rect, (int)pitch))
             return rc;
     }
     HIP_TRY(hipMemcpyAsync(out_host, c->d_results, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (trace)
+        fprintf(stderr, "[melf host-fed] n=%d crop %dx%d: %.2f ms in all, %.2f ms of it packing (%d pool threads), %.1f MB over PCIe\n", n, ccols,
+                crows, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), pack_ms,
+                host_pool().size() + 1, (double)n * crop_stride / 1e6);
     return MELF_SUCCESS;
 }
 
@@ -966,7 +1029,7 @@ extern "C" int melf_match_ccoeff(melf_ctx* c, const uint8_t* images_host, int n,
     if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, in_bytes)) return rc;
     if (int rc = grow(&c->d_stage_out, &c->stage_out_cap, map_bytes + 16)) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_stage_in, images_host, in_bytes, hipMemcpyHostToDevice, c->stream));
-    if (int rc = enter_stream(c, c->stream)) return rc;
+    if (int rc = claim_lane(c, 0, c->stream)) return rc;
     MatchSrc ms;
     ms.base = c->d_stage_in; ms.frame_stride = (size_t)rows * cols; ms.row_stride = cols;
     ms.x0 = 0; ms.y0 = 0; ms.rows = rows; ms.cols = cols;
