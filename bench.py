@@ -448,7 +448,7 @@ def config5_block(env, cfg3_frames, steps, warmup, traffic):
 def hostfed_block(env, ctx, frames, B, H, W):
     """melf_process_batch: frames in pageable HOST memory in, records out (PCIe inclusive; never `value`)."""
     host = frames[:B].cpu().numpy()
-    ctx.process_batch(host[:64])
+    ctx.process_batch(host)   # warm-up at full size: the pinned staging buffers are allocated on first use
     reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):

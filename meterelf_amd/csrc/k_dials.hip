@@ -117,8 +117,15 @@ __device__ inline void for_each_kept(uint64_t outer, int lane, int wx0, int wy0,
     }
 }
 
-constexpr int DIAL_LIST_CAP = 1024;
+constexpr int DIAL_LIST_CAP = 768;   // candidate pixels of a dial window that take the exact float path
 constexpr int RING_CAP = 256;
+// LDS of one dial (one wave), carved from the kernel's dynamic block: the ring arrays of the angle phase re-use the
+// candidate list of the pixel phase.
+//   [0, 2048) ra, [2048, 4096) rd   (double[RING_CAP] each)      | pixel phase: [0, 3072) list_px u32[CAP], [3072, 4608) list_pos u16[CAP]
+//   [4096, 4608) ring list u16[RING_CAP]
+//   [4608, 5120) exact in-range bits, two dwords per window row
+constexpr int DIAL_LDS_BYTES = 5120;
+static_assert(DIAL_LIST_CAP * 4 + DIAL_LIST_CAP * 2 <= 4608 && RING_CAP * 16 + RING_CAP * 2 <= 4608, "dial LDS layout");
 
 // Three bytes of a packed 3-channel pixel with ONE (unaligned) dword load instead of three byte loads: the
 // dword starts one byte early (so it never runs past the buffer's end) except at the buffer's very first pixel.
@@ -142,8 +149,9 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_dials_stamps(ui
 #define DSTAMP(k) do { } while (0)
 #endif
 
-template <bool FROM_HLS>
-__global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, melf_params P,
+// NR: window rows whose pixels a lane requests up front (the largest dial window of the context, rounded up to 8)
+template <bool FROM_HLS, int NR>
+__global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) void k_dials(DialsSrc src, melf_params P,
                                                               const DialGeom* __restrict__ geom,
                                                               const uint64_t* __restrict__ rowmasks,
                                                               const MatchPartial* __restrict__ partials,
@@ -151,39 +159,45 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
 {
     __shared__ int s_status[MELF_MAX_DIALS];
     __shared__ double s_pos[MELF_MAX_DIALS], s_angle[MELF_MAX_DIALS];
-    __shared__ float s_mv;
-    __shared__ int s_mi;
-    __shared__ uint16_t s_list[MELF_MAX_DIALS][DIAL_LIST_CAP];  // candidate pixels (y << 6 | x) of each dial's window
-    __shared__ uint32_t s_mask[MELF_MAX_DIALS][128];            // exact in-range bits, two dwords per window row
-    __shared__ double s_ra[MELF_MAX_DIALS][RING_CAP], s_rd[MELF_MAX_DIALS][RING_CAP];  // ring points: angle (NaN = dropped), distance^2
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // DIAL_LDS_BYTES per dial
 
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63, d = threadIdx.x >> 6;
     DSTAMP(0);
     const uint8_t* frame = src.base + (size_t)f * src.frame_stride;
+    uint8_t* const lds = s_dyn + (size_t)d * DIAL_LDS_BYTES;
+    uint32_t* const list_px = (uint32_t*)lds;                       // pixel phase
+    uint16_t* const list_pos = (uint16_t*)(lds + 3072);             // pixel phase
+    double* const s_ra_d = (double*)lds;                            // angle phase
+    double* const s_rd_d = (double*)(lds + 2048);
+    uint16_t* const ring_list = (uint16_t*)(lds + 4096);
+    uint32_t* const mask_d = (uint32_t*)(lds + 4608);
 
     // ---- minMaxLoc over the K2 partials; DialsNotFoundError check (_image.py:62-64) ----
     int mx = 0, my = 0;
     float mv = 0.f;
     if (!FROM_HLS) {
-        if (d == 0) {
-            float bv = 0.f;
-            int bi = INT_MAX;
-            for (int k = lane; k < nparts; k += 64) {
-                const MatchPartial p = partials[(size_t)f * nparts + k];
-                if (p.idx != INT_MAX && (bi == INT_MAX || p.val > bv || (p.val == bv && p.idx < bi))) { bv = p.val; bi = p.idx; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (oi != INT_MAX && (bi == INT_MAX || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-            }
-            if (lane == 0) { s_mv = bv; s_mi = bi; }
+        // every wave folds the partials itself (a few dozen entries): no LDS hand-off, no workgroup barrier
+        float bv = 0.f;
+        int bi = INT_MAX;
+        for (int k = lane; k < nparts; k += 64) {
+            const MatchPartial p = partials[(size_t)f * nparts + k];
+            if (p.idx != INT_MAX && (bi == INT_MAX || p.val > bv || (p.val == bv && p.idx < bi))) { bv = p.val; bi = p.idx; }
         }
-        __syncthreads();
-        mv = s_mv;
-        const int mi = s_mi;
+        {   // (value, first index) maximum over the lanes, DPP scan: lane 63 ends with the result
+            auto fold = [&](float ov, int oi) {
+                if (oi != INT_MAX && (bi == INT_MAX || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            };
+#define MELF_PFOLD(CTRL, RM, BM) \
+            fold(__int_as_float(dpp_i32<CTRL, RM, BM>(0, __float_as_int(bv))), dpp_i32<CTRL, RM, BM>(INT_MAX, bi));
+            MELF_PFOLD(0x111, 0xf, 0xf) MELF_PFOLD(0x112, 0xf, 0xf) MELF_PFOLD(0x114, 0xf, 0xe) MELF_PFOLD(0x118, 0xf, 0xc)
+            MELF_PFOLD(0x142, 0xa, 0xf) MELF_PFOLD(0x143, 0xc, 0xf)
+#undef MELF_PFOLD
+            bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), 63));
+            bi = __builtin_amdgcn_readlane(bi, 63);
+        }
+        mv = bv;
+        const int mi = bi;
         mx = mi % rw;
         my = mi / rw;
         if ((double)mv < P.match_threshold) {
@@ -204,25 +218,36 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
     const melf_dial D = P.dial[d];
     const int wx0 = G.wx0, wy0 = G.wy0, ws = G.ws;
 
-    auto fetch = [&](int X, int Y, int& H, int& L, int& S) {
-        if (FROM_HLS) {
-            const uint32_t px = load_px3(frame + ((size_t)Y * P.tw + X) * 3, src.base);
-            H = px & 255; L = (px >> 8) & 255; S = (px >> 16) & 255;
-        } else {
-            const int cxp = mx + X, cyp = my + Y;  // meter-crop coordinates
-            const uint32_t px = load_px3(frame + (size_t)(src.y0 + cyp) * src.row_stride + (size_t)(src.x0 + cxp) * 3, src.base);
-            hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, hls_scalar_tail(cxp, src.crop_cols), P.hue_shift, H, L, S);
+    // Every pixel this wave needs is requested here, before anything waits: the 5x5 colour core (one pixel per lane)
+    // and the lane's column of the window (lane = column, one packed VGPR per window row).  Unconditional loads at
+    // clamped (always valid) coordinates: a load inside a bounds check makes the compiler wait for each one separately.
+    // The colour phase below then runs while the window's rows are still in flight -- one memory round trip for the
+    // wave instead of one for the core and one per 16 rows (half of the wave's life was such waits).
+    const int Xl = wx0 + lane;
+    const bool colvalid = lane < ws && Xl >= 0 && Xl < P.tw;
+    const int Xc = min(max(Xl, 0), P.tw - 1);
+    const bool tail = !FROM_HLS && hls_scalar_tail(mx + Xl, src.crop_cols);
+    const size_t rstride = FROM_HLS ? (size_t)P.tw * 3 : (size_t)src.row_stride;
+    const uint8_t* const origin = FROM_HLS ? frame : frame + (size_t)(src.y0 + my) * src.row_stride + (size_t)(src.x0 + mx) * 3;
+    const int coreX = G.core_x - 2 + lane % 5, coreY = G.core_y - 2 + (lane < 25 ? lane / 5 : 0);
+    const bool corevalid = lane < 25 && coreX >= 0 && coreX < P.tw && coreY >= 0 && coreY < P.th;
+    const uint32_t corepx = load_px3(origin + (size_t)min(max(coreY, 0), P.th - 1) * rstride + (size_t)min(max(coreX, 0), P.tw - 1) * 3, src.base);
+    uint32_t pxv[NR];
+    if (!FROM_HLS) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int Y = min(max(wy0 + k, 0), P.th - 1);
+            pxv[k] = load_px3(origin + (size_t)Y * rstride + (size_t)Xc * 3, src.base);
         }
-    };
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // get_dial_color (_reading.py:154-160): mean of the 5x5 core, Python round()
     int sh = 0, sl = 0, ss = 0, cnt = 0;
-    if (lane < 25) {
-        const int X = G.core_x - 2 + lane % 5, Y = G.core_y - 2 + lane / 5;
-        if (X >= 0 && X < P.tw && Y >= 0 && Y < P.th) {
-            fetch(X, Y, sh, sl, ss);
-            cnt = 1;
-        }
+    if (corevalid) {
+        if (FROM_HLS) { sh = corepx & 255; sl = (corepx >> 8) & 255; ss = (corepx >> 16) & 255; }
+        else hls_pixel(corepx & 255, (corepx >> 8) & 255, (corepx >> 16) & 255, hls_scalar_tail(mx + coreX, src.crop_cols), P.hue_shift, sh, sl, ss);
+        cnt = 1;
     }
     sh = wave_sum_i32(sh); sl = wave_sum_i32(sl); ss = wave_sum_i32(ss); cnt = wave_sum_i32(cnt);
     const double inv = cnt ? 1.0 / (double)cnt : 0.0;  // cv::mean: sum * (1./N)
@@ -234,24 +259,15 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
 
     DSTAMP(2);
     // inRange over the window (get_mask_by_color, _utils.py:113-119): row masks via ballot.
-    // Phase 1 requests every window pixel of this lane's column (lane = column, one packed VGPR per
-    // window row) so that all the loads are in flight together; phase 2 converts and tests.
-    const int Xl = wx0 + lane;
-    const bool colvalid = lane < ws && Xl >= 0 && Xl < P.tw;
-    const int Xc = min(max(Xl, 0), P.tw - 1);
-    const bool tail = !FROM_HLS && hls_scalar_tail(mx + Xl, src.crop_cols);
     uint64_t m0 = 0, V = 0;
-    auto exact_rows = [&]() {  // every window pixel through the exact float path
+    auto exact_rows = [&]() {  // every window pixel through the exact float path (its own loads: the rare path must not
+                               // keep the prefilter's pixel registers alive)
         for (int yc = 0; yc < ws; yc += 16) {
-            uint32_t pxv[16];
+            uint32_t pxe[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                // unconditional loads at clamped (always valid) coordinates: a load inside the bounds check makes
-                // the compiler wait for each one separately (16 serialized round trips per chunk)
                 const int Y = min(max(wy0 + yc + k, 0), P.th - 1);
-                const uint8_t* p = FROM_HLS ? frame + ((size_t)Y * P.tw + Xc) * 3
-                                            : frame + (size_t)(src.y0 + my + Y) * src.row_stride + (size_t)(src.x0 + mx + Xc) * 3;
-                pxv[k] = load_px3(p, src.base);
+                pxe[k] = load_px3(origin + (size_t)Y * rstride + (size_t)Xc * 3, src.base);
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
                 bool in = false;
                 if (valid) {
                     int H, L, S;
-                    const uint32_t px = pxv[k];
+                    const uint32_t px = pxe[k];
                     if (FROM_HLS) { H = px & 255; L = (px >> 8) & 255; S = (px >> 16) & 255; }
                     else hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, tail, P.hue_shift, H, L, S);
                     in = H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his;
@@ -277,66 +293,46 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
         // sum = max + min and diff = max - min, L is sum/2 rounded either way and S is 255*diff/den rounded
         // (den = sum below mid-grey, 510 - sum above), both float paths within 1e-4 of the real value, so a
         // pixel whose L or S misses the bounds by a whole unit cannot be in range.  (2) The candidates --
-        // typically the needle, a tenth of the window -- are compacted and only they take the exact float
-        // path, 64 at a time.  More candidates than the list holds: every pixel takes the exact path.
-        uint64_t C = 0;
-        for (int yc = 0; yc < ws; yc += 16) {
-            uint32_t pxv[16];
+        // typically the needle, a tenth of the window -- take the exact float path, 64 at a time: each row's
+        // candidates are appended (position and pixel, by the lane that holds it) to a list in LDS as the row is
+        // tested.  More candidates than the list holds: every pixel takes the exact path.
+        int total = 0;  // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int Y = min(max(wy0 + yc + k, 0), P.th - 1);  // clamped, unconditional (see exact_rows)
-                const uint8_t* p = frame + (size_t)(src.y0 + my + Y) * src.row_stride + (size_t)(src.x0 + mx + Xc) * 3;
-                pxv[k] = load_px3(p, src.base);
+        for (int k = 0; k < NR; ++k) {
+            const int y = k, Y = wy0 + y;
+            const bool valid = y < ws && colvalid && Y >= 0 && Y < P.th;
+            const int b8 = pxv[k] & 255, g8 = (pxv[k] >> 8) & 255, r8 = (pxv[k] >> 16) & 255;
+            const int vmax = max(max(b8, g8), r8), vmin = min(min(b8, g8), r8);
+            const int sum = vmax + vmin, diff = vmax - vmin;
+            const int den = sum <= 255 ? sum : 510 - sum;
+            const bool l_ok = sum >= 2 * lol - 1 && sum <= 2 * hil + 1;
+            const bool s_ok = diff == 0 ? los == 0 : (510 * diff >= (2 * los - 2) * den && 510 * diff <= (2 * his + 2) * den);
+            const bool cand = valid && l_ok && s_ok;
+            const uint64_t cb = __ballot(cand), vb = __ballot(valid);
+            if (lane == y) V = vb;
+            const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+            if (cand && slot < DIAL_LIST_CAP) {
+                list_pos[slot] = (uint16_t)(y << 6 | lane);
+                list_px[slot] = pxv[k];
             }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int y = yc + k, Y = wy0 + y;
-                const bool valid = y < ws && colvalid && Y >= 0 && Y < P.th;
-                const int b8 = pxv[k] & 255, g8 = (pxv[k] >> 8) & 255, r8 = (pxv[k] >> 16) & 255;
-                const int vmax = max(max(b8, g8), r8), vmin = min(min(b8, g8), r8);
-                const int sum = vmax + vmin, diff = vmax - vmin;
-                const int den = sum <= 255 ? sum : 510 - sum;
-                const bool l_ok = sum >= 2 * lol - 1 && sum <= 2 * hil + 1;
-                const bool s_ok = diff == 0 ? los == 0 : (510 * diff >= (2 * los - 2) * den && 510 * diff <= (2 * his + 2) * den);
-                const uint64_t cb = __ballot(valid && l_ok && s_ok), vb = __ballot(valid);
-                if (lane == y) { C = cb; V = vb; }
-            }
+            total += __popcll(cb);
         }
         DSTAMP(6);
-        const int mine = __popcll(C);
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        const int total = __shfl(incl, 63, 64);
         if (total > DIAL_LIST_CAP) {
             exact_rows();
         } else {
-            uint16_t* list = s_list[d];
-            uint32_t* mask = s_mask[d];
-            mask[lane] = 0;
-            mask[64 + lane] = 0;
-            int at = incl - mine;
-            uint64_t bits = C;
-            while (bits) {
-                const int x = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                list[at++] = (uint16_t)(lane << 6 | x);
-            }
+            mask_d[lane] = 0;
+            mask_d[64 + lane] = 0;
             DSTAMP(7);
             for (int t = lane; t < total; t += 64) {
-                const int e = list[t], y = e >> 6, x = e & 63;
-                const int cxp = mx + wx0 + x;
-                const uint8_t* p = frame + (size_t)(src.y0 + my + wy0 + y) * src.row_stride + (size_t)(src.x0 + cxp) * 3;
+                const int e = list_pos[t], y = e >> 6, x = e & 63;
+                const uint32_t px = list_px[t];
                 int H, L, S;
-                const uint32_t px = load_px3(p, src.base);
-                hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, hls_scalar_tail(cxp, src.crop_cols), P.hue_shift, H, L, S);
+                hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, hls_scalar_tail(mx + wx0 + x, src.crop_cols), P.hue_shift, H, L, S);
                 if (H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his)
-                    atomicOr(&mask[2 * y + (x >> 5)], 1u << (x & 31));
+                    atomicOr(&mask_d[2 * y + (x >> 5)], 1u << (x & 31));
             }
-            m0 = (uint64_t)mask[2 * lane] | ((uint64_t)mask[2 * lane + 1] << 32);
+            m0 = (uint64_t)mask_d[2 * lane] | ((uint64_t)mask_d[2 * lane + 1] << 32);
         }
     }
 
@@ -377,7 +373,9 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
             const uint64_t rowsb = __ballot(rem != 0);
             if (rowsb == 0) break;
             const int r0 = __builtin_ctzll(rowsb);
-            const uint64_t rv = shfl_u64(rem, r0);
+            // row r0 of `rem` for every lane: r0 is wave-uniform, so this is two v_readlane (no LDS permute)
+            const uint64_t rv = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rem, r0) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rem >> 32), r0) << 32);
             const int b0 = __builtin_ctzll(rv);
             uint64_t s = (lane == r0) ? (1ull << b0) : 0ull;
             for (;;) {
@@ -428,17 +426,12 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
         // passes of the reference (count / minimum, trimming, weighted mean) run over the cached values.  Walking
         // each row's bits per lane instead costs an atan per point and pass, times the longest row.
         const int rmine = __popcll(outer);
-        int rincl = rmine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(rincl, o, 64);
-            if (lane >= o) rincl += t;
-        }
-        const int rtotal = __shfl(rincl, 63, 64);
+        const int rincl = wave_scan_i32(rmine);
+        const int rtotal = __builtin_amdgcn_readlane(rincl, 63);
         if (rtotal <= RING_CAP) {
-            uint16_t* list = s_list[d];
-            double* ra = s_ra[d];
-            double* rd = s_rd[d];
+            uint16_t* list = ring_list;
+            double* ra = s_ra_d;
+            double* rd = s_rd_d;
             {
                 int at = rincl - rmine;
                 uint64_t bits = outer;
@@ -464,8 +457,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
                 rd[t] = dx * dx + dy * dy;
             }
             nk = wave_sum_i32(nk);
-#pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) mina = fmin(mina, __shfl_xor(mina, o2, 64));
+            mina = wave_min_f64(mina);
             if (nk == 0) {
                 status = 2;  // unreadable dial (_reading.py:79-81)
             } else {
@@ -517,8 +509,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
                 if (a < mina) mina = a;
             });
             nk = wave_sum_i32(nk);
-    #pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) mina = fmin(mina, __shfl_xor(mina, o2, 64));
+                mina = wave_min_f64(mina);
             if (nk == 0) {
                 status = 2;  // unreadable dial (_reading.py:79-81)
             } else {
@@ -594,15 +585,24 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS) void k_dials(DialsSrc src, mel
 
 void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& P, const DialGeom* d_geom,
                   const uint64_t* d_rowmasks, const MatchPartial* d_partials, int nparts, int rw,
-                  melf_result* d_results, hipStream_t stream)
+                  melf_result* d_results, hipStream_t stream, int ws_max)
 {
     dim3 grid(n), block(64 * P.ndials);
-    if (from_hls)
-        hipLaunchKernelGGL(k_dials<true>, grid, block, 0, stream, src, P, d_geom, d_rowmasks, d_partials, nparts, rw,
-                           d_results);
-    else
-        hipLaunchKernelGGL(k_dials<false>, grid, block, 0, stream, src, P, d_geom, d_rowmasks, d_partials, nparts, rw,
-                           d_results);
+    const size_t shmem = (size_t)P.ndials * DIAL_LDS_BYTES;
+    const int nr = ws_max <= 32 ? 32 : (ws_max <= 40 ? 40 : (ws_max <= 48 ? 48 : (ws_max <= 56 ? 56 : 64)));
+#define MELF_DIALS_LAUNCH(HLS, NRV) \
+    hipLaunchKernelGGL((k_dials<HLS, NRV>), grid, block, shmem, stream, src, P, d_geom, d_rowmasks, d_partials, nparts, rw, d_results)
+#define MELF_DIALS_NR(HLS)                                   \
+    switch (nr) {                                            \
+        case 32: MELF_DIALS_LAUNCH(HLS, 32); break;          \
+        case 40: MELF_DIALS_LAUNCH(HLS, 40); break;          \
+        case 48: MELF_DIALS_LAUNCH(HLS, 48); break;          \
+        case 56: MELF_DIALS_LAUNCH(HLS, 56); break;          \
+        default: MELF_DIALS_LAUNCH(HLS, 64); break;          \
+    }
+    if (from_hls) { MELF_DIALS_NR(true) } else { MELF_DIALS_NR(false) }
+#undef MELF_DIALS_NR
+#undef MELF_DIALS_LAUNCH
 }
 
 }  // namespace melf

@@ -217,6 +217,7 @@ struct melf_ctx {
     MatchGeom mg;
     uint32_t* d_tplT = nullptr;
     DialGeom* d_geom = nullptr;
+    int ws_max = 0;                      // largest dial window (rows) of the context
     uint64_t* d_rowmasks = nullptr;
     int8_t* d_atab = nullptr;            // Toeplitz template fragments of the MFMA match (NULL: template shape unsupported)
     long tsum = 0;
@@ -414,6 +415,7 @@ static int setup_device_tables(melf_ctx* c)
         G.core_x = (int)D.cx;  // int() truncation, meterelf/_reading.py:156
         G.core_y = (int)D.cy;
         if (G.ws > 64) return fail(MELF_ERR_TOO_LARGE, "dial mask radius > 29 px does not fit the 64x64 dial window");
+        if (G.ws > c->ws_max) c->ws_max = G.ws;
         const uint8_t* disk = c->h_masks.data() + (size_t)d * 2 * n;
         for (int pl = 0; pl < 2; ++pl)
             for (int y = 0; y < th; ++y)
@@ -809,7 +811,7 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
             ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
             {
                 KernelTimer t(c, MELF_K_DIALS, ls);
-                launch_dials(ds, false, m, P, c->d_geom, c->d_rowmasks, parts, nparts, rw, res_dev + g0, ls);
+                launch_dials(ds, false, m, P, c->d_geom, c->d_rowmasks, parts, nparts, rw, res_dev + g0, ls, c->ws_max);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -1071,7 +1073,7 @@ extern "C" int melf_read_dials(melf_ctx* c, const uint8_t* dials_hls_host, int n
     ds.x0 = 0; ds.y0 = 0; ds.crop_rows = P.th; ds.crop_cols = P.tw;
     {
         KernelTimer t(c, MELF_K_DIALS, c->stream);
-        launch_dials(ds, true, n, P, c->d_geom, c->d_rowmasks, nullptr, 0, 1, c->d_results, c->stream);
+        launch_dials(ds, true, n, P, c->d_geom, c->d_rowmasks, nullptr, 0, 1, c->d_results, c->stream, c->ws_max);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, c->d_results, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));

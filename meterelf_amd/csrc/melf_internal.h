@@ -112,7 +112,7 @@ struct DialsSrc {
 
 void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& P, const DialGeom* d_geom,
                   const uint64_t* d_rowmasks /* [ndials][3][64] */, const MatchPartial* d_partials,
-                  int nparts, int rw, melf_result* d_results, hipStream_t stream);
+                  int nparts, int rw, melf_result* d_results, hipStream_t stream, int ws_max /* largest DialGeom::ws */);
 
 // ---- K1b / HLS --------------------------------------------------------------
 void launch_bgr2hls(const uint8_t* d_src, int rows, int cols, size_t row_stride, int hue_shift,
