@@ -20,7 +20,16 @@ def load_template(params: Params) -> np.ndarray:
     from PIL import Image
     try:
         with Image.open(params.dials_file) as im:
-            template = np.ascontiguousarray(np.asarray(im.convert('L'), dtype=np.uint8))
+            if im.mode in ('L', '1', 'P') and im.mode != 'L':
+                im = im.convert('L')
+            if im.mode == 'L':
+                template = np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+            else:
+                # cv2.IMREAD_GRAYSCALE of a colour file: cv2's fixed-point BGR2GRAY (R 4899, G 9617, B 1868 of 2^14,
+                # rounded) -- Pillow's convert('L') uses other weights and truncation
+                rgb = np.asarray(im.convert('RGB'), dtype=np.int64)
+                template = np.ascontiguousarray(
+                    ((rgb[:, :, 0] * 4899 + rgb[:, :, 1] * 9617 + rgb[:, :, 2] * 1868 + 8192) >> 14).astype(np.uint8))
     except Exception:
         raise IOError("Cannot read dials template: {}".format(params.dials_file))
     assert template.shape == params.dials_template_size

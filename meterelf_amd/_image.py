@@ -1,8 +1,9 @@
 """Image loading for the path (reference: meterelf/_image.py:12-55).
 
-JPEG decode stays on the host (cv2.imread in the reference, Pillow's
-libjpeg-turbo here: ISLOW IDCT + fancy upsampling, same as cv2's defaults).
-Everything after the decode -- crop, HLS, dial finding -- happens on the GPU.
+Baseline JPEG files are decoded on the GPU (melf_jpeg_process_files, the default of get_meter_values); this module
+is the HOST decoder behind cv2.imread's other cases -- formats the GPU decoder does not take (PNG, progressive or
+CMYK JPEG ...), files it reports as corrupt, and METERELF_DECODE=host -- with Pillow's libjpeg-turbo (ISLOW IDCT +
+fancy upsampling, cv2's defaults).  Everything after the decode -- crop, HLS, dial finding -- happens on the GPU.
 """
 from typing import Optional
 
@@ -13,12 +14,19 @@ from .exceptions import ImageLoadingError
 
 
 def imread_bgr(filename: str) -> Optional[np.ndarray]:
-    """cv2.imread(filename): H x W x 3 uint8 BGR, or None if unreadable."""
-    from PIL import Image
+    """cv2.imread(filename): H x W x 3 uint8 BGR, or None if unreadable.
+
+    Like cv2.imread (OpenCV 3.4): a truncated file yields the part libjpeg could decode (the rest grey) instead of an
+    error, and the EXIF orientation tag is applied."""
+    from PIL import Image, ImageFile, ImageOps
     try:
+        ImageFile.LOAD_TRUNCATED_IMAGES = True
         with Image.open(filename) as im:
+            im = ImageOps.exif_transpose(im)
             rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
     except Exception:
+        return None
+    if rgb.ndim != 3 or rgb.shape[0] == 0 or rgb.shape[1] == 0:
         return None
     return np.ascontiguousarray(rgb[:, :, ::-1])
 

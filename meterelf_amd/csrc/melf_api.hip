@@ -1242,17 +1242,31 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
     if (n == 0) return MELF_SUCCESS;
     if (!paths || !out_host || !status || !H_used || !W_used || n < 0 || n > 32768) return fail(MELF_ERR_INVALID, "bad argument");
-    std::vector<std::vector<uint8_t>> blobs(n);
-    std::vector<int> hs(n, 0), ws(n, 0), oks(n, 0);
+    std::vector<std::vector<uint8_t>> blobs;
+    std::vector<int> hs, ws, oks;
+    try {
+        blobs.resize(n);
+        hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0);
+    } catch (const std::exception&) {
+        return fail(MELF_ERR_INVALID, "out of host memory");
+    }
     {
+        // a camera frame is tens of KiB; a "JPEG" of more than 64 MiB is not one of ours (and n of them would not fit)
+        const long max_file = 64L << 20;
         host_pool().run(n, [&](int i) {
             FILE* fp = paths[i] ? fopen(paths[i], "rb") : nullptr;
             if (!fp) { status[i] = MELF_JPEG_UNREADABLE; return; }
             fseek(fp, 0, SEEK_END);
             const long sz = ftell(fp);
             fseek(fp, 0, SEEK_SET);
-            if (sz <= 0 || sz > (1L << 30)) { fclose(fp); status[i] = MELF_JPEG_UNREADABLE; return; }
-            blobs[i].resize((size_t)sz);
+            if (sz <= 0 || sz > max_file) { fclose(fp); status[i] = sz > max_file ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_UNREADABLE; return; }
+            try {  // nothing may escape a pool task (melf_threads.h)
+                blobs[i].resize((size_t)sz);
+            } catch (const std::exception&) {
+                fclose(fp);
+                status[i] = MELF_JPEG_UNREADABLE;
+                return;
+            }
             const size_t got = fread(blobs[i].data(), 1, (size_t)sz, fp);
             fclose(fp);
             if (got != (size_t)sz) { blobs[i].clear(); status[i] = MELF_JPEG_UNREADABLE; return; }

@@ -29,7 +29,9 @@ public:
     }
     int size() const { return (int)workers_.size(); }
 
-    // fn(i) for i in [0, n): indices are handed out in small blocks; the caller works too and returns when all are done
+    // fn(i) for i in [0, n): indices are handed out in small blocks; the caller works too and returns when all are done.
+    // fn must not throw: an exception on a worker would terminate the process, one on the caller would unwind past
+    // workers that still dereference fn_.  Callers that can fail (allocation, I/O) catch inside fn and record a status.
     void run(int n, const std::function<void(int)>& fn)
     {
         if (n <= 0) return;
@@ -90,11 +92,13 @@ private:
     bool stop_ = false;
 };
 
-// one pool per process, created on first use
+// One pool per process, created on first use and deliberately never destroyed: a destructor that joins the workers
+// would hang exit() in a forked child (the threads exist in the parent only), and at process exit the threads go away
+// with the process anyway.
 inline WorkerPool& host_pool()
 {
-    static WorkerPool pool((int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 2u) - 1u, 15u));
-    return pool;
+    static WorkerPool* pool = new WorkerPool((int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 2u) - 1u, 15u));
+    return *pool;
 }
 
 }  // namespace melf
