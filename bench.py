@@ -237,9 +237,10 @@ def match_roofline(P, H, W, kt, frames_total, traffic_entry):
 
 
 def kernel_sources_sha():
+    """Hash of the kernel sources (k_*.hip and the device header): what the measured HBM traffic depends on."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'meterelf_amd', 'csrc', '*.hip')) +
-                    glob.glob(os.path.join(ROOT, 'meterelf_amd', 'csrc', '*.h'))):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'meterelf_amd', 'csrc', 'k_*.hip')) +
+                    [os.path.join(ROOT, 'meterelf_amd', 'csrc', 'melf_device.h')]):
         with open(f, 'rb') as fp:
             h.update(fp.read())
     return h.hexdigest()[:16]

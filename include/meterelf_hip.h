@@ -19,10 +19,11 @@
  * which is also what torch's default stream handle 0 means) without synchronising
  * it unless stated: work the caller enqueued on `stream` before the call is seen
  * by the kernels, and whatever the caller enqueues on it afterwards sees the
- * records.  The work buffers belong to the context: if consecutive *_dev calls
- * arrive on different streams, the library orders the later stream after the
- * earlier call by an event, so a context can be moved between streams but never
- * runs two batches' kernels against the same buffers at once.
+ * records.  A context owns two sets of work buffers ("lanes") and hands a lane
+ * to each caller stream: *_dev calls that arrive on two different streams run
+ * concurrently on the GPU, a third stream (or a call that needs the lane
+ * another stream used last) is ordered behind that stream's work by an event.
+ * Two batches' kernels never run against the same buffers at once.
  */
 #ifndef METERELF_HIP_H
 #define METERELF_HIP_H
@@ -119,6 +120,9 @@ int melf_blob_params(const void* blob, size_t blob_bytes, melf_params* out);
 int melf_ctx_create(int device, const void* blob, size_t blob_bytes, int blob_on_device, melf_ctx** out);
 void melf_ctx_destroy(melf_ctx* ctx);
 int melf_ctx_params(const melf_ctx* ctx, melf_params* out);
+/* Waits for all work the context has enqueued on caller streams and forgets those streams.  Call it before
+ * destroying a stream that *_dev calls of this context were issued on. */
+int melf_ctx_sync(melf_ctx* ctx);
 /* copy the context's dial masks back (tests) */
 int melf_ctx_get_masks(const melf_ctx* ctx, uint8_t* masks);
 
@@ -126,7 +130,9 @@ int melf_ctx_get_masks(const melf_ctx* ctx, uint8_t* masks);
  * (meterelf/_reading.py:19-115 with meterelf/_image.py:23-66) ---------------
  * frames: n full camera frames, H x W x 3 u8 BGR (cv2.imread layout), frame f at
  * frames + f*frame_stride bytes.  The meter_rect crop is taken inside, with
- * numpy-slice clamping (meterelf/_image.py:54-55). */
+ * numpy-slice clamping (meterelf/_image.py:54-55).  Host frames: only that crop
+ * crosses PCIe (packed by host threads into pinned staging buffers, copied by
+ * DMA in chunks that overlap the previous chunk's kernels). */
 int melf_process_batch(melf_ctx* ctx, const uint8_t* frames_host, int n, int H, int W,
                        size_t frame_stride, melf_result* out_host);
 /* frames already in HBM; results go to d_results (device, may be NULL) and/or

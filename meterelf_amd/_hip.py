@@ -61,7 +61,7 @@ class HipError(RuntimeError):
 EXPORTS = [
     'melf_last_error', 'melf_abi_version', 'melf_device_count', 'melf_build_dial_masks',
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
-    'melf_ctx_params', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
+    'melf_ctx_params', 'melf_ctx_sync', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
@@ -96,6 +96,7 @@ def lib():
     L.melf_ctx_destroy.restype = None
     L.melf_ctx_params.argtypes = [vp, C.POINTER(MelfParams)]
     L.melf_ctx_get_masks.argtypes = [vp, vp]
+    L.melf_ctx_sync.argtypes = [vp]
     L.melf_process_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp]
     L.melf_process_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]
     L.melf_process_stream_dev.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, vp]
@@ -213,6 +214,10 @@ class Context:
         self.device = device
         self.params = MelfParams()
         check(L.melf_ctx_params(self._h, C.byref(self.params)))
+
+    def sync(self):
+        """Waits for the context's work on every caller stream and forgets the streams (call before destroying one)."""
+        check(self._L.melf_ctx_sync(self._h))
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:

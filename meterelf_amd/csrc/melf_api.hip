@@ -555,6 +555,21 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     delete c;
 }
 
+// Waits for everything the context has enqueued on the caller streams it has been used with, and forgets those
+// streams: call it before destroying a stream the context has worked on (a lane would otherwise still name it).
+extern "C" int melf_ctx_sync(melf_ctx* c)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int l = 0; l < melf_ctx::NLANES; ++l) {
+        if (c->lane_owned[l]) HIP_TRY(hipStreamSynchronize(c->lane_owner[l]));
+        c->lane_owned[l] = false;
+        c->lane_owner[l] = nullptr;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MELF_SUCCESS;
+}
+
 extern "C" int melf_ctx_params(const melf_ctx* c, melf_params* out)
 {
     if (!c || !out) return fail(MELF_ERR_INVALID, "NULL argument");

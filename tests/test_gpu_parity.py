@@ -798,3 +798,45 @@ def test_full_path_with_either_matrix_core_kernel(env, monkeypatch, sd, kind):
         r.close()
     _compare_records(recs, ores, tag=kind)
     assert recs2.tobytes() == recs[:33].tobytes()
+
+
+def test_two_caller_streams_use_two_lanes(env):
+    """A context gives each caller stream its own lane: two batches enqueued on two streams run concurrently and give
+    the records of serial calls; a third stream has to take a lane over (ordered by an event) and is right too."""
+    import ctypes as C
+    from meterelf_amd import _hip
+    e = env['sample-images1']
+    frames = synth_frames(_good(e['files']), 192, 123)
+    ctx = e['reader'].ctx
+    ref = ctx.process_batch(frames)
+    hip = C.CDLL('libamdhip64.so')
+    (n, H, W) = (64, frames.shape[1], frames.shape[2])
+    rsz = _hip.RESULT_DTYPE.itemsize
+    (d_frames, d_res) = (C.c_void_p(), C.c_void_p())
+    streams = [C.c_void_p() for _ in range(3)]
+    assert hip.hipMalloc(C.byref(d_frames), C.c_size_t(frames.nbytes)) == 0
+    assert hip.hipMalloc(C.byref(d_res), C.c_size_t(len(frames) * rsz)) == 0
+    for s in streams:
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0   # hipStreamNonBlocking
+    try:
+        assert hip.hipMemcpy(d_frames, frames.ctypes.data_as(C.c_void_p), C.c_size_t(frames.nbytes), 1) == 0
+        for rep in range(3):       # several rounds: lanes are re-used, the third stream keeps taking one over
+            assert hip.hipMemset(d_res, 0, C.c_size_t(len(frames) * rsz)) == 0
+            assert hip.hipDeviceSynchronize() == 0
+            for b in range(3):
+                ctx.process_batch_dev(d_frames.value + b * n * H * W * 3, n, H, W, d_results_ptr=d_res.value + b * n * rsz,
+                                      want_host=False, stream=streams[(b + rep) % 3].value)
+            assert hip.hipDeviceSynchronize() == 0
+            got = np.zeros(len(frames), _hip.RESULT_DTYPE)
+            assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d_res, C.c_size_t(got.nbytes), 2) == 0
+            assert got.tobytes() == ref.tobytes(), rep
+        # the null stream (stream = NULL) is a stream like any other
+        assert hip.hipMemset(d_res, 0, C.c_size_t(n * rsz)) == 0
+        out = ctx.process_batch_dev(d_frames.value, n, H, W, want_host=True, stream=None)
+        assert out.tobytes() == ref[:n].tobytes()
+    finally:
+        ctx.sync()   # the context forgets the streams before they are destroyed
+        for s in streams:
+            hip.hipStreamDestroy(s)
+        hip.hipFree(d_frames)
+        hip.hipFree(d_res)

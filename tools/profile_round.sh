@@ -1,21 +1,68 @@
 #!/bin/bash
-# Collects the round's profiles on the GPU box: kernel-trace stats of the default bench command, then HBM
-# traffic counters (FETCH_SIZE, WRITE_SIZE in separate --pmc passes, as MI355X_MICROARCH.md prescribes) for
-# the fused-mask stage, the full pipeline and the JPEG path.  Writes small summaries under gpurun_out/prof/.
+# Collects a round's profiles on the GPU box:  tools/profile_round.sh r02
+#  * rocprofv3 --kernel-trace --stats of the DEFAULT bench command (per-kernel average durations)
+#  * HBM traffic counters, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md: they do not fit one
+#    pass; FETCH_SIZE is doubled for wide coalesced reads on gfx950), for each workload bench.py reports a roofline on:
+#      config3  full path, sample-images1, 1024 frames per launch, four batches in rotation
+#      config4  full path, sample-images2
+#      config2  fused mask, B=256 640x480, four buffer pairs in rotation
+#      config5  fused mask, 1080p, B=512
+#      jpeg     1024 fixture files
+#  * traffic.json: bytes per launch for bench.py, stamped with the hash of the kernel sources they were measured on
+# Everything lands in gpurun_out/prof_<round>/; copy it to profiles/<round>/ to commit it.
 set -e
 export TMPDIR=/tmp
-OUT=gpurun_out/prof
+R=${1:-r02}
+OUT=gpurun_out/prof_$R
 rm -rf $OUT /tmp/prof && mkdir -p $OUT /tmp/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python3 bench.py --steps 20 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 f=$(find /tmp/prof/stats -name '*kernel_stats.csv' | head -1)
 head -1 "$f" > $OUT/bench_kernel_stats.csv
 grep -i 'melf' "$f" >> $OUT/bench_kernel_stats.csv || true
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv --kernel-include-regex 'melf' -d /tmp/prof/pmc_fused_$c -- python3 tools/run_stage.py fused --iters 5 > /dev/null 2>&1
-  rocprofv3 --pmc $c --output-format csv --kernel-include-regex 'melf' -d /tmp/prof/pmc_full_$c -- python3 tools/run_stage.py full --iters 5 > /dev/null 2>&1
-  rocprofv3 --pmc $c --output-format csv --kernel-include-regex 'melf' -d /tmp/prof/pmc_jpeg_$c -- python3 tools/jpeg_timing.py sample-images1 1024 > /dev/null 2>&1
-done
-python3 tools/pmc_summary.py /tmp/prof/pmc_fused_FETCH_SIZE /tmp/prof/pmc_fused_WRITE_SIZE > $OUT/pmc_fused.txt
-python3 tools/pmc_summary.py /tmp/prof/pmc_full_FETCH_SIZE /tmp/prof/pmc_full_WRITE_SIZE > $OUT/pmc_full.txt
-python3 tools/pmc_summary.py /tmp/prof/pmc_jpeg_FETCH_SIZE /tmp/prof/pmc_jpeg_WRITE_SIZE > $OUT/pmc_jpeg.txt
-cat $OUT/pmc_fused.txt $OUT/pmc_full.txt $OUT/pmc_jpeg.txt
+echo "kernel stats done" >> $OUT/progress.txt
+pmc() {  # name, command...
+  name=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv --kernel-include-regex 'melf' -d /tmp/prof/pmc_${name}_$c -- "$@" > /dev/null 2>&1
+  done
+  python3 tools/pmc_summary.py /tmp/prof/pmc_${name}_FETCH_SIZE /tmp/prof/pmc_${name}_WRITE_SIZE > $OUT/pmc_$name.txt
+  echo "pmc $name done" >> $OUT/progress.txt
+}
+pmc config3 python3 tools/run_stage.py full --iters 8
+pmc config4 python3 tools/run_stage.py full --iters 8 --sample-dir sample-images2
+pmc config2 python3 tools/run_stage.py fused --iters 8
+pmc config5 python3 tools/run_stage.py fused --iters 4 --hw 1080x1920 --batch 512 --nbuf 1
+pmc jpeg python3 tools/jpeg_timing.py sample-images1 1024
+python3 - "$OUT" <<'PY'
+import json, os, re, sys
+sys.path.insert(0, os.getcwd())
+import bench
+out = sys.argv[1]
+def load(name):
+    d = {}
+    for ln in open(os.path.join(out, 'pmc_%s.txt' % name)):
+        m = re.match(r'(\S+)\s+(\S+)\s+n=\d+\s+mean=(\S+)', ln)
+        if m:
+            d.setdefault(m.group(1), {})[m.group(2)] = float(m.group(3))
+    return d
+def bytes_of(k):  # KiB counters; FETCH_SIZE doubled (gfx950 wide coalesced reads)
+    return int(round((2 * k.get('FETCH_SIZE', 0.0) + k.get('WRITE_SIZE', 0.0)) * 1024))
+per = {}
+detail = {}
+for (cfg, kernels) in (('config3', ('k_match_mfma', 'k_match_gen', 'k_prep_lplane', 'k_colsum', 'k_dials')),
+                       ('config4', ('k_match_mfma', 'k_match_gen', 'k_prep_lplane', 'k_colsum', 'k_dials')),
+                       ('config2', ('k_fused_mask',)), ('config5', ('k_fused_mask',)),
+                       ('jpeg', ('k_jpeg_huff', 'k_jpeg_idct', 'k_jpeg_color'))):
+    d = load(cfg)
+    for k in kernels:
+        if k in d:
+            short = 'k_match' if k.startswith('k_match') else k
+            detail['%s:%s' % (cfg, k)] = bytes_of(d[k])
+            per['%s:%s' % (cfg, short)] = bytes_of(d[k])
+json.dump({'_note': 'HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes '
+                    '(tools/profile_round.sh; raw counters: pmc_*.txt next to this file)',
+           'kernel_sources_sha16': bench.kernel_sources_sha(), 'per_launch_bytes': per, 'per_kernel': detail},
+          open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
+print(json.dumps(per, indent=1))
+PY
+cat $OUT/bench_kernel_stats.csv | cut -c1-200
