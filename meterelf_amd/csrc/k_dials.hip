@@ -149,9 +149,14 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_dials_stamps(ui
 #define DSTAMP(k) do { } while (0)
 #endif
 
+// Register budget: 104 of the SIMD's 512 ("amdgpu-num-vgpr" is doubled by the backend for gfx90a+'s unified file), so that a
+// wave of this kernel fits beside a resident k_match_mfma wave (408) when two caller streams drive the context's lanes.
+#ifndef MELF_DIALS_VGPRS
+#define MELF_DIALS_VGPRS 52
+#endif
 // NR: window rows whose pixels a lane requests up front (the largest dial window of the context, rounded up to 8)
 template <bool FROM_HLS, int NR>
-__global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) void k_dials(DialsSrc src, melf_params P,
+__global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_vgpr(MELF_DIALS_VGPRS))) void k_dials(DialsSrc src, melf_params P,
                                                               const DialGeom* __restrict__ geom,
                                                               const uint64_t* __restrict__ rowmasks,
                                                               const MatchPartial* __restrict__ partials,

@@ -296,9 +296,12 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                 // first use and waits vmcnt(0) every ten MFMAs: 26 % MFMA utilisation.)
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
-                    // image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD
+                    // Image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD.  Its fragment kb is
+                    // requested one sub-block AFTER this step's last read of the oldest row's fragment kb (sub-block kb,
+                    // xb = 0): the two never live at once, so the incoming row shares the oldest row's registers and
+                    // the ring costs R rows + a fragment or two instead of R + 1 rows.
 #pragma unroll
-                    for (int kb = d; kb < (d == ND - 1 ? NKB : d + 1); ++kb)
+                    for (int kb = (d == 0 ? NKB : d - 1); kb < (d == 0 ? NKB : d); ++kb)
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -311,6 +314,11 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                     // fragment d of template row i + 1 (the table carries one extra all-zero row), into the registers the
                     // MFMAs above have just read: issued in the shadow of the running MFMAs
                     a[d] = Ap[((size_t)(i + 1) * ND + d) * 64];
+                    if (d == ND - 1) {  // the incoming row's last fragments
+#pragma unroll
+                        for (int kb = ND - 1; kb < NKB; ++kb)
+                            buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -392,8 +400,14 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 }
 
 
+// Register budget of the kernel.  "amdgpu-num-vgpr" counts architectural VGPRs and the backend doubles it for the unified
+// register file of gfx90a+ (VGPRs + AGPRs): 204 -> 408 of the SIMD's 512, which leaves 104 -- one wave of k_dials -- per
+// SIMD for the other pipeline lane's kernels while a match wave is resident.
+#ifndef MELF_MATCH_VGPRS
+#define MELF_MATCH_VGPRS 204
+#endif
 template <int ND, int NXB, int R, int PD>
-__global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
+__global__ __launch_bounds__(64, 1) __attribute__((amdgpu_num_vgpr(MELF_MATCH_VGPRS))) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                                       const uint32_t* __restrict__ ws, MfmaGeom g,
                                                       float* __restrict__ result_map, MatchPartial* __restrict__ partials)
 {

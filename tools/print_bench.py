@@ -10,6 +10,9 @@ print('  kernels ms', d.get('kernel_ms'), '| k_match %.4f ms frac %.4f' % (r.get
 s = d.get('sustained')
 if s:
     print('  sustained %.4f ms/step over %.2f s, k_match %.4f ms frac %.4f' % (s['ms_per_step'], s['seconds'], s['k_match_avg_launch_ms'], s['k_match_frac']))
+t = d.get('two_streams')
+if t:
+    print('  two streams %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t['records_identical_to_single_stream']))
 f = d.get('fused_mask')
 if f:
     print('  fused (config 2) %.4f ms  %.0f GB/s  frac %.4f' % (f['roofline']['avg_launch_ms'], f['roofline']['achieved'], f['roofline']['frac']))
@@ -17,6 +20,8 @@ c = d.get('config4')
 if c:
     print('  config4 %.0f frames/s  %.4f ms/step  kernels %s  k_match frac %.4f  mism %s' % (
         c['frames_per_s'], c['ms_per_step'], c['kernel_ms'], c['roofline']['frac'], (c.get('cpu_baseline') or {}).get('parity_mismatches_vs_gpu')))
+    if c.get('two_streams'):
+        print('    two streams %.4f ms/step  %.0f frames/s' % (c['two_streams']['ms_per_step'], c['two_streams']['frames_per_s']))
 c = d.get('config5')
 if c:
     fm = c['fused_mask']['roofline']
