@@ -40,6 +40,11 @@ import time
 
 import numpy as np
 
+# Streams only overlap on the GPU if they sit on different hardware queues, and the HIP runtime spreads ALL of a process's
+# streams (torch creates pools of them) over GPU_MAX_HW_QUEUES = 4 queues by default: with four, the two caller streams of
+# the `two_streams` block shared a queue on some runs and did not overlap at all.  Must be set before HIP initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -399,6 +404,24 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
     alg_bytes = FB * H * W * 4   # 3 B/px read + 1 B/px written
     gbs = alg_bytes / (favg * 1e-3) / 1e9
     (tr, src) = traffic.get(label + ':k_fused_mask')
+    # the same launches alternating between two streams: one launch's ramp-up fills the other's tail
+    two = None
+    if nbuf >= 2:
+        def launch2(i):
+            b = i % nbuf
+            ctx.hls_inrange_close_dev(frames.data_ptr() + b * FB * H * W * 3, FB, H, W, masks.data_ptr() + b * FB * H * W,
+                                      stream=env.stream_objs[i % 2].cuda_stream)
+        for i in range(4):
+            launch2(i)
+        env.sync()
+        n2 = max(steps, 40)
+        t20 = time.perf_counter()
+        for i in range(n2):
+            launch2(i)
+        env.sync()
+        t2 = time.perf_counter() - t20
+        two = {'launches': n2, 'ms_per_launch': round(t2 / n2 * 1e3, 4), 'GBps': round(alg_bytes * n2 / t2 / 1e9, 1),
+               'frac_of_hbm_peak': round(alg_bytes * n2 / t2 / 1e9 / HBM_PEAK_GBS, 4)}
     del masks
     return {
         'workload': 'B=%d %dx%d uniform-random u8 frames, fused HLS+inRange+closing only, %d distinct buffer pairs '
@@ -408,6 +431,7 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
                      'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': tr, 'traffic_source': src,
                      'avg_launch_ms': round(favg, 4), 'launches': fn,
                      'algorithmic': '%d B/frame x %d frames/launch' % (H * W * 4, FB)},
+        'two_streams': two,
     }
 
 

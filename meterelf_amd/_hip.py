@@ -8,6 +8,11 @@ import os
 
 import numpy as np
 
+# Streams overlap on the GPU only if they sit on different hardware queues; the HIP runtime spreads all of a process's
+# streams over GPU_MAX_HW_QUEUES = 4 by default.  Eight keeps the context's two lanes (two caller streams) apart from each
+# other and from the copy stream in practice.  Read when HIP initialises: harmless if that has already happened.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MELF_LIB_PATH') or os.path.join(_PKG, 'libmeterelf_hip.so')  # override: A/B builds
 

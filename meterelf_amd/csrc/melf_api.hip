@@ -229,22 +229,22 @@ struct melf_ctx {
         int rows, cols, groups;
         GenPlan plan;
         GenDev dev;
-        void* part[2] = {nullptr, nullptr};
-        int* counters[2] = {nullptr, nullptr};
+        void* part[4] = {nullptr, nullptr, nullptr, nullptr};       // per pipeline lane (NLANES)
+        int* counters[4] = {nullptr, nullptr, nullptr, nullptr};
     };
     std::vector<GenEntry*> gen_cache;
-    // two pipeline lanes: a batch is split in halves that run on separate streams, so that one
-    // half's VALU-bound kernels (prep, dials) overlap the other half's matrix-core-bound match
-    static const int NLANES = 2;
+    // pipeline lanes: sets of work buffers that can be in flight at once (one per caller stream, up to NLANES), so that
+    // one batch's VALU-bound kernels (prep, dials) overlap another batch's matrix-core-bound match
+    static const int NLANES = 2;   // three or four lanes (and as many caller streams) measured no faster than two
     int active_lane = 0;                 // melf_process_stream_dev: which lane's work buffers the next batch uses
     int lanes = 1;                       // MELF_LANES=2 enables the split (measured slower on MI355X: the two
                                          // half-batch match kernels do not overlap usefully; kept for experiments)
-    hipStream_t lane_stream[NLANES] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {nullptr, nullptr};
-    int8_t* d_lg[NLANES] = {nullptr, nullptr}; size_t lg_cap[NLANES] = {0, 0};
-    uint16_t* d_rsum[NLANES] = {nullptr, nullptr}; size_t rsum_cap[NLANES] = {0, 0};
-    uint32_t* d_wsum[NLANES] = {nullptr, nullptr}; size_t wsum_cap[NLANES] = {0, 0};
-    MatchPartial* d_lpart[NLANES] = {nullptr, nullptr}; size_t lpart_cap[NLANES] = {0, 0};
+    hipStream_t lane_stream[NLANES] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {};
+    int8_t* d_lg[NLANES] = {}; size_t lg_cap[NLANES] = {};
+    uint16_t* d_rsum[NLANES] = {}; size_t rsum_cap[NLANES] = {};
+    uint32_t* d_wsum[NLANES] = {}; size_t wsum_cap[NLANES] = {};
+    MatchPartial* d_lpart[NLANES] = {}; size_t lpart_cap[NLANES] = {};
     uint32_t* d_fused_tables = nullptr;  // K1b lookup tables (built on the GPU at creation)
     int fused_ambiguous = 0;             // hue-table entries whose answer depends on float32 rounding of the triple
     int fused_active_sectors = 0;        // bit c: hue sector c (max = r/g/b) has in-range entries
@@ -272,9 +272,9 @@ struct melf_ctx {
     // arrive on two different streams run on the two lanes and overlap on the GPU (one batch's prep / dials kernels in
     // the shadow of the other's match kernel); a third stream, or a call that needs a particular lane, first waits for
     // what the lane's previous stream enqueued (claim_lane).
-    hipStream_t lane_owner[NLANES] = {nullptr, nullptr};
-    bool lane_owned[NLANES] = {false, false};
-    uint64_t lane_used[NLANES] = {0, 0};
+    hipStream_t lane_owner[NLANES] = {};
+    bool lane_owned[NLANES] = {};
+    uint64_t lane_used[NLANES] = {};
     uint64_t use_clock = 0;
     hipEvent_t ev_order = nullptr;
     std::vector<TimedEvent> events;
@@ -532,7 +532,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     hipFree(c->d_atab);
     for (auto* ge : c->gen_cache) {
         hipFree(ge->dev.atab); hipFree(ge->dev.atabv); hipFree(ge->dev.tasks);
-        for (int l = 0; l < 2; ++l) { hipFree(ge->part[l]); hipFree(ge->counters[l]); }
+        for (int l = 0; l < melf_ctx::NLANES; ++l) { hipFree(ge->part[l]); hipFree(ge->counters[l]); }
         delete ge;
     }
     for (int l = 0; l < melf_ctx::NLANES; ++l) {
@@ -659,7 +659,7 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
         HIP_TRY(hipDeviceSynchronize());
         auto* old = c->gen_cache.front();
         hipFree(old->dev.atab); hipFree(old->dev.atabv); hipFree(old->dev.tasks);
-        for (int l = 0; l < 2; ++l) { hipFree(old->part[l]); hipFree(old->counters[l]); }
+        for (int l = 0; l < melf_ctx::NLANES; ++l) { hipFree(old->part[l]); hipFree(old->counters[l]); }
         delete old;
         c->gen_cache.erase(c->gen_cache.begin());
     }
@@ -806,7 +806,7 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
     }
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
         const int mtot = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
-        const int nl = split ? melf_ctx::NLANES : 1;
+        const int nl = split ? c->lanes : 1;
         const int per = split ? ((mtot / nl + 31) / 32) * 32 : mtot;
         for (int l = 0; l < nl; ++l) {
             const int g0 = f0 + l * per;

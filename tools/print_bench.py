@@ -15,7 +15,7 @@ if t:
     print('  two streams %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t['records_identical_to_single_stream']))
 f = d.get('fused_mask')
 if f:
-    print('  fused (config 2) %.4f ms  %.0f GB/s  frac %.4f' % (f['roofline']['avg_launch_ms'], f['roofline']['achieved'], f['roofline']['frac']))
+    print('  fused (config 2) %.4f ms  %.0f GB/s  frac %.4f  | two streams %s' % (f['roofline']['avg_launch_ms'], f['roofline']['achieved'], f['roofline']['frac'], f.get('two_streams')))
 c = d.get('config4')
 if c:
     print('  config4 %.0f frames/s  %.4f ms/step  kernels %s  k_match frac %.4f  mism %s' % (
