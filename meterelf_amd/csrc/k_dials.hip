@@ -594,7 +594,7 @@ void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& 
 {
     dim3 grid(n), block(64 * P.ndials);
     const size_t shmem = (size_t)P.ndials * DIAL_LDS_BYTES;
-    const int nr = ws_max <= 32 ? 32 : (ws_max <= 40 ? 40 : (ws_max <= 48 ? 48 : (ws_max <= 56 ? 56 : 64)));
+    const int nr = ws_max <= 32 ? 32 : (ws_max <= 40 ? 40 : (ws_max <= 48 ? 48 : (ws_max <= 52 ? 52 : (ws_max <= 56 ? 56 : 64))));
 #define MELF_DIALS_LAUNCH(HLS, NRV) \
     hipLaunchKernelGGL((k_dials<HLS, NRV>), grid, block, shmem, stream, src, P, d_geom, d_rowmasks, d_partials, nparts, rw, d_results)
 #define MELF_DIALS_NR(HLS)                                   \
@@ -602,6 +602,7 @@ void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& 
         case 32: MELF_DIALS_LAUNCH(HLS, 32); break;          \
         case 40: MELF_DIALS_LAUNCH(HLS, 40); break;          \
         case 48: MELF_DIALS_LAUNCH(HLS, 48); break;          \
+        case 52: MELF_DIALS_LAUNCH(HLS, 52); break;          \
         case 56: MELF_DIALS_LAUNCH(HLS, 56); break;          \
         default: MELF_DIALS_LAUNCH(HLS, 64); break;          \
     }
