@@ -68,7 +68,7 @@ EXPORTS = [
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_sync', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
-    'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
+    'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
     'melf_jpeg_process_files',
 ]
@@ -114,6 +114,7 @@ def lib():
     L.melf_inrange.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.melf_ctx_fused_table_ties.argtypes = [vp, C.POINTER(C.c_int)]
     L.melf_ctx_set_profiling.argtypes = [vp, C.c_int]
+    L.melf_ctx_set_frames_resident.argtypes = [vp, C.c_int]
     L.melf_ctx_timings.argtypes = [vp, vp, vp]
     i32p = C.POINTER(C.c_int32)
     L.melf_jpeg_probe.argtypes = [vp, C.c_size_t, i32p, i32p, i32p]
@@ -378,6 +379,11 @@ class Context:
             arr = (C.c_char_p * n)(*enc)
             check(self._L.melf_jpeg_process_files(self._h, arr, n, C.byref(H), C.byref(W), _ptr(out), _ptr(status)))
         return out, status, (H.value, W.value)
+
+    def set_frames_resident(self, on):
+        """Promise that the frames of every process_batch_dev call are complete in HBM when the call is made: a call's prep
+        kernels then run under the previous call's dials kernel (melf_ctx_set_frames_resident)."""
+        check(self._L.melf_ctx_set_frames_resident(self._h, int(bool(on))))
 
     def set_profiling(self, on):
         check(self._L.melf_ctx_set_profiling(self._h, int(on)))  # False/0 off, True/1 every kernel, 2 only k_match

@@ -23,6 +23,7 @@
 // (tools/ubench/mfma_i8_layout.hip): A lane l = A[l & 31][16 (l >> 5) + j],
 // B lane l = B[16 (l >> 5) + j][l & 31], D lane l reg r = D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
 #include <limits.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -532,7 +533,9 @@ void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, in
     const size_t pre_bytes = (size_t)32 * (nkb * 32 + 8) * sizeof(int16_t);
     // row chunks of the column-sum pass: at most 96 KiB of LDS per workgroup
     const int max_in = 96 * 1024 / 256;
-    const int ychunk = rh + th - 1 <= max_in ? rh : std::max(1, max_in - (th - 1));
+    int ychunk = rh + th - 1 <= max_in ? rh : std::max(1, max_in - (th - 1));
+    static const int want_chunks = getenv("MELF_COLSUM_CHUNKS") ? atoi(getenv("MELF_COLSUM_CHUNKS")) : 1;  // experiments
+    if (want_chunks > 1) ychunk = std::min(ychunk, (rh + want_chunks - 1) / want_chunks);
     const int nchunks = (rh + ychunk - 1) / ychunk;
     const size_t col_bytes = (size_t)(std::min(rh, ychunk) + th - 1) * 128 * sizeof(uint16_t);
     int dev = 0;

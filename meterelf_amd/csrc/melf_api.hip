@@ -272,6 +272,15 @@ struct melf_ctx {
     // arrive on two different streams run on the two lanes and overlap on the GPU (one batch's prep / dials kernels in
     // the shadow of the other's match kernel); a third stream, or a call that needs a particular lane, first waits for
     // what the lane's previous stream enqueued (claim_lane).
+    // "Frames resident" (melf_ctx_set_frames_resident): the caller guarantees that the frames of a *_dev call are complete in
+    // memory when the call is made.  A call's prep kernels (which only read frames and write the lane's work buffers)
+    // then run on the lane's side stream as soon as the lane's previous match kernel is done, i.e. under the previous
+    // call's dials kernel, instead of behind it.
+    bool frames_resident = false;
+    bool ahead_ok = false;               // set by the entry points that may use it, for the duration of the call
+    hipStream_t side_stream[NLANES] = {};
+    hipEvent_t ev_match_done[NLANES] = {}, ev_prep_done[NLANES] = {};
+    bool match_done_valid[NLANES] = {};
     hipStream_t lane_owner[NLANES] = {};
     bool lane_owned[NLANES] = {};
     uint64_t lane_used[NLANES] = {};
@@ -542,6 +551,11 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_order) hipEventDestroy(c->ev_order);
+    for (int l = 0; l < melf_ctx::NLANES; ++l) {
+        if (c->side_stream[l]) hipStreamDestroy(c->side_stream[l]);
+        if (c->ev_match_done[l]) hipEventDestroy(c->ev_match_done[l]);
+        if (c->ev_prep_done[l]) hipEventDestroy(c->ev_prep_done[l]);
+    }
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
     hipFree(c->d_crops);
@@ -565,6 +579,7 @@ extern "C" int melf_ctx_sync(melf_ctx* c)
         if (c->lane_owned[l]) HIP_TRY(hipStreamSynchronize(c->lane_owner[l]));
         c->lane_owned[l] = false;
         c->lane_owner[l] = nullptr;
+        if (c->side_stream[l]) HIP_TRY(hipStreamSynchronize(c->side_stream[l]));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MELF_SUCCESS;
@@ -588,6 +603,14 @@ extern "C" int melf_ctx_fused_table_ties(const melf_ctx* c, int* count)
 {
     if (!c || !count) return fail(MELF_ERR_INVALID, "NULL argument");
     *count = c->fused_ambiguous;
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_set_frames_resident(melf_ctx* c, int on)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    c->frames_resident = on != 0;
+    if (!on) for (int l = 0; l < melf_ctx::NLANES; ++l) c->match_done_valid[l] = false;
     return MELF_SUCCESS;
 }
 
@@ -687,6 +710,36 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
     return MELF_SUCCESS;
 }
 
+// Where lane bl's prep kernels go: the lane's side stream, released by the lane's previous match kernel, when the
+// frames are known to be resident; else the call's own stream.
+static int prep_stream_for(melf_ctx* c, int bl, hipStream_t ls, hipStream_t* out)
+{
+    *out = ls;
+    if (!(c->frames_resident && c->ahead_ok && c->match_done_valid[bl])) return MELF_SUCCESS;
+    if (!c->side_stream[bl]) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side_stream[bl], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_prep_done[bl], hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamWaitEvent(c->side_stream[bl], c->ev_match_done[bl], 0));
+    *out = c->side_stream[bl];
+    return MELF_SUCCESS;
+}
+static int prep_done(melf_ctx* c, int bl, hipStream_t ps, hipStream_t ls)
+{
+    if (ps == ls) return MELF_SUCCESS;
+    HIP_TRY(hipEventRecord(c->ev_prep_done[bl], ps));
+    HIP_TRY(hipStreamWaitEvent(ls, c->ev_prep_done[bl], 0));
+    return MELF_SUCCESS;
+}
+static int match_launched(melf_ctx* c, int bl, hipStream_t ls)
+{
+    if (!(c->frames_resident && c->ahead_ok)) { c->match_done_valid[bl] = false; return MELF_SUCCESS; }
+    if (!c->ev_match_done[bl]) HIP_TRY(hipEventCreateWithFlags(&c->ev_match_done[bl], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_match_done[bl], ls));
+    c->match_done_valid[bl] = true;
+    return MELF_SUCCESS;
+}
+
 // prep + match of m images on stream ls with lane bl's work buffers; *parts / *nparts: per-frame (max, first arg-max)
 // partials for the consumer (k_dials or the host fold of melf_match_ccoeff)
 static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int bl, hipStream_t ls, float* d_map,
@@ -709,12 +762,16 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
         if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.nparts)) return rc;
         *parts = c->d_lpart[bl];
+        hipStream_t ps;
+        if (int rc = prep_stream_for(c, bl, ls, &ps)) return rc;
         {
-            KernelTimer t(c, MELF_K_LPLANE, ls);
-            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ls);
+            KernelTimer t(c, MELF_K_LPLANE, ps);
+            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ps);
         }
+        if (int rc = prep_done(c, bl, ps, ls)) return rc;
         launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls,
                           ev.start, ev.stop);
+        if (int rc = match_launched(c, bl, ls)) return rc;
     } else if (kind == MK_GEN) {
         melf_ctx::GenEntry* ge = nullptr;
         if (int rc = gen_entry(c, ms.rows, ms.cols, m, &ge)) return rc;
@@ -731,19 +788,24 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
             if (pl.part_bytes) HIP_TRY(hipMalloc(&ge->part[bl], pl.part_bytes));
         }
         *parts = c->d_lpart[bl];
+        hipStream_t ps;
+        if (int rc = prep_stream_for(c, bl, ls, &ps)) return rc;
         {
-            KernelTimer t(c, MELF_K_LPLANE, ls);
+            KernelTimer t(c, MELF_K_LPLANE, ps);
             launch_match_prep(ms, from_bgr, m, pl.groups, pl.rows_pad, pl.nkb, pl.rwp, pl.rh, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl],
-                              c->d_wsum[bl], ls);
+                              c->d_wsum[bl], ps);
         }
+        if (int rc = prep_done(c, bl, ps, ls)) return rc;
         GenDev dev = ge->dev;
         dev.part = ge->part[bl];
         dev.counters = ge->counters[bl];
         launch_gen_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls, ev.start, ev.stop);
+        if (int rc = match_launched(c, bl, ls)) return rc;
     } else {
         *nparts = match_parts(c->mg, ms.rows, ms.cols);
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * *nparts)) return rc;
         *parts = c->d_lpart[bl];
+        c->match_done_valid[bl] = false;
         KernelTimer t(c, MELF_K_MATCH, ls);
         launch_match(ms, from_bgr, m, c->mg, c->d_tplT, d_map, *parts, nullptr, ls);
     }
@@ -774,7 +836,10 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
     } else if (int rc = acquire_lane(c, st, &c->active_lane)) {
         return rc;
     }
-    return process_batch_on(c, d_frames, n, H, W, frame_stride, d_results, out_host, st);
+    c->ahead_ok = c->lanes == 1 && n <= MAX_FRAMES_PER_LAUNCH;  // one prep / match / dials sequence per call
+    const int rc = process_batch_on(c, d_frames, n, H, W, frame_stride, d_results, out_host, st);
+    c->ahead_ok = false;
+    return rc;
 }
 
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,

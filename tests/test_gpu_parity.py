@@ -840,3 +840,44 @@ def test_two_caller_streams_use_two_lanes(env):
             hip.hipStreamDestroy(s)
         hip.hipFree(d_frames)
         hip.hipFree(d_res)
+
+
+def test_frames_resident_hint_same_records(env):
+    """melf_ctx_set_frames_resident: a call's prep kernels run on the lane's side stream under the previous call's dials
+    kernel.  Six calls back to back over three resident batches (and a lane change in between): records identical."""
+    import ctypes as C
+    from meterelf_amd import _hip
+    e = env['sample-images2']
+    frames = synth_frames(_good(e['files']), 3 * 160, 321)
+    ctx = e['reader'].ctx
+    ref = ctx.process_batch(frames)
+    hip = C.CDLL('libamdhip64.so')
+    (n, H, W) = (160, frames.shape[1], frames.shape[2])
+    rsz = _hip.RESULT_DTYPE.itemsize
+    (d_frames, d_res) = (C.c_void_p(), C.c_void_p())
+    streams = [C.c_void_p() for _ in range(2)]
+    assert hip.hipMalloc(C.byref(d_frames), C.c_size_t(frames.nbytes)) == 0
+    assert hip.hipMalloc(C.byref(d_res), C.c_size_t(2 * len(frames) * rsz)) == 0
+    for s in streams:
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+    try:
+        assert hip.hipMemcpy(d_frames, frames.ctypes.data_as(C.c_void_p), C.c_size_t(frames.nbytes), 1) == 0
+        assert hip.hipMemset(d_res, 0, C.c_size_t(2 * len(frames) * rsz)) == 0
+        assert hip.hipDeviceSynchronize() == 0   # the promise: frames complete before the calls
+        ctx.set_frames_resident(True)
+        for i in range(6):
+            b = i % 3
+            st = streams[0] if i != 3 else streams[1]   # call 3 arrives on another stream (takes the other lane)
+            ctx.process_batch_dev(d_frames.value + b * n * H * W * 3, n, H, W, d_results_ptr=d_res.value + i * n * rsz,
+                                  want_host=False, stream=st.value)
+        assert hip.hipDeviceSynchronize() == 0
+        got = np.zeros(2 * len(frames), _hip.RESULT_DTYPE)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d_res, C.c_size_t(got.nbytes), 2) == 0
+        assert got[:len(frames)].tobytes() == ref.tobytes() and got[len(frames):].tobytes() == ref.tobytes()
+    finally:
+        ctx.set_frames_resident(False)
+        ctx.sync()
+        for s in streams:
+            hip.hipStreamDestroy(s)
+        hip.hipFree(d_frames)
+        hip.hipFree(d_res)
