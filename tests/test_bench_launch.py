@@ -36,7 +36,7 @@ def test_gpus_flag_must_match_world_size():
     assert p.returncode != 0 and b'WORLD_SIZE' in p.stderr
 
 
-SMALL = ['--steps', '3', '--warmup', '1', '--batch', '64', '--nbuf', '2']
+SMALL = ['--steps', '3', '--warmup', '1', '--batch', '64', '--nbuf', '2', '--preheat', '0']
 
 
 @pytest.mark.gpu
