@@ -281,7 +281,7 @@ __device__ __forceinline__ void gen_vform(const int8_t* __restrict__ Lg, const i
     i32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0;
-    constexpr int U = 4;  // MFMAs per group; two groups of operands in flight
+    constexpr int U = 8;  // MFMAs per group; two groups of operands in flight (two loads per MFMA: the loop lives on load latency)
     i32x4 av[2][U], bv[2][U];
 #define MELF_V_REQUEST(KK, SET)                                                                           \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                        \
@@ -383,7 +383,8 @@ GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes)
     // run in rounds of 1024 (one wave per SIMD); every K pass primes its rings, every wave has an epilogue; a sliced
     // tile pays the hand-off and the completing wave's pass over the other slices' partial tiles.
     struct Tile { int y0, R, Rc, xb0, nxb; long work; bool v; };
-    const long slots = 1024;
+    const int nvt = p.vcols * ((p.rh + 31) / 32);          // V-form tiles per group
+    const long slots = std::max(64L, 1024L - 6L * nvt * p.groups);   // wave slots for the H form: ~6 slices per V tile reserved
     double best_cost = 1e30;
     int best_rc = 8, best_nxb = 2, best_ns = 1;
     for (int rc = 8; rc >= 2; rc -= 2)
@@ -437,9 +438,13 @@ GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes)
         const Tile& t = tiles[ti];
         const int klen = t.v ? (std::min(32, p.rh - t.y0) + th - 1) * p.ndv : p.nd * th;
         int ns = best_ns;
-        if (t.v) {  // V-form tiles: slices about as heavy as the H-form ones, at least 64 MFMAs each
-            ns = h_slice_work > 0 ? (int)((t.work + h_slice_work - 1) / h_slice_work) : 1;
-            ns = std::max(1, std::min(std::min(ns, 16), klen / 64));
+        if (t.v) {
+            // V-form tiles: two loads per MFMA make their K loop latency-bound (~0.1 us per MFMA), so they take every wave
+            // slot the H-form tiles leave in the first round (never a second round), in slices of >= 48 MFMAs, <= 16 of them
+            (void)h_slice_work;
+            const long h_waves = (long)(p.ntiles - nvt) * best_ns;
+            const long left = std::max(1L, (1024L / p.groups - h_waves) / std::max(1, nvt));
+            ns = (int)std::max(1L, std::min<long>(std::min<long>(16, left), klen / 48));
         }
         const int nq = t.v ? 4 : t.Rc * t.nxb * 4;
         for (int sl = 0; sl < ns; ++sl) {
