@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collects a round's profiles on the GPU box:  tools/profile_round.sh r02
-#  * rocprofv3 --kernel-trace --stats of the DEFAULT bench command (per-kernel average durations)
+#  * rocprofv3 --kernel-trace --stats of the default bench command minus its two_streams blocks (`--skip twostream`:
+#    launches that share the chip with another stream's kernels have stretched durations and would blur the per-kernel
+#    averages the roofline lines are checked against)
 #  * HBM traffic counters, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md: they do not fit one
 #    pass; FETCH_SIZE is doubled for wide coalesced reads on gfx950), for each workload bench.py reports a roofline on:
 #      config3  full path, sample-images1, 1024 frames per launch, four batches in rotation
@@ -14,12 +16,15 @@ set -e
 export TMPDIR=/tmp
 R=${1:-r02}
 OUT=gpurun_out/prof_$R
-rm -rf $OUT /tmp/prof && mkdir -p $OUT /tmp/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+if [ -z "$STATS_ONLY" ]; then rm -rf $OUT; fi
+rm -rf /tmp/prof && mkdir -p $OUT /tmp/prof
+echo "python3 bench.py --skip twostream" > $OUT/bench_command.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python3 bench.py --skip twostream > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 f=$(find /tmp/prof/stats -name '*kernel_stats.csv' | head -1)
 head -1 "$f" > $OUT/bench_kernel_stats.csv
 grep -i 'melf' "$f" >> $OUT/bench_kernel_stats.csv || true
 echo "kernel stats done" >> $OUT/progress.txt
+if [ -n "$STATS_ONLY" ]; then cut -c1-200 $OUT/bench_kernel_stats.csv; exit 0; fi
 pmc() {  # name, command...
   name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
