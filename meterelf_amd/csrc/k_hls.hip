@@ -626,15 +626,17 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     const long total = (long)n * segs;
     const int grid = (int)(total < target ? total : target);
     const size_t shmem = (size_t)(2 * NB * wpr) * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {false};  // per device (several contexts on several GPUs may live in one process)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
         if (getenv("MELF_FUSED_TRACE")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fused_mask_lut<V, T, PF, WPS>, T, shmem);
             fprintf(stderr, "[melf fused] V=%d T=%d PD=%d WPS=%d grid=%d shmem=%zu resident blocks/CU=%d\n", V, T, PF, WPS, grid, shmem, nb);
         }
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, d_frames, n, H, W, hue_shift,
                        B, d_tables, d_masks, segs, seg_rows, NB, plain_store);
