@@ -812,60 +812,86 @@ __device__ __forceinline__ uint32_t ycc_to_bgr(int y, int cb, int cr)
     return (uint32_t)min(max(b, 0), 255) | ((uint32_t)min(max(g, 0), 255) << 8) | ((uint32_t)min(max(r, 0), 255) << 16);
 }
 
-// 4:2:0 fast path (W % 8 == 0): one thread per 8 output pixels of one row = 4 chroma columns.
-// The border cases of the triangle filter are the general formula with the missing neighbour
-// replaced by the sample itself ((4t + 8) >> 4 == (3t + t + 8) >> 4), i.e. clamped indices.
+// 4:2:0 fast path (W % 8 == 0, even window rows): one thread per 8 output pixels of TWO rows (2 cy, 2 cy + 1) = 4 chroma
+// columns of chroma row cy, which both rows weigh 3/4, plus the row above for the even and the row below for the odd
+// output row: three chroma rows fetched for two output rows instead of four, and the work items of a window are packed
+// into the workgroups (a 272-pixel window has 34 items per row: one row per 256-thread workgroup left 87 % of the lanes
+// idle).  The border cases of the triangle filter are the general formula with the missing neighbour replaced by the
+// sample itself ((4t + 8) >> 4 == (3t + t + 8) >> 4), i.e. clamped indices.
 __global__ __launch_bounds__(256) void k_jpeg_color420(const JpegImageDev* __restrict__ imgs, const int32_t* __restrict__ status,
                                                        const uint8_t* __restrict__ planes, int H, int W,
                                                        uint8_t* __restrict__ frames, JpegWindow win)
 {
-    const int img = blockIdx.z, y = win.y0 + blockIdx.y;
-    const int g = win.x0 / 8 + blockIdx.x * 256 + threadIdx.x;  // group of 8 pixels
-    if (g * 8 >= win.x1) return;
+    const int img = blockIdx.y;
+    const int gx = (win.x1 - win.x0 + 7) / 8;                 // groups of 8 pixels per window row
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int pr = item / gx, g = win.x0 / 8 + (item - pr * gx);
+    const int y = win.y0 + 2 * pr;                            // even (win.y0 is a multiple of 16)
+    if (y >= win.y1 || g * 8 >= win.x1) return;
+    const bool two = y + 1 < win.y1;
     // the record and the status in one round trip (field by field, each && waited for its own load)
     const JpegImageDev rec = imgs[img];
     const int32_t st = status[img];
     const JpegImageDev* R = &rec;
     if (!(rec.ok && rec.ncomp == 3 && rec.hs0 == 2 && rec.vs0 == 2)) return;  // the generic kernel's image
+    uint8_t* const orow = frames + ((size_t)img * H + y) * W * 3 + (size_t)g * 24;
     if (st != 0) {  // failed in the entropy decoder: zero frame
-        uint2* z = (uint2*)(frames + ((size_t)img * H + y) * W * 3 + (size_t)g * 24);
+        uint2* z = (uint2*)orow;
         z[0] = z[1] = z[2] = make_uint2(0u, 0u);
+        if (two) {
+            uint2* z2 = (uint2*)(orow + (size_t)W * 3);
+            z2[0] = z2[1] = z2[2] = make_uint2(0u, 0u);
+        }
         return;
     }
     const int ys = R->blocks_x[0] * 8, cs = R->blocks_x[1] * 8;
     const int cw = (W + 1) >> 1, ch = (H + 1) >> 1;
-    const int cy = y >> 1, fy = (y & 1) ? min(cy + 1, ch - 1) : max(cy - 1, 0);
+    const int cy = y >> 1, fu = max(cy - 1, 0), fd = min(cy + 1, ch - 1);
     const int cx0 = g * 4;
     const int cl = max(cx0 - 1, 0), cr = min(cx0 + 4, cw - 1);
-    int t[2][6];
+    int te[2][6], to[2][6];   // 3 * near + far for the even / the odd output row
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const uint8_t* P = planes + R->plane_off[1 + c];
         const uint8_t* near = P + (size_t)cy * cs;
-        const uint8_t* far = P + (size_t)fy * cs;
-        const uint32_t n4 = *(const uint32_t*)(near + cx0), f4 = *(const uint32_t*)(far + cx0);
-        t[c][0] = 3 * near[cl] + far[cl];
-        t[c][5] = 3 * near[cr] + far[cr];
+        const uint8_t* up = P + (size_t)fu * cs;
+        const uint8_t* dn = P + (size_t)fd * cs;
+        const uint32_t n4 = *(const uint32_t*)(near + cx0), u4 = *(const uint32_t*)(up + cx0), d4 = *(const uint32_t*)(dn + cx0);
+        const int nl = near[cl], nr = near[cr];
+        te[c][0] = 3 * nl + up[cl]; te[c][5] = 3 * nr + up[cr];
+        to[c][0] = 3 * nl + dn[cl]; to[c][5] = 3 * nr + dn[cr];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[c][1 + j] = 3 * (int)((n4 >> (8 * j)) & 255u) + (int)((f4 >> (8 * j)) & 255u);
+        for (int j = 0; j < 4; ++j) {
+            const int nj = 3 * (int)((n4 >> (8 * j)) & 255u);
+            te[c][1 + j] = nj + (int)((u4 >> (8 * j)) & 255u);
+            to[c][1 + j] = nj + (int)((d4 >> (8 * j)) & 255u);
+        }
     }
-    const uint2 yy = *(const uint2*)(planes + R->plane_off[0] + (size_t)y * ys + g * 8);
-    uint32_t px[8];
+    const uint8_t* yrow = planes + R->plane_off[0] + (size_t)y * ys + g * 8;
+    const uint2 yy0 = *(const uint2*)yrow;
+    const uint2 yy1 = two ? *(const uint2*)(yrow + ys) : yy0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int cbe = (3 * t[0][1 + j] + t[0][j] + 8) >> 4, cbo = (3 * t[0][1 + j] + t[0][2 + j] + 7) >> 4;
-        const int cre = (3 * t[1][1 + j] + t[1][j] + 8) >> 4, cro = (3 * t[1][1 + j] + t[1][2 + j] + 7) >> 4;
-        const uint32_t ysrc = j < 2 ? yy.x : yy.y;
-        px[2 * j] = ycc_to_bgr((int)((ysrc >> (16 * (j & 1))) & 255u), cbe, cre);
-        px[2 * j + 1] = ycc_to_bgr((int)((ysrc >> (16 * (j & 1) + 8)) & 255u), cbo, cro);
+    for (int row = 0; row < 2; ++row) {
+        if (row == 1 && !two) break;
+        const int (*t)[6] = row ? to : te;
+        const uint2 yy = row ? yy1 : yy0;
+        uint32_t px[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cbe = (3 * t[0][1 + j] + t[0][j] + 8) >> 4, cbo = (3 * t[0][1 + j] + t[0][2 + j] + 7) >> 4;
+            const int cre = (3 * t[1][1 + j] + t[1][j] + 8) >> 4, cro = (3 * t[1][1 + j] + t[1][2 + j] + 7) >> 4;
+            const uint32_t ysrc = j < 2 ? yy.x : yy.y;
+            px[2 * j] = ycc_to_bgr((int)((ysrc >> (16 * (j & 1))) & 255u), cbe, cre);
+            px[2 * j + 1] = ycc_to_bgr((int)((ysrc >> (16 * (j & 1) + 8)) & 255u), cbo, cro);
+        }
+        uint32_t* o = (uint32_t*)(orow + (size_t)row * W * 3);
+        uint32_t d[6];
+        d[0] = px[0] | (px[1] << 24); d[1] = (px[1] >> 8) | (px[2] << 16); d[2] = (px[2] >> 16) | (px[3] << 8);
+        d[3] = px[4] | (px[5] << 24); d[4] = (px[5] >> 8) | (px[6] << 16); d[5] = (px[6] >> 16) | (px[7] << 8);
+        *(uint2*)(o) = make_uint2(d[0], d[1]);
+        *(uint2*)(o + 2) = make_uint2(d[2], d[3]);
+        *(uint2*)(o + 4) = make_uint2(d[4], d[5]);
     }
-    uint32_t* o = (uint32_t*)(frames + ((size_t)img * H + y) * W * 3 + (size_t)g * 24);
-    uint32_t d[6];
-    d[0] = px[0] | (px[1] << 24); d[1] = (px[1] >> 8) | (px[2] << 16); d[2] = (px[2] >> 16) | (px[3] << 8);
-    d[3] = px[4] | (px[5] << 24); d[4] = (px[5] >> 8) | (px[6] << 16); d[5] = (px[6] >> 16) | (px[7] << 8);
-    *(uint2*)(o) = make_uint2(d[0], d[1]);
-    *(uint2*)(o + 2) = make_uint2(d[2], d[3]);
-    *(uint2*)(o + 4) = make_uint2(d[4], d[5]);
 }
 
 __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImageDev* __restrict__ imgs, const int32_t* __restrict__ status,
@@ -1142,7 +1168,10 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
     }
     if (timer) timer(timer_arg, 2, 0);
     const int fast420 = (W % 8 == 0 && w->n_420 > 0) ? 1 : 0;
-    if (fast420) hipLaunchKernelGGL(k_jpeg_color420, dim3((win_w / 8 + 255) / 256, win_h, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, win);
+    if (fast420) {
+        const int items = ((win_w + 7) / 8) * ((win_h + 1) / 2);   // 8 pixels x 2 rows each
+        hipLaunchKernelGGL(k_jpeg_color420, dim3((items + 255) / 256, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, win);
+    }
     if (!fast420 || w->n_420 < n)
         hipLaunchKernelGGL(k_jpeg_color, dim3((win_w + 1023) / 1024, win_h, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, fast420, win);
     if (timer) timer(timer_arg, 2, 1);
