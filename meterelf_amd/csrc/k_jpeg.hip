@@ -284,7 +284,21 @@ struct SegState {
     uint32_t p;      // bit position
     int blk, k;      // block within the MCU, coefficient index (0 = DC symbol comes next)
 };
-constexpr int LOOK_BITS = 11;  // first-level lookup of the segment-parallel kernel (built in LDS by the kernel itself)
+// First-level lookup of the Huffman kernels, built in LDS by the kernels themselves: four tables (DC 0, DC 1, AC 0,
+// AC 1) of 2^TAB_BITS dwords.  An entry says what the next TAB_BITS bits of the stream start with -- ONE symbol, or
+// TWO when the second code also lies wholly inside the window:
+//   bits  0.. 4  bits1  bits the first symbol occupies, code + magnitude bits (the symbol alone fixes their number)
+//   bits  5..11  adv1   coefficients it advances: DC 1; AC run + 1, ZRL 16, end of block 64 (k leaves the block)
+//   bits 12..16  bits2  bits of both symbols together (0: no second symbol in the entry)
+//   bits 17..23  adv2   coefficients both advance together (64 when the second ends the block)
+//   bits 24..28  len1   code length of the first symbol (bits1 - len1 magnitude bits follow it)
+// 0: the first code is longer than the window (canonical decode from `slow`, rare).
+// The second symbol of a DC entry is the block's first AC symbol, decoded with the AC table that goes with that DC
+// table (McuLayout::pair_bits says for which blocks of the MCU that pairing holds).  The coefficient-writing decoder
+// reads the first symbol only; the state-only decoder of the speculative pass and of the synchronisation rounds takes
+// both: a flat block (DC difference + end of block, 4-6 bits) is one step, most short AC symbols go two at a time.
+constexpr int TAB_BITS = 10;
+constexpr uint32_t TAB_MASK = (1u << TAB_BITS) - 1u;
 
 // Per-MCU-position tables packed into registers: 1 bit of DC table id, 1 bit of AC table id and 2 bits
 // of component per block position (an MCU has at most 6 blocks here).
@@ -300,14 +314,100 @@ struct McuWindow {  // the same in MCUs of one image
 
 struct McuLayout {
     uint32_t dc_bits, ac_bits, comp_bits;
+    uint32_t pair_bits;  // per block: its AC table is the one the DC entries' second symbols were decoded with
+    int ac_of_dc0, ac_of_dc1;  // that AC table, per DC table
     int bpm, yblocks;
 };
 
-template <bool WRITE>
+__device__ __forceinline__ McuLayout jpeg_mcu_layout(const JpegImageDev* R)
+{
+    const int ncomp = R->ncomp;
+    McuLayout L;
+    L.yblocks = ncomp == 1 ? 1 : R->hs0 * R->vs0;
+    L.bpm = ncomp == 1 ? 1 : L.yblocks + 2;
+    L.dc_bits = L.ac_bits = L.comp_bits = L.pair_bits = 0;
+    int a0 = -1, a1 = -1;
+    for (int b = 0; b < L.bpm; ++b) {
+        const int c = b < L.yblocks ? 0 : 1 + b - L.yblocks;
+        const int td = R->td[c] & 1, ta = R->ta[c] & 1;
+        L.dc_bits |= (uint32_t)td << b;
+        L.ac_bits |= (uint32_t)ta << b;
+        L.comp_bits |= (uint32_t)c << (2 * b);
+        if (td == 0 && a0 < 0) a0 = ta;
+        if (td == 1 && a1 < 0) a1 = ta;
+        L.pair_bits |= (uint32_t)((td == 0 ? a0 : a1) == ta ? 1 : 0) << b;
+    }
+    L.ac_of_dc0 = a0 < 0 ? 0 : a0;
+    L.ac_of_dc1 = a1 < 0 ? 0 : a1;
+    return L;
+}
+
+// bits1 | adv1 << 5 | len1 << 24 of a symbol
+__device__ __forceinline__ uint32_t huff_step(const bool dc, const int len, const int sym)
+{
+    const int sbits = sym & 15, run = sym >> 4;
+    const int adv = dc ? 1 : (sbits ? run + 1 : (run == 15 ? 16 : 64));
+    return (uint32_t)(len + sbits) | (uint32_t)adv << 5 | (uint32_t)len << 24;
+}
+
+// Canonical decode of the code at the top of the nb-bit window x, looking at its first `avail` bits only: the symbol's
+// step, or 0 when the code is longer than that.  sl: the table's HuffSlow in LDS.
+template <int NB>
+__device__ __forceinline__ uint32_t huff_window_step(const uint32_t* __restrict__ sl, const bool dc, const uint32_t x, const int avail)
+{
+    int len = 1;
+#pragma unroll
+    for (int l = 1; l <= NB; ++l) len += (l <= avail && (x >> (NB - l)) >= sl[l - 1]) ? 1 : 0;
+    if (len > avail) return 0;
+    const int idx = (int)sl[16 + len - 1] + (int)(x >> (NB - len));
+    return huff_step(dc, len, ((const uint8_t*)(sl + 32))[idx & 255]);
+}
+
+// The four tables, by all T threads of the workgroup (slow[] complete; a barrier must follow).
+template <int T>
+__device__ __forceinline__ void jpeg_build_tables(uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow, const McuLayout L, const int tid)
+{
+    for (int i = tid; i < (4 << TAB_BITS); i += T) {
+        const int t = i >> TAB_BITS;
+        const bool dc = t < 2;
+        const uint32_t x = (uint32_t)i & TAB_MASK;
+        uint32_t e = huff_window_step<TAB_BITS>(slow + t * SLOW_DW, dc, x, TAB_BITS);
+        const int bits1 = (int)(e & 31u), adv1 = (int)((e >> 5) & 127u);
+        if (e && adv1 != 64 && bits1 < TAB_BITS) {  // a second code may lie wholly inside the window
+            const int t2 = dc ? 2 + (t == 0 ? L.ac_of_dc0 : L.ac_of_dc1) : t;
+            const uint32_t e2 = huff_window_step<TAB_BITS>(slow + t2 * SLOW_DW, false, (x << bits1) & TAB_MASK, TAB_BITS - bits1);
+            if (e2) {
+                const int a2 = (int)((e2 >> 5) & 127u);
+                e |= (uint32_t)(bits1 + (int)(e2 & 31u)) << 12 | (uint32_t)(a2 == 64 ? 64 : adv1 + a2) << 17;
+            }
+        }
+        tab[i] = e;
+    }
+}
+
+// The first symbol when its code is longer than the window: the canonical compares for the remaining lengths.
+// A window that starts with no code at all (only a speculative decode or a corrupt file gets there) counts as a
+// 16-bit end of block / zero DC difference and sets `invalid`.
+__device__ __forceinline__ uint32_t huff_long_step(const uint32_t* __restrict__ sl, const bool dc, const uint32_t w, bool& invalid)
+{
+    const uint32_t code16 = w >> 16;
+    int len = TAB_BITS + 1, sym = 0;
+#pragma unroll
+    for (int l = TAB_BITS + 1; l <= 16; ++l) len += (code16 >> (16 - l)) >= sl[l - 1] ? 1 : 0;
+    if (len > 16) {
+        invalid = true;
+        len = 16;
+    } else {
+        const int idx = (int)sl[16 + len - 1] + (int)(code16 >> (16 - len));
+        sym = ((const uint8_t*)(sl + 32))[idx & 255];
+    }
+    return huff_step(dc, len, sym);
+}
+
+// One segment, symbol by symbol, writing the coefficients of the blocks inside the window.
 __device__ __forceinline__ void jpeg_decode_segment(
-    const uint32_t* __restrict__ W, const uint16_t* __restrict__ look, const uint32_t* __restrict__ slow,
-    const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk, int64_t& dsum,
-    // WRITE only:
+    const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow,
+    const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk,
     int nb, const int total_blocks, int pred0, int pred1, int pred2, const int hs0, const int vs0, const int mcus_x,
     const int bxs0, const int bxs1, int16_t* __restrict__ c0, int16_t* __restrict__ c1, int16_t* __restrict__ c2, int& bad,
     const McuWindow mw = McuWindow{0, 1 << 30, 0, 1 << 30})
@@ -326,72 +426,117 @@ __device__ __forceinline__ void jpeg_decode_segment(
             cb = (blk == L.yblocks ? c1 : c2) + (size_t)(my * bxs1 + mx) * 64;
         }
     };
-    if (WRITE) {
+    {
         const int mcu = nb / L.bpm;
         my = mcu / mcus_x;
         mx = mcu - my * mcus_x;
         block_ptr();
     }
     nblk = 0;
-    dsum = 0;
     // bit buffer over the scan in global memory (dwords in file byte order): the top `bitcnt` bits are valid
     uint32_t di = (p >> 5) + 2;
     uint64_t bitbuf = (((uint64_t)__builtin_bswap32(W[di - 2]) << 32) | __builtin_bswap32(W[di - 1])) << (p & 31u);
     int bitcnt = 64 - (int)(p & 31u);
     while (p < p_end) {
-        if (WRITE && nb >= total_blocks) break;
+        if (nb >= total_blocks) break;
         if (bitcnt < 32) {
             bitbuf |= (uint64_t)__builtin_bswap32(W[di++]) << (32 - bitcnt);
             bitcnt += 32;
         }
         const uint32_t w = (uint32_t)(bitbuf >> 32);  // the next 32 bits: code + magnitude fit (<= 16 + 15)
         const bool isdc = k == 0;
-        const uint32_t t = 2u * (isdc ? 0u : 1u) + (((isdc ? L.dc_bits : L.ac_bits) >> blk) & 1u);
-        const uint32_t e = look[(t << LOOK_BITS) + (w >> (32 - LOOK_BITS))];
-        int len = e >> 8, sym = e & 255;
-        if (!e) {  // longer than LOOK_BITS (rare)
-            const uint32_t* sl = slow + t * SLOW_DW;
-            const uint32_t code16 = w >> 16;
-            len = LOOK_BITS + 1;
-#pragma unroll
-            for (int l = LOOK_BITS + 1; l <= 16; ++l) len += (code16 >> (16 - l)) >= sl[l - 1] ? 1 : 0;
-            if (len > 16) {  // not a code: only a speculative decode (or a corrupt file) gets here
-                if (WRITE) bad = 1;
-                len = 16; sym = 0;
-            } else {
-                const int idx = (int)sl[16 + len - 1] + (int)(code16 >> (16 - len));
-                sym = ((const uint8_t*)(sl + 32))[idx & 255];
-            }
+        const uint32_t t = isdc ? (L.dc_bits >> blk) & 1u : 2u + ((L.ac_bits >> blk) & 1u);
+        uint32_t e = tab[(t << TAB_BITS) + (w >> (32 - TAB_BITS))];
+        if (!e) {
+            bool invalid = false;
+            e = huff_long_step(slow + t * SLOW_DW, isdc, w, invalid);
+            if (invalid) bad = 1;
         }
-        const int sbits = sym & 15;
-        const int run = sym >> 4;
-        const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - len - sbits, sbits);  // width 0 -> 0
+        const int used = (int)(e & 31u), adv = (int)((e >> 5) & 127u), sbits = used - (int)((e >> 24) & 31u);
+        const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - used, sbits);  // width 0 -> 0
         const int half = (1 << sbits) >> 1;
         const int v = raw < half ? raw - 2 * half + 1 : raw;  // EXTEND (F.2.2.1); sbits = 0 -> 0
-        p += len + sbits;
-        bitbuf <<= len + sbits;
-        bitcnt -= len + sbits;
-        const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
-        if (isdc) dsum += (int64_t)v << (16 * comp);  // three 16-bit lanes, separated again after the scan
-        const int pos = isdc ? 0 : k + run;
-        if (WRITE) {
-            if (isdc) {
-                int pr;
-                if (comp == 0) pr = (pred0 += v); else if (comp == 1) pr = (pred1 += v); else pr = (pred2 += v);
-                if (cb) cb[0] = (int16_t)pr;
-            } else if (sbits && pos < 64 && cb) {
-                cb[nat[pos]] = (int16_t)v;
-            }
+        p += (uint32_t)used;
+        bitbuf <<= used;
+        bitcnt -= used;
+        if (isdc) {
+            const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
+            int pr;
+            if (comp == 0) pr = (pred0 += v); else if (comp == 1) pr = (pred1 += v); else pr = (pred2 += v);
+            if (cb) cb[0] = (int16_t)pr;
+        } else {
+            const int pos = k + adv - 1;  // run zeros, then this coefficient
+            if (sbits && pos < 64 && cb) cb[nat[pos]] = (int16_t)v;
         }
-        k = isdc ? 1 : (sbits ? pos + 1 : (run == 15 ? k + 16 : 64));
+        k += adv;  // DC: 0 -> 1
         if (k >= 64) {
             k = 0;
             ++nblk;
             if (++blk == L.bpm) {
                 blk = 0;
-                if (WRITE) { if (++mx == mcus_x) { mx = 0; ++my; } }
+                if (++mx == mcus_x) { mx = 0; ++my; }
             }
-            if (WRITE) { ++nb; block_ptr(); }
+            ++nb;
+            block_ptr();
+        }
+    }
+    s.p = p; s.blk = blk; s.k = k;
+}
+
+// What a segment's decode does to the decoder state, without the coefficients: exit state, blocks completed, DC
+// differences summed per component.  The same walk as jpeg_decode_segment (same tables, same treatment of impossible
+// codes, same stop at p_end; the second symbol of an entry is taken only where the one-at-a-time decoder would decode
+// it next: same block, before p_end), so a segment entered in the true state leaves in the true state.
+__device__ __forceinline__ void jpeg_state_segment(
+    const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow, const McuLayout L,
+    SegState& s, const uint32_t p_end, int& nblk, int64_t& dsum, int* diag = nullptr)
+{
+    uint32_t p = s.p;
+    int blk = s.blk, k = s.k;
+    nblk = 0;
+    dsum = 0;
+    uint32_t di = (p >> 5) + 2;
+    uint64_t bitbuf = (((uint64_t)__builtin_bswap32(W[di - 2]) << 32) | __builtin_bswap32(W[di - 1])) << (p & 31u);
+    int bitcnt = 64 - (int)(p & 31u);
+    while (p < p_end) {
+        if (bitcnt < 32) {
+            bitbuf |= (uint64_t)__builtin_bswap32(W[di++]) << (32 - bitcnt);
+            bitcnt += 32;
+        }
+        const uint32_t w = (uint32_t)(bitbuf >> 32);
+        const bool isdc = k == 0;
+        const uint32_t t = isdc ? (L.dc_bits >> blk) & 1u : 2u + ((L.ac_bits >> blk) & 1u);
+        uint32_t e = tab[(t << TAB_BITS) + (w >> (32 - TAB_BITS))];
+#ifdef MELF_JPEG_ROUNDS
+        if (diag) ++diag[0];
+#endif
+        if (!e) {
+            bool invalid = false;
+            e = huff_long_step(slow + t * SLOW_DW, isdc, w, invalid);
+        }
+        const int bits1 = (int)(e & 31u), adv1 = (int)((e >> 5) & 127u), bits2 = (int)((e >> 12) & 31u), adv2 = (int)((e >> 17) & 127u);
+        if (isdc) {  // the value is needed: DC predictors of the segments behind this one
+            const int sbits = bits1 - (int)((e >> 24) & 31u);
+            const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - bits1, sbits);
+            const int half = (1 << sbits) >> 1;
+            const int v = raw < half ? raw - 2 * half + 1 : raw;
+            const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
+            dsum += (int64_t)v << (16 * comp);  // three 16-bit lanes, separated again after the scan
+        }
+        const bool pair_ok = !isdc || ((L.pair_bits >> blk) & 1u);
+        const bool two = bits2 != 0 && pair_ok && k + adv1 < 64 && p + (uint32_t)bits1 < p_end;
+#ifdef MELF_JPEG_ROUNDS
+        if (diag && two) ++diag[1];
+#endif
+        const int used = two ? bits2 : bits1;
+        k += two ? adv2 : adv1;
+        p += (uint32_t)used;
+        bitbuf <<= used;
+        bitcnt -= used;
+        if (k >= 64) {
+            k = 0;
+            ++nblk;
+            if (++blk == L.bpm) blk = 0;
         }
     }
     s.p = p; s.blk = blk; s.k = k;
@@ -415,6 +560,12 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_stamps(uin
 }
 #define JSTAMP(k) do { if (tid == 0 && img < 8192) g_jpeg_stamps[8 * img + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ uint32_t g_jpeg_rounds[8192];
+// images 0..7, rounds 1..32: segments decoded again, cycles, loop iterations of the slowest lane, of all lanes, two-symbol steps
+__device__ uint32_t g_jpeg_round_log[8 * 32 * 5];
+extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_round_log(uint32_t* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jpeg_round_log), sizeof(g_jpeg_round_log)) == hipSuccess ? 0 : -1;
+}
 extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_rounds(uint32_t* out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jpeg_rounds), sizeof(uint32_t) * (size_t)(n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1;
@@ -453,7 +604,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
                                                  const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
                                                  int32_t* __restrict__ status, JpegWindow win)
 {
-    __shared__ uint16_t look[4 << LOOK_BITS];
+    __shared__ uint32_t tab[4 << TAB_BITS];
     __shared__ uint32_t slow[4 * SLOW_DW];
     __shared__ uint8_t nat[64];
     __shared__ uint32_t e_p[T], e_s[T];  // exit state of each segment: bit position, blk << 8 | k
@@ -462,6 +613,9 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
     __shared__ int64_t sc_d[T];          // packed DC-difference sums (then: prefix sums)
     __shared__ uint16_t todo[T];         // segments to decode again this round, compacted
     __shared__ int wcount[T / 64];
+#ifdef MELF_JPEG_ROUNDS
+    __shared__ int s_diag[3];
+#endif
     const int tid = threadIdx.x;
     const int img = blockIdx.x;
     const JpegImageDev* R = imgs + img;
@@ -481,31 +635,9 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
         for (int i = tid; i < 64; i += T) nat[i] = c_zz2nat[i];
     }
     __syncthreads();
-    // first-level lookup tables: the canonical decode of every LOOK_BITS-bit prefix
-    for (int i = tid; i < (4 << LOOK_BITS); i += T) {
-        const uint32_t* sl = slow + (i >> LOOK_BITS) * SLOW_DW;
-        const uint32_t x = (uint32_t)i & ((1u << LOOK_BITS) - 1u);
-        int len = 1;
-#pragma unroll
-        for (int l = 1; l <= LOOK_BITS; ++l) len += (x >> (LOOK_BITS - l)) >= sl[l - 1] ? 1 : 0;
-        uint32_t e = 0;
-        if (len <= LOOK_BITS) {
-            const int idx = (int)sl[16 + len - 1] + (int)(x >> (LOOK_BITS - len));
-            e = ((uint32_t)len << 8) | ((const uint8_t*)(sl + 32))[idx & 255];
-        }
-        look[i] = (uint16_t)e;
-    }
-    const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
-    McuLayout L;
-    L.yblocks = ncomp == 1 ? 1 : hs0 * vs0;
-    L.bpm = ncomp == 1 ? 1 : L.yblocks + 2;
-    L.dc_bits = L.ac_bits = L.comp_bits = 0;
-    for (int b = 0; b < L.bpm; ++b) {
-        const int c = b < L.yblocks ? 0 : 1 + b - L.yblocks;
-        L.dc_bits |= (uint32_t)(R->td[c] & 1) << b;
-        L.ac_bits |= (uint32_t)(R->ta[c] & 1) << b;
-        L.comp_bits |= (uint32_t)c << (2 * b);
-    }
+    const McuLayout L = jpeg_mcu_layout(R);
+    jpeg_build_tables<T>(tab, slow, L, tid);
+    const int hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
     const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
     const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
     int16_t* c0 = coefs + (size_t)R->coef_blk[0] * 64;
@@ -524,9 +656,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
         SegState ex = {(uint32_t)tid * S, 0, 0};
         int nblk = 0;
         int64_t dsum = 0;
-        if (mine)
-            jpeg_decode_segment<false>(W, look, slow, nat, L, ex, min((uint32_t)(tid + 1) * S, bits + 32u), nblk, dsum, 0, 0, 0, 0, 0, hs0,
-                                       vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+        if (mine) jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(tid + 1) * S, bits + 32u), nblk, dsum);
         n_p[tid] = (uint32_t)tid * S;  // entry of the last decode
         n_s[tid] = 0;
         e_p[tid] = ex.p;
@@ -556,6 +686,10 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
         }
         if (total == 0) break;
         ++rounds;
+#ifdef MELF_JPEG_ROUNDS
+        const uint64_t round_t0 = __builtin_amdgcn_s_memtime();
+        if (tid < 3) s_diag[tid] = 0;
+#endif
         if (ch) {
             const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
             todo[pos] = (uint16_t)tid;
@@ -569,14 +703,31 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
             SegState ex = {n_p[i], (int)(n_s[i] >> 8), (int)(n_s[i] & 255u)};
             int nblk;
             int64_t dsum;
-            jpeg_decode_segment<false>(W, look, slow, nat, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, dsum, 0, 0, 0, 0, 0, hs0, vs0,
-                                       mcus_x, bxs0, bxs1, c0, c1, c2, bad);
+#ifdef MELF_JPEG_ROUNDS
+            int diag[2] = {0, 0};
+            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, dsum, diag);
+            atomicMax(&s_diag[0], diag[0]);
+            atomicAdd(&s_diag[1], diag[0]);
+            atomicAdd(&s_diag[2], diag[1]);
+#else
+            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, dsum);
+#endif
             e_p[i] = ex.p;  // nobody reads exit states before the next barrier
             e_s[i] = (uint32_t)(ex.blk << 8 | ex.k);
             sc_n[i] = nblk;
             sc_d[i] = dsum;
         }
         __syncthreads();
+#ifdef MELF_JPEG_ROUNDS
+        if (tid == 0 && img < 8 && rounds <= 32) {
+            uint32_t* lg = g_jpeg_round_log + (img * 32 + rounds - 1) * 5;
+            lg[0] = (uint32_t)total;
+            lg[1] = (uint32_t)(__builtin_amdgcn_s_memtime() - round_t0);
+            lg[2] = (uint32_t)s_diag[0];
+            lg[3] = (uint32_t)s_diag[1];
+            lg[4] = (uint32_t)s_diag[2];
+        }
+#endif
     }
     JSTAMP(3);
     // exclusive prefix over the segments: blocks completed, packed DC differences per component
@@ -602,9 +753,8 @@ __global__ __launch_bounds__(T) void k_jpeg_huff(const JpegImageDev* __restrict_
         if (entry.blk != nb_in % L.bpm) bad = 1;  // the propagated state and the block count disagree: corrupt stream
         SegState st = entry;
         int n2;
-        int64_t d2;
-        jpeg_decode_segment<true>(W, look, slow, nat, L, st, p_end, n2, d2, nb_in, total_blocks, p0, p1, p2, hs0, vs0, mcus_x, bxs0,
-                                  bxs1, c0, c1, c2, bad, mwin);
+        jpeg_decode_segment(W, tab, slow, nat, L, st, p_end, n2, nb_in, total_blocks, p0, p1, p2, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2,
+                            bad, mwin);
     }
     const int anybad = __syncthreads_or(bad);
     JSTAMP(5);
@@ -631,7 +781,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
                                                      const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
                                                      int32_t* __restrict__ status, JpegWindow win)
 {
-    __shared__ uint16_t look[4 << LOOK_BITS];
+    __shared__ uint32_t tab[4 << TAB_BITS];
     __shared__ uint32_t slow[4 * SLOW_DW];
     __shared__ uint8_t nat[64];
     const int tid = threadIdx.x;
@@ -647,30 +797,9 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
         for (int i = tid; i < 64; i += T) nat[i] = c_zz2nat[i];
     }
     __syncthreads();
-    for (int i = tid; i < (4 << LOOK_BITS); i += T) {
-        const uint32_t* sl = slow + (i >> LOOK_BITS) * SLOW_DW;
-        const uint32_t x = (uint32_t)i & ((1u << LOOK_BITS) - 1u);
-        int len = 1;
-#pragma unroll
-        for (int l = 1; l <= LOOK_BITS; ++l) len += (x >> (LOOK_BITS - l)) >= sl[l - 1] ? 1 : 0;
-        uint32_t e = 0;
-        if (len <= LOOK_BITS) {
-            const int idx = (int)sl[16 + len - 1] + (int)(x >> (LOOK_BITS - len));
-            e = ((uint32_t)len << 8) | ((const uint8_t*)(sl + 32))[idx & 255];
-        }
-        look[i] = (uint16_t)e;
-    }
-    const int ncomp = R->ncomp, hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
-    McuLayout L;
-    L.yblocks = ncomp == 1 ? 1 : hs0 * vs0;
-    L.bpm = ncomp == 1 ? 1 : L.yblocks + 2;
-    L.dc_bits = L.ac_bits = L.comp_bits = 0;
-    for (int b = 0; b < L.bpm; ++b) {
-        const int c = b < L.yblocks ? 0 : 1 + b - L.yblocks;
-        L.dc_bits |= (uint32_t)(R->td[c] & 1) << b;
-        L.ac_bits |= (uint32_t)(R->ta[c] & 1) << b;
-        L.comp_bits |= (uint32_t)c << (2 * b);
-    }
+    const McuLayout L = jpeg_mcu_layout(R);
+    jpeg_build_tables<T>(tab, slow, L, tid);
+    const int hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
     const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
     const int per_interval = (int)R->restart_interval * L.bpm;
     const int nint = (int)R->rst_cnt;
@@ -686,9 +815,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
         SegState st = {rst[it] * 8u, 0, 0};
         const int nb0 = it * per_interval, nb1 = min(nb0 + per_interval, total_blocks);
         int n2;
-        int64_t d2;
-        jpeg_decode_segment<true>(W, look, slow, nat, L, st, bits + 32u, n2, d2, nb0, nb1, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0,
-                                  c1, c2, bad, mwin);
+        jpeg_decode_segment(W, tab, slow, nat, L, st, bits + 32u, n2, nb0, nb1, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad, mwin);
         if (n2 < nb1 - nb0) bad = 1;  // ran out of data before the interval's last block
     }
     const int anybad = __syncthreads_or(bad);

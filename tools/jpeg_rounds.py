@@ -45,3 +45,12 @@ print('cycles per workgroup: median %.0f max %.0f' % (np.median(tot), tot.max())
 for k in range(5):
     dlt = t[:, k + 1] - t[:, k]
     print('  %-30s median %8.0f (%4.1f %%)  max %8.0f' % (names[k], np.median(dlt), 100 * np.median(dlt) / np.median(tot), dlt.max()))
+
+if hasattr(L, 'melf_debug_jpeg_round_log'):
+    log = np.zeros((8, 32, 5), np.uint32)
+    if L.melf_debug_jpeg_round_log(log.ctypes.data_as(C.c_void_p)) == 0:
+        for im in range(2):
+            print('  image %d, per round: segments decoded again / cycles / loop iterations of the slowest lane | of all lanes, two-symbol steps among them' % im)
+            for r in log[im]:
+                if r[0]:
+                    print('    %4d %7d %4d | %6d %6d' % (r[0], r[1], r[2], r[3], r[4]))
