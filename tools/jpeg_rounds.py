@@ -25,7 +25,10 @@ out = np.zeros((n, H, W, 3), np.uint8)
 status = np.zeros(n, np.int32)
 (ptrs, sizes, keep) = _hip._file_table(blobs)
 L = _hip.lib()
-_hip.check(L.melf_jpeg_decode_batch(reader.ctx._h, ptrs, sizes, n, H, W, out.ctypes.data_as(C.c_void_p), 0, status.ctypes.data_as(C.c_void_p)))
+if len(sys.argv) > 2 and sys.argv[2] == 'crop':  # the windowed decode of melf_jpeg_process_batch instead of whole frames
+    (_, status) = reader.ctx.jpeg_process_batch(blobs, H, W)
+else:
+    _hip.check(L.melf_jpeg_decode_batch(reader.ctx._h, ptrs, sizes, n, H, W, out.ctypes.data_as(C.c_void_p), 0, status.ctypes.data_as(C.c_void_p)))
 assert (status == 0).all()
 st = np.zeros(n, np.uint32)
 assert L.melf_debug_jpeg_rounds(st.ctypes.data_as(C.c_void_p), n) == 0
