@@ -228,6 +228,14 @@ int melf_jpeg_process_batch(melf_ctx* ctx, const uint8_t* const* data, const siz
 int melf_jpeg_process_files(melf_ctx* ctx, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                             melf_result* out_host, int32_t* status);
 
+/* The same call in two halves, for a host that wants to work on the previous chunk's records meanwhile
+ * (get_meter_values does: meterelf_amd/_api.py): _begin returns at once and the call runs on a thread of the library,
+ * _end waits for it and returns its status code (message via melf_last_error as usual).  One call in flight per
+ * context; every pointer must stay valid until _end; no other call on the context between the two. */
+int melf_jpeg_process_files_begin(melf_ctx* ctx, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
+                                  melf_result* out_host, int32_t* status);
+int melf_jpeg_process_files_end(melf_ctx* ctx);
+
 /* Promise that the frames handed to melf_process_batch_dev are complete in device memory at the time of each call (they
  * do not depend on work still pending on the call's stream -- e.g. frames that were uploaded or decoded earlier and
  * synchronised).  The library then starts a call's prep kernels, which only read the frames, under the PREVIOUS call's

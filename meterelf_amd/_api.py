@@ -4,8 +4,9 @@
 
 Lazy, yields in input order, per-image ImageProcessingError becomes the `error`
 field (re-raised only when DEBUG is set).  Unlike the reference's one-at-a-time
-loop, files go to the GPU in chunks (METERELF_BATCH, default 1024), so up to one
-chunk is read ahead of the consumer.
+loop, files go to the GPU in chunks (METERELF_BATCH, default 1024) and the library already
+works on the next chunk while the current chunk's results are consumed, so up to two chunks
+are read ahead of the consumer.
 
 cv2.imread of the reference (meterelf/_image.py:49): baseline JPEG files are read (on threads, inside the
 library) and decoded on the GPU (METERELF_DECODE=gpu, the default; bit-identical to libjpeg's defaults); any other file, and
@@ -17,7 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional
 
 from . import _debug, _params
-from ._engine import MeterReader, result_to_python
+from ._engine import MeterReader, records_to_python, result_to_python
 from ._image import ImageFile
 from .exceptions import ImageProcessingError
 
@@ -56,41 +57,80 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         except ImageProcessingError as e:
             return e
 
+    # GPU decode: the library works on chunk k + 1 (file reads, Huffman tables, kernels) on its own thread
+    # (melf_jpeg_process_files_begin / _end) while this thread turns chunk k's records into Python objects and the
+    # consumer handles them.
+    begun = False  # a _begin without its _end
+
+    def _gpu_read(chunk: List[str]):
+        if hasattr(reader, 'read_jpeg_paths_batch'):
+            (records, ok) = reader.read_jpeg_paths_batch(chunk)
+            return (records, ok.tolist())
+        recs = reader.read_jpeg_paths(chunk)
+        return [None if rec is None else result_to_python(rec, reader.dial_names, f) for (rec, f) in zip(recs, chunk)]
+
     try:
-        for chunk in _chunks(filenames, batch):
+        chunks = _chunks(filenames, batch)
+        chunk = next(chunks, None)
+        while chunk is not None:
             if reader is None:
                 reader = MeterReader(params)
             assert len(reader.dial_names) == 4  # meterelf/_reading.py:166
             errors: Dict[int, ImageProcessingError] = {}
             by_index: Dict[int, object] = {}
-            on_host = list(range(len(chunk)))
-            if gpu_decode:
-                for (i, rec) in enumerate(reader.read_jpeg_paths(chunk)):  # files are read inside the library
-                    if rec is not None:
-                        by_index[i] = rec
-                on_host = [i for i in range(len(chunk)) if i not in by_index]
-            frames, where = [], []
-            host_files = [chunk[i] for i in on_host]
-            decoded = list(pool.map(_decode, host_files)) if pool is not None else [_decode(f) for f in host_files]
-            for (i, item) in zip(on_host, decoded):
-                if isinstance(item, ImageProcessingError):
-                    errors[i] = item
-                    if _debug.DEBUG:
-                        raise item
+            converted: list = [None] * len(chunk)  # (meter_values, error) of the files the GPU decoded
+            raw = None
+            if gpu_decode:  # files are read inside the library
+                if begun:
+                    raw = reader.read_jpeg_paths_end()
+                    raw = (raw[0], raw[1].tolist())
+                    begun = False
                 else:
-                    frames.append(item)
-                    where.append(i)
-            records = reader.read_many(frames) if frames else []
-            by_index.update(zip(where, records))
+                    raw = _gpu_read(chunk)
+            following = next(chunks, None)
+            overlap = following is not None and gpu_decode and batch > 1 and hasattr(reader, 'read_jpeg_paths_begin')
+            if isinstance(raw, tuple):
+                # a chunk whose files all went through the GPU decoder needs the context no more: the next one may start
+                if overlap and all(raw[1]):
+                    reader.read_jpeg_paths_begin(following)
+                    begun = True
+                converted = records_to_python(raw[0], raw[1], reader.dial_names, chunk)
+            elif raw is not None:
+                converted = raw
+            on_host = [i for i in range(len(chunk)) if converted[i] is None]
+            if on_host:
+                frames, where = [], []
+                host_files = [chunk[i] for i in on_host]
+                decoded = list(pool.map(_decode, host_files)) if pool is not None else [_decode(f) for f in host_files]
+                for (i, item) in zip(on_host, decoded):
+                    if isinstance(item, ImageProcessingError):
+                        errors[i] = item
+                        if _debug.DEBUG:
+                            raise item
+                    else:
+                        frames.append(item)
+                        where.append(i)
+                records = reader.read_many(frames) if frames else []
+                by_index.update(zip(where, records))
             for (i, filename) in enumerate(chunk):
-                meter_values: Dict[str, float] = {}
-                error = errors.get(i)
-                if error is None:
-                    (meter_values, error) = result_to_python(by_index[i], reader.dial_names, filename)
-                    if error is not None and _debug.DEBUG:
-                        raise error
+                done = converted[i]
+                if done is not None:
+                    (meter_values, error) = done
+                else:
+                    meter_values = {}
+                    error = errors.get(i)
+                    if error is None:
+                        (meter_values, error) = result_to_python(by_index[i], reader.dial_names, filename)
+                if error is not None and _debug.DEBUG and i not in errors:
+                    raise error
                 yield MeterImageData(filename, meter_values.get('value'), error, meter_values)
+            chunk = following
     finally:
+        if begun and reader is not None:
+            try:
+                reader.read_jpeg_paths_end()  # the context must be idle before it is closed
+            except Exception:
+                pass
         if pool is not None:
             pool.shutdown(wait=False)
         if reader is not None:

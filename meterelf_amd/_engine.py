@@ -66,6 +66,28 @@ def result_to_python(rec, dial_names: List[str], filename: str = '') -> Tuple[Di
     raise RuntimeError('unknown frame status {}'.format(status))
 
 
+def records_to_python(records: np.ndarray, ok, dial_names: List[str], filenames: List[str]) -> list:
+    """result_to_python over a whole record array: one (meter_values, error) per record, None where `ok[i]` is
+    false.  The columns are converted to Python objects once per array instead of field by field per record
+    (numpy scalar access costs more than everything else the API does per file)."""
+    status = records['status'].tolist()
+    pos = records['pos'][:, :len(dial_names)].tolist()
+    value = records['value'].tolist()
+    four = len(dial_names) == 4
+    out: list = []
+    for i in range(len(status)):
+        if not ok[i]:
+            out.append(None)
+        elif status[i] == _hip.FRAME_OK:
+            values = dict(zip(dial_names, pos[i]))
+            if four:
+                values['value'] = value[i]
+            out.append((values, None))
+        else:
+            out.append(result_to_python(records[i], dial_names, filenames[i]))
+    return out
+
+
 class MeterReader:
     def __init__(self, params: Params, device: int = 0, blob: Optional[np.ndarray] = None) -> None:
         self.params = params
@@ -110,23 +132,50 @@ class MeterReader:
                     out[i] = recs[k]
         return out
 
-    def read_jpeg_paths(self, paths: List[str]) -> List[Optional[np.void]]:
-        """File names -> records (melf_jpeg_process_files: the library reads the files itself).  None for a
-        file the GPU decoder does not take (unreadable, not a baseline JPEG, corrupt): the caller's host branch."""
-        out: List[Optional[np.void]] = [None] * len(paths)
-        todo = list(range(len(paths)))
-        while todo:
+    def read_jpeg_paths_batch(self, paths: List[str]) -> Tuple[np.ndarray, np.ndarray]:
+        """File names -> (records, ok) (melf_jpeg_process_files: the library reads the files itself).  ok[i] is
+        false for a file the GPU decoder does not take (unreadable, not a baseline JPEG, corrupt): the caller's
+        host branch."""
+        records = np.zeros(len(paths), _hip.RESULT_DTYPE)
+        ok = np.zeros(len(paths), bool)
+        todo = np.arange(len(paths))
+        while len(todo):
             (recs, status, _hw) = self.ctx.jpeg_process_files([paths[i] for i in todo])
-            again = []
-            for (k, i) in enumerate(todo):
-                if status[k] == _hip.JPEG_OK:
-                    out[i] = recs[k]
-                elif status[k] == _hip.JPEG_SIZE_MISMATCH:
-                    again.append(i)
+            status = np.asarray(status)
+            good = status == _hip.JPEG_OK
+            records[todo[good]] = recs[good]
+            ok[todo[good]] = True
+            again = todo[status == _hip.JPEG_SIZE_MISMATCH]
             if len(again) == len(todo):
                 break  # cannot happen (the first accepted file defines the size); never loop forever
             todo = again
-        return out
+        return records, ok
+
+    def read_jpeg_paths_begin(self, paths: List[str]) -> None:
+        """read_jpeg_paths_batch in two halves: the library works on `paths` on its own thread until
+        read_jpeg_paths_end() collects (records, ok).  Nothing else may use this reader in between."""
+        self._begun = list(paths)
+        self.ctx.jpeg_process_files_begin(self._begun)
+
+    def read_jpeg_paths_end(self) -> Tuple[np.ndarray, np.ndarray]:
+        paths = self._begun
+        self._begun = None
+        (recs, status, _hw) = self.ctx.jpeg_process_files_end()
+        status = np.asarray(status)
+        ok = status == _hip.JPEG_OK
+        records = np.zeros(len(paths), _hip.RESULT_DTYPE)
+        records[ok] = recs[ok]
+        again = np.flatnonzero(status == _hip.JPEG_SIZE_MISMATCH)
+        if len(again):  # files of another frame size: their own call(s), now
+            (r2, ok2) = self.read_jpeg_paths_batch([paths[i] for i in again])
+            records[again] = r2
+            ok[again] = ok2
+        return records, ok
+
+    def read_jpeg_paths(self, paths: List[str]) -> List[Optional[np.void]]:
+        """The same as a list: a record, or None where the caller has to decode on the host."""
+        (records, ok) = self.read_jpeg_paths_batch(paths)
+        return [records[i] if ok[i] else None for i in range(len(paths))]
 
     def read_many(self, images: List[np.ndarray], cropped: Optional[List[bool]] = None) -> List[np.void]:
         """Heterogeneous list of frames: grouped by shape, one batched call per group."""

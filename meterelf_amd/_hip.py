@@ -70,7 +70,7 @@ EXPORTS = [
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
-    'melf_jpeg_process_files',
+    'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end',
 ]
 
 _lib = None
@@ -122,6 +122,8 @@ def lib():
     L.melf_jpeg_decode_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
     L.melf_jpeg_process_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.melf_jpeg_process_files.argtypes = [vp, vp, C.c_int, i32p, i32p, vp, vp]
+    L.melf_jpeg_process_files_begin.argtypes = [vp, vp, C.c_int, i32p, i32p, vp, vp]
+    L.melf_jpeg_process_files_end.argtypes = [vp]
     if L.melf_abi_version() != ABI_VERSION:
         raise HipError('libmeterelf_hip.so ABI version mismatch')
     _lib = L
@@ -379,6 +381,24 @@ class Context:
             arr = (C.c_char_p * n)(*enc)
             check(self._L.melf_jpeg_process_files(self._h, arr, n, C.byref(H), C.byref(W), _ptr(out), _ptr(status)))
         return out, status, (H.value, W.value)
+
+    def jpeg_process_files_begin(self, paths):
+        """Starts jpeg_process_files(paths) on a thread of the library and returns at once; jpeg_process_files_end()
+        waits for it.  One call in flight per context, no other call on it in between."""
+        n = len(paths)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        status = np.zeros(n, np.int32)
+        hw = (C.c_int32(0), C.c_int32(0))
+        enc = [os.fsencode(p) for p in paths]
+        arr = (C.c_char_p * max(n, 1))(*enc)
+        check(self._L.melf_jpeg_process_files_begin(self._h, arr, n, C.byref(hw[0]), C.byref(hw[1]), _ptr(out), _ptr(status)))
+        self._files_pending = (out, status, hw, arr, enc)  # everything the library points into, alive until _end
+
+    def jpeg_process_files_end(self):
+        (out, status, hw, _arr, _enc) = self._files_pending
+        self._files_pending = None
+        check(self._L.melf_jpeg_process_files_end(self._h))
+        return out, status, (hw[0].value, hw[1].value)
 
     def set_frames_resident(self, on):
         """Promise that the frames of every process_batch_dev call are complete in HBM when the call is made: a call's prep

@@ -1,10 +1,14 @@
 // Host side of libmeterelf_hip: calibration blob, per-GPU context, entry points.
 // The C ABI is declared and documented in include/meterelf_hip.h.
 #include <emmintrin.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -265,6 +269,14 @@ struct melf_ctx {
     uint8_t* d_stage_out = nullptr;
     size_t stage_out_cap = 0;
     JpegWorkspace* jpeg = nullptr;     // created by the first JPEG batch
+    // melf_jpeg_process_files: the files' bytes (grow-only: no per-file allocation, no zero fill, and after the first
+    // call no fresh pages to fault in), and the call in flight of the begin / end pair
+    uint8_t* file_arena = nullptr;
+    size_t file_arena_cap = 0;
+    std::thread files_thread;
+    bool files_in_flight = false;
+    int files_rc = 0;
+    std::string files_err;
     // profiling
     bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
     int profiling = 0;                // 0 off, 1 every kernel, 2 only the dominant kernel (k_match)
@@ -535,6 +547,8 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
 extern "C" void melf_ctx_destroy(melf_ctx* c)
 {
     if (!c) return;
+    if (c->files_thread.joinable()) c->files_thread.join();
+    free(c->file_arena);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
@@ -1322,37 +1336,69 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
     if (n == 0) return MELF_SUCCESS;
     if (!paths || !out_host || !status || !H_used || !W_used || n < 0 || n > 32768) return fail(MELF_ERR_INVALID, "bad argument");
-    std::vector<std::vector<uint8_t>> blobs;
-    std::vector<int> hs, ws, oks;
+    // Two passes on the host pool: open + size, then -- the offsets known -- read into the context's ONE grow-only
+    // arena (no per-file allocation, no zero fill, no fresh pages to fault in after the first call: with sixteen
+    // threads faulting pages of the same address space the per-file buffers cost more than the reads).
+    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int> hs, ws, oks, fds;
+    std::vector<size_t> off;
     try {
-        blobs.resize(n);
-        hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0);
+        hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0); fds.assign(n, -1);
+        off.assign((size_t)n + 1, 0);
     } catch (const std::exception&) {
         return fail(MELF_ERR_INVALID, "out of host memory");
     }
-    {
-        // a camera frame is tens of KiB; a "JPEG" of more than 64 MiB is not one of ours (and n of them would not fit)
-        const long max_file = 64L << 20;
-        host_pool().run(n, [&](int i) {
-            FILE* fp = paths[i] ? fopen(paths[i], "rb") : nullptr;
-            if (!fp) { status[i] = MELF_JPEG_UNREADABLE; return; }
-            fseek(fp, 0, SEEK_END);
-            const long sz = ftell(fp);
-            fseek(fp, 0, SEEK_SET);
-            if (sz <= 0 || sz > max_file) { fclose(fp); status[i] = sz > max_file ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_UNREADABLE; return; }
-            try {  // nothing may escape a pool task (melf_threads.h)
-                blobs[i].resize((size_t)sz);
-            } catch (const std::exception&) {
-                fclose(fp);
-                status[i] = MELF_JPEG_UNREADABLE;
-                return;
-            }
-            const size_t got = fread(blobs[i].data(), 1, (size_t)sz, fp);
-            fclose(fp);
-            if (got != (size_t)sz) { blobs[i].clear(); status[i] = MELF_JPEG_UNREADABLE; return; }
-            status[i] = MELF_JPEG_OK;
-            jpeg_probe(blobs[i].data(), blobs[i].size(), &hs[i], &ws[i], &oks[i], nullptr);
-        });
+    // a camera frame is tens of KiB; a "JPEG" of more than 64 MiB is not one of ours (and n of them would not fit)
+    const off_t max_file = (off_t)64 << 20;
+    host_pool().run(n, [&](int i) {
+        const int fd = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+        if (fd < 0) { status[i] = MELF_JPEG_UNREADABLE; return; }
+        struct stat sb;
+        const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+        if (!regular || sb.st_size <= 0 || sb.st_size > max_file) {
+            status[i] = regular && sb.st_size > max_file ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_UNREADABLE;
+            close(fd);
+            return;
+        }
+        fds[i] = fd;
+        off[(size_t)i + 1] = (size_t)sb.st_size;
+        status[i] = MELF_JPEG_OK;
+    });
+    const auto t_opened = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) off[(size_t)i + 1] += off[i];
+    if (off[n] > c->file_arena_cap) {
+        const size_t want = off[n] + off[n] / 4 + (1u << 20);
+        uint8_t* q = (uint8_t*)realloc(c->file_arena, want);
+        if (!q) {
+            for (int i = 0; i < n; ++i) if (fds[i] >= 0) close(fds[i]);
+            return fail(MELF_ERR_INVALID, "out of host memory");
+        }
+        c->file_arena = q;
+        c->file_arena_cap = want;
+    }
+    uint8_t* const base = c->file_arena;
+    const auto t_arena = std::chrono::steady_clock::now();
+    host_pool().run(n, [&](int i) {
+        if (fds[i] < 0) return;
+        const size_t sz = off[(size_t)i + 1] - off[i];
+        size_t got = 0;
+        while (got < sz) {
+            const ssize_t r = read(fds[i], base + off[i] + got, sz - got);
+            if (r > 0) got += (size_t)r;
+            else if (r < 0 && errno == EINTR) continue;
+            else break;
+        }
+        close(fds[i]);
+        if (got != sz) { status[i] = MELF_JPEG_UNREADABLE; return; }
+        jpeg_probe(base + off[i], sz, &hs[i], &ws[i], &oks[i], nullptr);
+    });
+    if (trace) {
+        const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): open + size %.2f ms, arena %.2f ms, read + probe %.2f ms\n", n, off[n] / 1e6,
+                ms(t0, t_opened), ms(t_opened, t_arena), ms(t_arena, std::chrono::steady_clock::now()));
     }
     // the batch shape: that of the first file the decoder takes
     int H = 0, W = 0;
@@ -1366,7 +1412,7 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
         if (status[i] != MELF_JPEG_OK) continue;
         if (!oks[i]) { status[i] = hs[i] > 0 ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_CORRUPT; continue; }
         if (hs[i] != H || ws[i] != W) { status[i] = MELF_JPEG_SIZE_MISMATCH; continue; }
-        ptr.push_back(blobs[i].data()); len.push_back(blobs[i].size()); where.push_back(i);
+        ptr.push_back(base + off[i]); len.push_back(off[(size_t)i + 1] - off[i]); where.push_back(i);
     }
     if (ptr.empty()) return MELF_SUCCESS;
     const int m = (int)ptr.size();
@@ -1374,5 +1420,40 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
     std::vector<int32_t> st(m);
     if (int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data())) return rc;
     for (int k = 0; k < m; ++k) { out_host[where[k]] = res[k]; status[where[k]] = st[k]; }
+    return MELF_SUCCESS;
+}
+
+// The same call split in two for a scripting host: _begin returns at once, the work (file reads, Huffman tables,
+// upload, kernels, records) runs on a thread of the library, _end waits for it and returns its code.  Between the two
+// the caller can turn the PREVIOUS chunk's records into its own objects -- with a helper thread of the host language
+// instead, the interpreter lock's hand-over (5 ms in CPython) eats the overlap.  One call in flight per context; all
+// pointers must stay valid until _end; no other call on the context in between.
+extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
+                                             melf_result* out_host, int32_t* status)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (c->files_in_flight) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_begin: a call is already in flight on this context");
+    if (c->files_thread.joinable()) c->files_thread.join();
+    c->files_rc = 0;
+    c->files_err.clear();
+    try {
+        c->files_thread = std::thread([=]() {
+            c->files_rc = melf_jpeg_process_files(c, paths, n, H_used, W_used, out_host, status);
+            if (c->files_rc) c->files_err = g_err;  // this thread's message, for the thread that calls _end
+        });
+    } catch (const std::exception& e) {
+        return fail(MELF_ERR_INVALID, std::string("cannot start a thread: ") + e.what());
+    }
+    c->files_in_flight = true;
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_jpeg_process_files_end(melf_ctx* c)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (!c->files_in_flight) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_end without _begin");
+    c->files_thread.join();
+    c->files_in_flight = false;
+    if (c->files_rc) return fail(c->files_rc, c->files_err);
     return MELF_SUCCESS;
 }

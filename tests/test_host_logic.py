@@ -176,6 +176,35 @@ def test_result_to_python_debug_dial_positions(monkeypatch):
                                  'unreadable dials = 0.001, 0.1)')
 
 
+def test_records_to_python_equals_per_record_conversion():
+    """The whole-array conversion of the file API gives what result_to_python gives record by record."""
+    names = ['0.0001', '0.001', '0.01', '0.1']
+    rng = np.random.default_rng(5)
+    recs = np.zeros(40, _hip.RESULT_DTYPE)
+    recs['status'] = rng.integers(0, 4, 40)
+    recs['pos'] = rng.uniform(0, 10, (40, _hip.MAX_DIALS))
+    recs['value'] = rng.uniform(0, 1000, 40)
+    recs['match_val'] = rng.uniform(0, 2e7, 40).astype(np.float32)
+    recs['failed_dial'] = rng.integers(0, 4, 40)
+    recs['unreadable_mask'] = rng.integers(1, 16, 40)
+    ok = (rng.integers(0, 5, 40) > 0).tolist()
+    files = ['f%d' % i for i in range(40)]
+    got = _engine.records_to_python(recs, ok, names, files)
+    assert {_hip.FRAME_OK, _hip.FRAME_DIALS_NOT_FOUND, _hip.FRAME_NEEDLE_CONTOURS_NOT_FOUND,
+            _hip.FRAME_ANGLE_UNDETERMINED} == set(recs['status'].tolist())
+    for i in range(40):
+        if not ok[i]:
+            assert got[i] is None
+            continue
+        (vals, err) = _engine.result_to_python(recs[i], names, files[i])
+        assert got[i][0] == vals and list(got[i][0]) == list(vals)
+        assert all(type(v) is float for v in got[i][0].values())
+        assert (got[i][1] is None) == (err is None)
+        if err is not None:
+            assert type(got[i][1]) is type(err) and got[i][1].get_message() == err.get_message()
+            assert got[i][1].filename == err.filename
+
+
 def test_no_gpu_means_loud_failure():
     if _hip.device_count() > 0:
         pytest.skip('a GPU is visible')

@@ -18,7 +18,9 @@ files = sorted(glob.glob(os.path.join(d, '*.jpg'))) * 32
 
 
 def run(label):
-    list(get_meter_values(pfile, files[:64]))
+    # warm-up with the same chunk size: the first chunk of a size in a process pays for first-time device and pinned
+    # allocations of that size (hundreds of milliseconds), later readers get them back at once
+    list(get_meter_values(pfile, files[:2 * int(os.environ.get('METERELF_BATCH', '64'))]))
     t0 = time.perf_counter()
     vals = [r.value for r in get_meter_values(pfile, files)]
     dt = time.perf_counter() - t0
