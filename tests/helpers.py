@@ -50,3 +50,18 @@ class OracleReader:
 def params_file_of(params):
     import os
     return os.path.join(os.path.dirname(params.dials_file), 'params.yml')
+
+
+def hip_runtime():
+    """The HIP runtime instance libmeterelf_hip.so is bound to, for tests that allocate device memory themselves.
+    ctypes.CDLL('libamdhip64.so') is not good enough: once torch has been imported the process can hold two copies
+    (torch ships its own and loads it by path), and device memory of one is unknown to the other (hipMalloc fails with
+    'no device' or the pointers are foreign).  The library is always loaded before torch in this suite, so its copy is
+    the mapped one that does not live under torch/."""
+    import ctypes as C
+
+    from meterelf_amd import _hip
+    _hip.lib()
+    paths = sorted({line.split()[-1] for line in open('/proc/self/maps') if 'libamdhip64' in line})
+    ours = [p for p in paths if '/torch/' not in p] or paths
+    return C.CDLL(ours[0])

@@ -14,6 +14,8 @@ import re
 import numpy as np
 import pytest
 
+from tests.helpers import hip_runtime
+
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -659,7 +661,7 @@ def test_stream_of_batches_matches_single_calls(env):
     ctx = e['reader'].ctx
     ref = ctx.process_batch(frames)
     L = _hip.lib()
-    hip = C.CDLL('libamdhip64.so')
+    hip = hip_runtime()
     nbytes = frames.nbytes
     (d_frames, d_res) = (C.c_void_p(), C.c_void_p())
     assert hip.hipMalloc(C.byref(d_frames), C.c_size_t(nbytes)) == 0
@@ -691,7 +693,7 @@ def test_host_fed_batches_crop_upload(env):
     ores = po.process_frames(frames, e['oparams'])
     _compare_records(recs, ores, tag='host-fed')
     assert sum(int(r['status']) == 0 for r in recs) > 550
-    hip = C.CDLL('libamdhip64.so')
+    hip = hip_runtime()
     d_frames = C.c_void_p()
     assert hip.hipMalloc(C.byref(d_frames), C.c_size_t(frames.nbytes)) == 0
     try:
@@ -809,7 +811,7 @@ def test_two_caller_streams_use_two_lanes(env):
     frames = synth_frames(_good(e['files']), 192, 123)
     ctx = e['reader'].ctx
     ref = ctx.process_batch(frames)
-    hip = C.CDLL('libamdhip64.so')
+    hip = hip_runtime()
     (n, H, W) = (64, frames.shape[1], frames.shape[2])
     rsz = _hip.RESULT_DTYPE.itemsize
     (d_frames, d_res) = (C.c_void_p(), C.c_void_p())
@@ -851,7 +853,7 @@ def test_frames_resident_hint_same_records(env):
     frames = synth_frames(_good(e['files']), 3 * 160, 321)
     ctx = e['reader'].ctx
     ref = ctx.process_batch(frames)
-    hip = C.CDLL('libamdhip64.so')
+    hip = hip_runtime()
     (n, H, W) = (160, frames.shape[1], frames.shape[2])
     rsz = _hip.RESULT_DTYPE.itemsize
     (d_frames, d_res) = (C.c_void_p(), C.c_void_p())

@@ -313,3 +313,68 @@ def test_get_meter_values_never_touches_the_host_decoder_for_fixtures(sd, monkey
             assert line == exp, (r.filename, line, exp)
         n_values += 1 if r.value else 0
     assert n_values >= len(files) - 2
+
+
+@pytest.mark.gpu
+def test_process_files_in_two_halves(tmp_path):
+    """melf_jpeg_process_files_begin / _end: the records of the one-piece call; a second _begin before _end and an
+    _end without _begin are refused; files of two frame sizes and an unreadable one are routed as in the one-piece call."""
+    from meterelf_amd import MeterReader, _hip, _params
+    reader = MeterReader(_params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml')))
+    try:
+        files = _files('sample-images1') + [str(tmp_path / 'missing.jpg')]
+        (ref, ref_status, ref_hw) = reader.ctx.jpeg_process_files(files)
+        with pytest.raises(_hip.HipError):
+            reader.ctx._files_pending = (None, None, (None, None), None, None)
+            reader.ctx.jpeg_process_files_end()  # nothing in flight
+        reader.ctx.jpeg_process_files_begin(files)
+        pending = reader.ctx._files_pending
+        with pytest.raises(_hip.HipError):
+            reader.ctx.jpeg_process_files_begin(files[:3])  # one call in flight per context
+        reader.ctx._files_pending = pending
+        (got, status, hw) = reader.ctx.jpeg_process_files_end()
+        assert hw == ref_hw and np.array_equal(status, ref_status)
+        ok = status == _hip.JPEG_OK
+        # the first file the decoder takes sets the call's frame size (the two 640 x 480 frames come first in
+        # sample-images1); the 480 x 640 ones come back as 'another size' for a call of their own
+        assert ok.sum() == 2 and (status == _hip.JPEG_SIZE_MISMATCH).sum() == len(files) - 3
+        assert got[ok].tobytes() == ref[ok].tobytes()
+        assert status[-1] == _hip.JPEG_UNREADABLE
+        # the reader's pair: every size gets its call, like read_jpeg_paths_batch
+        (r1, ok1) = reader.read_jpeg_paths_batch(files)
+        reader.read_jpeg_paths_begin(files)
+        (r2, ok2) = reader.read_jpeg_paths_end()
+        assert np.array_equal(ok1, ok2) and r1[ok1].tobytes() == r2[ok2].tobytes() and ok1.sum() == len(files) - 1
+    finally:
+        reader.close()
+
+
+@pytest.mark.gpu
+def test_get_meter_values_overlapped_chunks_and_early_close(tmp_path, monkeypatch):
+    """Small chunks, so that the library works on chunk k + 1 while chunk k is consumed: same results as one big chunk,
+    with a file for the host branch in the middle (no overlap across that chunk); a generator dropped half way
+    leaves no call in flight behind."""
+    from PIL import Image
+
+    from meterelf_amd import get_meter_values
+    pfile = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
+    files = _files('sample-images2')[:60]
+    prog = str(tmp_path / 'progressive.jpg')
+    Image.open(files[7]).save(prog, 'JPEG', progressive=True, quality=95)
+    files = files[:25] + [prog, str(tmp_path / 'missing.jpg')] + files[25:]
+    monkeypatch.setenv('METERELF_BATCH', '1024')
+    ref = list(get_meter_values(pfile, files))
+    monkeypatch.setenv('METERELF_BATCH', '8')
+    got = list(get_meter_values(pfile, files))
+    assert len(got) == len(ref) == len(files)
+    for (a, b) in zip(got, ref):
+        assert a.filename == b.filename and a.value == b.value and a.meter_values == b.meter_values
+        assert (a.error is None) == (b.error is None)
+        if a.error is not None:
+            assert a.error.get_message() == b.error.get_message()
+    assert got[26].error is not None and got[25].value is not None
+    gen = get_meter_values(pfile, files)
+    first = [next(gen) for _ in range(10)]  # chunk 2 is being worked on by now
+    gen.close()
+    assert [r.value for r in first] == [r.value for r in ref[:10]]
+    assert [r.value for r in get_meter_values(pfile, files[:20])] == [r.value for r in ref[:20]]

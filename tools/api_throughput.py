@@ -38,6 +38,12 @@ for batch in (64, 256, 1024):
     os.environ['METERELF_BATCH'] = str(batch)
     got = run('GPU decode, chunks of %d' % batch)
     assert got == ref, 'values differ between decode paths'
+# a list long enough for the per-call costs (context creation and release, ~30 ms) to stop mattering
+short = files
+files = files * 4
+got = run('GPU decode, chunks of 1024')
+assert got == ref * 4
+files = short
 
 # the decode + read call alone, file bytes already in memory
 reader = MeterReader(_params.load(pfile))
