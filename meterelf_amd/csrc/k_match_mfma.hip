@@ -155,36 +155,43 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
 
 // ---------------------------------------------------------------------------
 // k_colsum: ws[g][y][x][n] = sum_{i < th} R[g][y + i][x][n]  (u32), exact.
-// One workgroup (128 threads) per 128 (x, n) columns of a group and per chunk of output rows: the tile of R is
-// fetched with coalesced, deeply pipelined loads into LDS, then every thread slides down its own column.
-// grid = (rwp * 32 / 128, groups, row chunks).
+// One workgroup per 128 (x, n) columns of a group and per chunk of output rows, Q threads per column: the tile of R is
+// fetched with coalesced, deeply pipelined loads into LDS (thread q of a column takes rows q, q + Q, ...), then thread
+// q slides down its own Q-th of the column's output rows (its first window summed from LDS).  With one thread per
+// column the launch is 1024 waves of latency-bound work -- one per SIMD; Q = 4 gives the loads four times the
+// requests in flight and cuts the serial slide to a quarter.
+// grid = (rwp * 32 / 128, groups, row chunks), block = 128 * Q.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_colsum(const uint16_t* __restrict__ R, int rows, int th, int rh, int rowlen /* rwp * 32 */,
-                                                int ychunk, uint32_t* __restrict__ ws)
+__global__ __launch_bounds__(1024) void k_colsum(const uint16_t* __restrict__ R, int rows, int th, int rh, int rowlen /* rwp * 32 */,
+                                                 int ychunk, uint32_t* __restrict__ ws)
 {
     extern __shared__ uint16_t col[];  // [rows of the chunk][128]
-    const int t = threadIdx.x, grp = blockIdx.y, c0 = blockIdx.x * 128;
+    const int t = threadIdx.x & 127, q = threadIdx.x >> 7, nq = blockDim.x >> 7;
+    const int grp = blockIdx.y, c0 = blockIdx.x * 128;
     const int y0 = blockIdx.z * ychunk, y1 = min(rh, y0 + ychunk);
     const int nin = y1 - y0 + th - 1;
     const uint16_t* r = R + ((size_t)grp * rows + y0) * rowlen + c0 + t;
     // sixteen independent loads in flight per thread (a loop of single loads waits for each one)
-    int y = 0;
-    for (; y + 16 <= nin; y += 16) {
+    int y = q;
+    for (; y + 15 * nq < nin; y += 16 * nq) {
         uint16_t v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = r[(size_t)(y + k) * rowlen];
+        for (int k = 0; k < 16; ++k) v[k] = r[(size_t)(y + k * nq) * rowlen];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) col[(y + k) * 128 + t] = v[k];
+        for (int k = 0; k < 16; ++k) col[(y + k * nq) * 128 + t] = v[k];
     }
-    for (; y < nin; ++y) col[y * 128 + t] = r[(size_t)y * rowlen];
+    for (; y < nin; y += nq) col[y * 128 + t] = r[(size_t)y * rowlen];
     __syncthreads();
+    const int nout = y1 - y0, per = (nout + nq - 1) / nq;
+    const int a = q * per, b = min(nout, a + per);
+    if (a >= b) return;
     uint32_t* o = ws + ((size_t)grp * rh + y0) * rowlen + c0 + t;
     uint32_t s = 0;
-    for (int yy = 0; yy < th - 1; ++yy) s += col[yy * 128 + t];
-    for (int y = 0; y < y1 - y0; ++y) {
-        s += col[(y + th - 1) * 128 + t];
-        o[(size_t)y * rowlen] = s;
-        s -= col[y * 128 + t];
+    for (int yy = a; yy < a + th - 1; ++yy) s += col[yy * 128 + t];
+    for (int yo = a; yo < b; ++yo) {
+        s += col[(yo + th - 1) * 128 + t];
+        o[(size_t)yo * rowlen] = s;
+        s -= col[yo * 128 + t];
     }
 }
 
@@ -549,8 +556,9 @@ void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, in
     }
     if (from_bgr) hipLaunchKernelGGL(k_prep_lplane<true>, grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
     else hipLaunchKernelGGL(k_prep_lplane<false>, grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
-    hipLaunchKernelGGL(k_colsum, dim3(rwp * 32 / 128, groups, nchunks), dim3(128), col_bytes, stream, d_r, src.rows, th, rh, rwp * 32,
-                       ychunk, d_ws);
+    static const int colsum_q = getenv("MELF_COLSUM_Q") ? std::min(8, std::max(1, atoi(getenv("MELF_COLSUM_Q")))) : 4;  // threads per column
+    hipLaunchKernelGGL(k_colsum, dim3(rwp * 32 / 128, groups, nchunks), dim3(128 * colsum_q), col_bytes, stream, d_r, src.rows, th, rh,
+                       rwp * 32, ychunk, d_ws);
 }
 
 void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
