@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--sample-dir', default='sample-images1')
     ap.add_argument('--hw', default='480x640', help='fused stage: frame rows x columns')
+    ap.add_argument('--profiling', type=int, default=1, help='full stage: 0 no event records, 1 every kernel, 2 only k_match (the bench setting)')
+    ap.add_argument('--device-records', action='store_true', help='full stage: records stay in HBM, no copy and no sync per call (the bench loop)')
     ap.add_argument('--nbuf', type=int, default=4, help='distinct buffer sets the launches rotate over (beyond the Infinity Cache)')
     a = ap.parse_args()
     import torch
@@ -61,8 +63,15 @@ def main():
         NB = max(1, a.nbuf)
         frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), NB * B, 2024, dev)
         (H, W) = base.shape[1:3]
+        ctx.set_profiling(a.profiling)
+        recs = torch.empty((NB, B * _hip.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         for i in range(a.iters):
-            ctx.process_batch_dev(frames.data_ptr() + (i % NB) * B * H * W * 3, B, H, W, want_host=True, stream=stream)
+            if a.device_records:
+                ctx.process_batch_dev(frames.data_ptr() + (i % NB) * B * H * W * 3, B, H, W, want_host=False, stream=stream,
+                                      d_results_ptr=recs[i % NB].data_ptr())
+            else:
+                ctx.process_batch_dev(frames.data_ptr() + (i % NB) * B * H * W * 3, B, H, W, want_host=True, stream=stream)
+        torch.cuda.synchronize()
     t = ctx.timings()
     for (k, (ms, n)) in t.items():
         if n:
