@@ -306,7 +306,8 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     ctx.timings()
     run(max(3, nbuf))
     kt_all = ctx.timings()
-    # ... then the timed region with stamps on the dominant kernel only (no extra packets in the queue)
+    # ... then the timed region with stamps on the dominant kernel only (the dispatch's own start / stop events: ~10 us of
+    # idle time around that kernel per step)
     ctx.set_profiling(2)
     ns = env.args.streams
     # untimed pre-heat right in front of the timed region: the event read-back above leaves the GPU idle for a moment and
