@@ -883,3 +883,69 @@ def test_frames_resident_hint_same_records(env):
             hip.hipStreamDestroy(s)
         hip.hipFree(d_frames)
         hip.hipFree(d_res)
+
+
+# ---- BASELINE.json's full per-GPU sizes: the oracle is too slow there, so what is checked is what cannot depend on the
+# ---- batch -- a frame's record is a function of that frame alone -- plus the oracle on a sample of the same frames
+def _records_equal(a, b):
+    return a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize('sd,seed', [('sample-images1', 2024), ('sample-images2', 2025)])
+def test_full_size_batch_properties(env, sd, seed):
+    """Configs 3 and 4: 1024 frames in one call.  (1) Batch-composition invariance: the records equal those of the same
+    frames in ragged pieces (one piece exercises the small-batch kernels).  (2) Permutation equivariance.  (3) A frame
+    repeated in the batch gives the same record everywhere.  (4) The oracle on 48 of the 1024."""
+    from oracle import pyoracle as po
+    e = env[sd]
+    reader = e['reader']
+    base = synth_frames(_good(e['files']), 256, seed, shift=12, sigma=6.0)
+    rng = np.random.default_rng(seed + 1)
+    pick = rng.integers(0, 256, 1024)
+    pick[:256] = np.arange(256)
+    frames = base[pick]  # every base frame at least once, the rest repeats in random places
+    whole = reader.read_frames(frames)
+    assert len(whole) == 1024
+    # (1) pieces: 1000 + 24, and 33 + 479 + 512
+    for cuts in ((0, 1000, 1024), (0, 33, 512, 1024)):
+        parts = np.concatenate([reader.read_frames(frames[a:b]) for (a, b) in zip(cuts, cuts[1:])])
+        assert _records_equal(parts, whole), cuts
+    # (2) a permutation of the batch permutes the records
+    perm = rng.permutation(1024)
+    assert _records_equal(reader.read_frames(frames[perm]), whole[perm])
+    # (3) repeats
+    first = {}
+    for (i, b) in enumerate(pick.tolist()):
+        j = first.setdefault(b, i)
+        assert whole[i].tobytes() == whole[j].tobytes(), (i, j)
+    # (4) the oracle on a sample
+    sample = rng.choice(1024, 48, replace=False)
+    _compare_records(whole[sample], po.process_frames(frames[sample], e['oparams']), tag=sd + ' full size')
+    statuses = set(int(s) for s in whole['status'])
+    assert 0 in statuses and len(statuses) >= 2  # readable frames and at least one kind of failure in the batch
+
+
+def test_full_size_fused_mask_properties(env):
+    """Config 2: B = 256 frames of 640 x 480 in one launch.  The mask of a frame does not depend on its neighbours in the
+    batch (pieces, permutation), closing is idempotent on its own output's domain (mask pixels are 0 / 255 only), and
+    the oracle agrees on 6 of the 256 frames."""
+    from oracle import pyoracle as po
+    ctx = env['sample-images1']['reader'].ctx
+    p = ctx.params
+    rng = np.random.default_rng(1234)
+    tiles = _blobby(rng, 16, 480, 640)
+    pick = rng.integers(0, 16, 256)
+    frames = tiles[pick]
+    # per-frame variation so that no two frames are equal: a different circular shift each
+    for i in range(256):
+        frames[i] = np.roll(frames[i], (i * 7) % 480, axis=0)
+    whole = ctx.hls_inrange_close(frames)
+    assert whole.shape == (256, 480, 640) and set(np.unique(whole).tolist()) <= {0, 255}
+    parts = np.concatenate([ctx.hls_inrange_close(frames[a:b]) for (a, b) in ((0, 100), (100, 101), (101, 256))])
+    assert np.array_equal(parts, whole)
+    perm = rng.permutation(256)
+    assert np.array_equal(ctx.hls_inrange_close(frames[perm]), whole[perm])
+    lo, hi = list(p.needle_lo), list(p.needle_hi)
+    for f in rng.choice(256, 6, replace=False):
+        assert np.array_equal(whole[f], po.hls_inrange_close(frames[f], p.hue_shift, lo, hi)), f
+    assert (whole > 0).any()
