@@ -1333,10 +1333,9 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
 
 // get_meter_values' inner loop for file names (meterelf/_api.py:22-33): the files are read here, on threads,
 // so that a scripting host pays one call per chunk instead of an open/read per file.
-extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
-                                       melf_result* out_host, int32_t* status)
+static int jpeg_process_files_impl(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
+                                   melf_result* out_host, int32_t* status)
 {
-    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
     if (n == 0) return MELF_SUCCESS;
     if (!paths || !out_host || !status || !H_used || !W_used || n < 0 || n > 32768) return fail(MELF_ERR_INVALID, "bad argument");
     // Two passes on the host pool: open + size, then -- the offsets known -- read into the context's ONE grow-only
@@ -1344,27 +1343,25 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
     // threads faulting pages of the same address space the per-file buffers cost more than the reads).
     static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<int> hs, ws, oks, fds;
+    std::vector<int> hs, ws, oks;
     std::vector<size_t> off;
     try {
-        hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0); fds.assign(n, -1);
+        hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0);
         off.assign((size_t)n + 1, 0);
     } catch (const std::exception&) {
         return fail(MELF_ERR_INVALID, "out of host memory");
     }
     // a camera frame is tens of KiB; a "JPEG" of more than 64 MiB is not one of ours (and n of them would not fit)
     const off_t max_file = (off_t)64 << 20;
+    // pass 1: sizes only.  No descriptor stays open between the passes: a chunk of 1024 files would sit right at the
+    // usual soft limit of 1024 open files, and a call may carry 32 768.
     host_pool().run(n, [&](int i) {
-        const int fd = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
-        if (fd < 0) { status[i] = MELF_JPEG_UNREADABLE; return; }
         struct stat sb;
-        const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+        const bool regular = paths[i] && stat(paths[i], &sb) == 0 && S_ISREG(sb.st_mode);
         if (!regular || sb.st_size <= 0 || sb.st_size > max_file) {
             status[i] = regular && sb.st_size > max_file ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_UNREADABLE;
-            close(fd);
             return;
         }
-        fds[i] = fd;
         off[(size_t)i + 1] = (size_t)sb.st_size;
         status[i] = MELF_JPEG_OK;
     });
@@ -1373,26 +1370,27 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
     if (off[n] > c->file_arena_cap) {
         const size_t want = off[n] + off[n] / 4 + (1u << 20);
         uint8_t* q = (uint8_t*)realloc(c->file_arena, want);
-        if (!q) {
-            for (int i = 0; i < n; ++i) if (fds[i] >= 0) close(fds[i]);
-            return fail(MELF_ERR_INVALID, "out of host memory");
-        }
+        if (!q) return fail(MELF_ERR_INVALID, "out of host memory");
         c->file_arena = q;
         c->file_arena_cap = want;
     }
     uint8_t* const base = c->file_arena;
     const auto t_arena = std::chrono::steady_clock::now();
+    // pass 2: open, read the size seen in pass 1, close (a file that shrank meanwhile is unreadable; of one that grew
+    // the decoder sees the first part and reports a corrupt stream: both go to the caller's host branch)
     host_pool().run(n, [&](int i) {
-        if (fds[i] < 0) return;
+        if (status[i] != MELF_JPEG_OK) return;
+        const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
+        if (fd < 0) { status[i] = MELF_JPEG_UNREADABLE; return; }
         const size_t sz = off[(size_t)i + 1] - off[i];
         size_t got = 0;
         while (got < sz) {
-            const ssize_t r = read(fds[i], base + off[i] + got, sz - got);
+            const ssize_t r = read(fd, base + off[i] + got, sz - got);
             if (r > 0) got += (size_t)r;
             else if (r < 0 && errno == EINTR) continue;
             else break;
         }
-        close(fds[i]);
+        close(fd);
         if (got != sz) { status[i] = MELF_JPEG_UNREADABLE; return; }
         jpeg_probe(base + off[i], sz, &hs[i], &ws[i], &oks[i], nullptr);
     });
@@ -1400,7 +1398,7 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): open + size %.2f ms, arena %.2f ms, read + probe %.2f ms\n", n, off[n] / 1e6,
+        fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): sizes %.2f ms, arena %.2f ms, open + read + probe %.2f ms\n", n, off[n] / 1e6,
                 ms(t0, t_opened), ms(t_opened, t_arena), ms(t_arena, std::chrono::steady_clock::now()));
     }
     // the batch shape: that of the first file the decoder takes
@@ -1426,6 +1424,14 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
     return MELF_SUCCESS;
 }
 
+extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
+                                       melf_result* out_host, int32_t* status)
+{
+    if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (c->files_in_flight) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files: a _begin is waiting for its _end on this context");
+    return jpeg_process_files_impl(c, paths, n, H_used, W_used, out_host, status);
+}
+
 // The same call split in two for a scripting host: _begin returns at once, the work (file reads, Huffman tables,
 // upload, kernels, records) runs on a thread of the library, _end waits for it and returns its code.  Between the two
 // the caller can turn the PREVIOUS chunk's records into its own objects -- with a helper thread of the host language
@@ -1441,7 +1447,7 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
     c->files_err.clear();
     try {
         c->files_thread = std::thread([=]() {
-            c->files_rc = melf_jpeg_process_files(c, paths, n, H_used, W_used, out_host, status);
+            c->files_rc = jpeg_process_files_impl(c, paths, n, H_used, W_used, out_host, status);
             if (c->files_rc) c->files_err = g_err;  // this thread's message, for the thread that calls _end
         });
     } catch (const std::exception& e) {

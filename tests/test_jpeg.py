@@ -331,6 +331,8 @@ def test_process_files_in_two_halves(tmp_path):
         pending = reader.ctx._files_pending
         with pytest.raises(_hip.HipError):
             reader.ctx.jpeg_process_files_begin(files[:3])  # one call in flight per context
+        with pytest.raises(_hip.HipError):
+            reader.ctx.jpeg_process_files(files[:3])  # nor the one-piece call meanwhile
         reader.ctx._files_pending = pending
         (got, status, hw) = reader.ctx.jpeg_process_files_end()
         assert hw == ref_hw and np.array_equal(status, ref_status)
@@ -378,3 +380,24 @@ def test_get_meter_values_overlapped_chunks_and_early_close(tmp_path, monkeypatc
     gen.close()
     assert [r.value for r in first] == [r.value for r in ref[:10]]
     assert [r.value for r in get_meter_values(pfile, files[:20])] == [r.value for r in ref[:20]]
+
+
+@pytest.mark.gpu
+def test_process_files_holds_no_descriptors():
+    """600 files in one call with the soft limit on open files at 128: the library reads them a few at a time (one per
+    pool thread), it does not open the whole chunk first."""
+    import resource
+
+    from meterelf_amd import MeterReader, _hip, _params
+    reader = MeterReader(_params.load(os.path.join(GOLDEN, 'sample-images2', 'params.yml')))
+    (soft, hard) = resource.getrlimit(resource.RLIMIT_NOFILE)
+    try:
+        files = (_files('sample-images2') * 3)[:600]
+        (ref, ref_status, _) = reader.ctx.jpeg_process_files(files)
+        assert (ref_status == _hip.JPEG_OK).all()
+        resource.setrlimit(resource.RLIMIT_NOFILE, (128, hard))
+        (got, status, _) = reader.ctx.jpeg_process_files(files)
+        assert (status == _hip.JPEG_OK).all() and got.tobytes() == ref.tobytes()
+    finally:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
+        reader.close()
