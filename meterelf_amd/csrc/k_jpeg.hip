@@ -669,7 +669,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     }
     __syncthreads();
     JSTAMP(2);
-    int rounds = 0, redone = 0;
+    int rounds = 0, redone = 0;  // reported by the diagnostic build only
+    (void)rounds;
+    (void)redone;
     for (;;) {
         // which segments see a new entry state?
         uint32_t np = 0, ns = 0;
