@@ -22,8 +22,12 @@ t0 = time.time()
 total = bad = 0
 stats = {}
 seed = 1000
+last_note = t0
 while time.time() - t0 < budget:
     for sd in dirs:
+        if time.time() - last_note > 60:  # a sign of life for long runs
+            last_note = time.time()
+            print('... %d frames, %d mismatches, %.0f s' % (total, bad, last_note - t0), flush=True)
         pfile = os.path.join(ROOT, 'tests', 'golden', sd, 'params.yml')
         files = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', sd, '*.jpg')))
         if seed % 4:   # mostly the readable frames; every fourth round the two rejected (other orientation) ones of sample-images1

@@ -22,7 +22,11 @@ ctx = reader.ctx
 rng = np.random.default_rng(20261003)
 t0 = time.time()
 (nfiles, bad, nbytes) = (0, 0, 0)
+last_note = t0
 while time.time() - t0 < budget:
+    if time.time() - last_note > 60:  # a sign of life for long runs
+        last_note = time.time()
+        print('... %d files, %d mismatches, %.0f s' % (nfiles, bad, last_note - t0), flush=True)
     (H, W) = (int(rng.integers(1, 300)), int(rng.integers(1, 400)))
     files = []
     for _ in range(int(rng.integers(1, 24))):
