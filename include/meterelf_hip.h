@@ -249,6 +249,29 @@ int melf_ctx_set_frames_resident(melf_ctx* ctx, int on);
  * returns per-kernel accumulated milliseconds and launch counts. */
 enum { MELF_K_LPLANE = 0, MELF_K_MATCH = 1, MELF_K_DIALS = 2, MELF_K_FUSED_MASK = 3, MELF_K_HLS = 4,
        MELF_K_JPEG_HUFF = 5, MELF_K_JPEG_IDCT = 6, MELF_K_JPEG_COLOR = 7, MELF_K_COUNT = 8 };
+/* Which kernel, in which layout, computed the template match (meterelf/_utils.py:91-97: ONE cv2.matchTemplate code
+ * path in the reference; here the batch size and the crop shape select among three kernels and, for the tuned one,
+ * among wave layouts) of the context's most recent call.  Tests assert it, so that a change of a dispatch threshold
+ * cannot silently move a parity test onto another kernel. */
+enum { MELF_MATCH_KERNEL_DOT4 = 0, MELF_MATCH_KERNEL_MFMA = 1, MELF_MATCH_KERNEL_GEN = 2 };
+typedef struct {
+    int32_t kernel;          /* MELF_MATCH_KERNEL_*                                                      */
+    int32_t n, rows, cols;   /* images of the launch, searched image size                                */
+    int32_t groups;          /* 32-frame groups                                                          */
+    int32_t waves;           /* waves of the launch (matrix-core kernels)                                */
+    int32_t rows_per_wave;   /* tuned kernel: map rows of a full-row wave (RB); general kernel: tile rows */
+    int32_t full_waves;      /* tuned kernel, per group: waves of RB full rows                           */
+    int32_t pair_waves;      /* tuned kernel, per group: waves of RB + 1 rows that share a middle row    */
+    int32_t capped;          /* tuned kernel: the register-capped instantiation was launched             */
+    int32_t tiles;           /* general / dot4 kernel: tiles (partials) per frame                        */
+    int32_t reserved[5];
+} melf_match_info;
+int melf_ctx_last_match(const melf_ctx* ctx, melf_match_info* out);
+/* The tuned kernel's wave layout for a template / searched-image shape and a batch of n images, without a GPU or a
+ * context (host logic; kernel = MELF_MATCH_KERNEL_MFMA when the shape belongs to the tuned kernel's class, else the
+ * kernel that takes it).  reserved[0] = padded template rows, reserved[1] = L-plane rows per frame group. */
+int melf_match_layout_query(int th, int tw, int rows, int cols, int n, melf_match_info* out);
+
 int melf_ctx_set_profiling(melf_ctx* ctx, int on);  /* 0 off, 1 every kernel, 2 only the match kernel (two event records per batch instead of eight) */
 int melf_ctx_timings(melf_ctx* ctx, double ms[MELF_K_COUNT], int64_t launches[MELF_K_COUNT]);
 const char* melf_kernel_name(int k);

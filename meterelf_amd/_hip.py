@@ -52,6 +52,14 @@ class MelfResult(C.Structure):
                 ('pos', C.c_double * MAX_DIALS), ('angle', C.c_double * MAX_DIALS), ('value', C.c_double)]
 
 
+class MelfMatchInfo(C.Structure):
+    _fields_ = [('kernel', C.c_int32), ('n', C.c_int32), ('rows', C.c_int32), ('cols', C.c_int32), ('groups', C.c_int32),
+                ('waves', C.c_int32), ('rows_per_wave', C.c_int32), ('full_waves', C.c_int32), ('pair_waves', C.c_int32),
+                ('capped', C.c_int32), ('tiles', C.c_int32), ('reserved', C.c_int32 * 5)]
+
+
+MATCH_KERNEL_NAMES = ('dot4', 'mfma', 'gen')
+
 RESULT_DTYPE = np.dtype([('status', '<i4'), ('match_x', '<i4'), ('match_y', '<i4'), ('failed_dial', '<i4'),
                          ('unreadable_mask', '<u4'), ('match_val', '<f4'),
                          ('pos', '<f8', (MAX_DIALS,)), ('angle', '<f8', (MAX_DIALS,)), ('value', '<f8')])
@@ -68,7 +76,7 @@ EXPORTS = [
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_sync', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
-    'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
+    'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
     'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end',
 ]
@@ -114,6 +122,8 @@ def lib():
     L.melf_inrange.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.melf_ctx_fused_table_ties.argtypes = [vp, C.POINTER(C.c_int)]
     L.melf_ctx_set_profiling.argtypes = [vp, C.c_int]
+    L.melf_ctx_last_match.argtypes = [vp, C.POINTER(MelfMatchInfo)]
+    L.melf_match_layout_query.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MelfMatchInfo)]
     L.melf_ctx_set_frames_resident.argtypes = [vp, C.c_int]
     L.melf_ctx_timings.argtypes = [vp, vp, vp]
     i32p = C.POINTER(C.c_int32)
@@ -205,6 +215,21 @@ def build_dial_masks(cparams):
     out = np.zeros((cparams.ndials, 2, cparams.th, cparams.tw), np.uint8)
     check(lib().melf_build_dial_masks(C.byref(cparams), _ptr(out)))
     return out
+
+
+def _match_info_dict(mi):
+    d = {k: getattr(mi, k) for (k, _t) in MelfMatchInfo._fields_ if k != 'reserved'}
+    d['kernel'] = MATCH_KERNEL_NAMES[mi.kernel]
+    d['layout'] = ('rb%d%s' % (mi.rows_per_wave, '+pairs' if mi.pair_waves else '')) if mi.kernel == 1 else None
+    d['th_pad'], d['rows_pad'] = mi.reserved[0], mi.reserved[1]
+    return d
+
+
+def match_layout_query(th, tw, rows, cols, n):
+    """The tuned matrix-core kernel's wave layout for this shape and batch size (host logic, no GPU needed)."""
+    mi = MelfMatchInfo()
+    check(lib().melf_match_layout_query(th, tw, rows, cols, n, C.byref(mi)))
+    return _match_info_dict(mi)
 
 
 class Context:
@@ -404,6 +429,13 @@ class Context:
         """Promise that the frames of every process_batch_dev call are complete in HBM when the call is made: a call's prep
         kernels then run under the previous call's dials kernel (melf_ctx_set_frames_resident)."""
         check(self._L.melf_ctx_set_frames_resident(self._h, int(bool(on))))
+
+    def last_match(self):
+        """Kernel and wave layout of the most recent template-match launch: dict with 'kernel' ('dot4' / 'mfma' / 'gen'),
+        'layout' (tuned kernel: 'rb<rows per wave>' + '+pairs' when pairs of waves share a map row), and the raw fields."""
+        mi = MelfMatchInfo()
+        check(self._L.melf_ctx_last_match(self._h, C.byref(mi)))
+        return _match_info_dict(mi)
 
     def set_profiling(self, on):
         check(self._L.melf_ctx_set_profiling(self._h, int(on)))  # False/0 off, True/1 every kernel, 2 only k_match

@@ -203,10 +203,9 @@ struct MfmaGeom {
     int rows_pad;        // rows per group in Lg
     int th_pad;          // template rows padded to a multiple of 6 (zero rows)
     int nframes;
-    int nparts;          // row blocks per frame = partials per frame
-    int na;              // balanced layout: blocks 0..na-1 own 4 full rows each, then pairs of 5-row blocks
-                         // that share their middle row (one 32-column block of it each); na < 0: uniform rows
-    int ur;              // uniform layout: rows per wave (5 or 2)
+    int nparts;          // row blocks per frame = partials per frame = na + 2 * (pairs)
+    int na;              // blocks 0..na-1 own RB full rows each; then pairs of (RB + 1)-row blocks that share their
+                         // middle row (one 32-column block of it each): 2 RB + 1 map rows per pair
     int k1;              // 128 * (sum T - 128 * th * tw)
     double tmean;
 };
@@ -410,14 +409,22 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 
 // Register budget of the kernel.  "amdgpu-num-vgpr" counts architectural VGPRs and the backend doubles it for the unified
 // register file of gfx90a+ (VGPRs + AGPRs): 204 -> 408 of the SIMD's 512, which leaves 104 -- one wave of k_dials -- per
-// SIMD for the other pipeline lane's kernels while a match wave is resident.
+// SIMD for the other pipeline lane's kernels while a match wave is resident.  Only the CAPPED instantiation carries the
+// limit (under it the 5-row waves spill ~400 bytes per lane to scratch, in the matrix pipe's shadow); the library launches
+// it when the context's other lane is in use, i.e. when there IS another kernel to sit beside the match waves
+// (profiles/r03/match_vgpr_cap_ab.txt), and the uncapped one otherwise.
 #ifndef MELF_MATCH_VGPRS
 #define MELF_MATCH_VGPRS 204
 #endif
-template <int ND, int NXB, int R, int PD>
-__global__ __launch_bounds__(64, 1) __attribute__((amdgpu_num_vgpr(MELF_MATCH_VGPRS))) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
-                                                      const uint32_t* __restrict__ ws, MfmaGeom g,
-                                                      float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+
+// The launch's layout (MfmaGeom::na, template RB): every wave carries 2 RB half-row units (RB full map rows x two
+// 32-column blocks) or, in a pair, 2 RB + 1 (RB + 1 rows of which the shared middle row counts half) -- so that
+// na + 2 pairs waves per frame group fill the chip's 1024 SIMDs in ONE round whatever the batch size: RB = 4 with pairs
+// at 1024 frames (8 or 9 units instead of 10), RB = 2 with pairs at 512 (4 or 5 instead of 8), RB = 3 at 640-900 ...
+template <int ND, int NXB, int RB, int PD>
+__device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
+                                            const uint32_t* __restrict__ ws, const MfmaGeom& g,
+                                            float* __restrict__ result_map, MatchPartial* __restrict__ partials)
 {
     // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so
     // ids with equal (id % 8) share an L2.  Give each XCD whole frame groups (they share Lg rows).
@@ -429,19 +436,13 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_num_vgpr(MELF_MATCH_VG
     const int per = nblk / 8, rem = nblk % 8, xcd = id & 7, sub = id >> 3;
     const int vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + sub;
     const int grp = vid / g.nparts, rblk = vid - grp * g.nparts;
-    if (NXB == 2 && g.na >= 0) {
-        // balanced layout: 8 or 9 half-row units per wave (see MfmaGeom::na)
-        if (rblk < g.na) {
-            match_wave<ND, 2, 4, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, 4 * rblk);
-        } else {
-            const int q = rblk - g.na, base = 4 * g.na + 9 * (q >> 1);
-            if ((q & 1) == 0) match_wave<ND, 2, 5, PD, 3, 1>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
-            else match_wave<ND, 2, 5, PD, 2, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + 4);
-        }
-    } else if (g.ur == 2) {  // small maps: more, lighter waves
-        match_wave<ND, NXB, 2, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * 2);
+    if (NXB == 2 && RB < 5 && rblk >= g.na) {
+        // a pair: two (RB + 1)-row waves, the first owns column block 0 of the shared middle row, the second block 1
+        const int q = rblk - g.na, base = RB * g.na + (2 * RB + 1) * (q >> 1);
+        if ((q & 1) == 0) match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 3, 1>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
+        else match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 2, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + RB);
     } else {
-        match_wave<ND, NXB, R, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * R);
+        match_wave<ND, NXB, RB, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * RB);
     }
 #ifdef MELF_MATCH_STAMP
     if (threadIdx.x == 0 && id < 8192) {
@@ -451,15 +452,36 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_num_vgpr(MELF_MATCH_VG
 #endif
 }
 
+template <int ND, int NXB, int RB, int PD>
+__global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
+                                                      const uint32_t* __restrict__ ws, MfmaGeom g,
+                                                      float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+{
+    match_block<ND, NXB, RB, PD>(Lg, Atab, ws, g, result_map, partials);
+}
+// the same kernel under the register cap (see above)
+template <int ND, int NXB, int RB, int PD>
+__global__ __launch_bounds__(64, 1) __attribute__((amdgpu_num_vgpr(MELF_MATCH_VGPRS))) void k_match_mfma_capped(
+    const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab, const uint32_t* __restrict__ ws, MfmaGeom g,
+    float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+{
+    match_block<ND, NXB, RB, PD>(Lg, Atab, ws, g, result_map, partials);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-constexpr int MM_ND = 7, MM_R = 5, MM_PD = 1;
-constexpr int MM_NBUF = MM_R + MM_PD;
-constexpr int MM_PERIOD = MM_NBUF;
-// th_pad: multiple of every wave type's rotation period (R = 5: 6; R = 4: 5; R = 2: 3)
-static int mm_th_pad(int th) { return (th + 29) / 30 * 30; }
-static_assert(MM_PD == 1 && MM_R == 5 && 30 % MM_PERIOD == 0, "th_pad rule assumes PD = 1, R in {2, 4, 5}");
+constexpr int MM_ND = 7, MM_PD = 1;
+// Template rows are padded with zero rows to a multiple of every wave type's rotation period (R + PD image-row
+// buffers): a launch with RB-row waves and pairs of (RB + 1)-row waves needs lcm(RB + 1, RB + 2), without pairs
+// RB + 1.  The fragment table carries the largest padding any layout can ask for (60 = lcm(3, 4, 5, 6)).
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static int mm_th_pad_max(int th) { return round_up(th, 60); }
+static int mm_th_pad(int th, int rb, bool pairs)
+{
+    static const int lcm2[6] = {0, 0, 12, 20, 30, 6};  // lcm(rb + 1, rb + 2); rb = 5 has no pairs
+    return round_up(th, pairs ? lcm2[rb] : rb + 1);
+}
 
 bool mfma_match_ok(int th, int tw, int rows, int cols)
 {
@@ -470,6 +492,15 @@ bool mfma_match_ok(int th, int tw, int rows, int cols)
            (long)th * tw * 65025L < (1L << 32);
 }
 
+// Cost model of one wave, in shader cycles (measured on MI355X): ~33 cycles per MFMA in the
+// loop, ~11 cycles of matrix-pipe idle per 1 KiB fragment load issued between the MFMA groups, the epilogue (window
+// sums, double-precision post-pass, arg-max) ~2 400 cycles per half-row unit, priming ~4 000.
+static double mm_wave_cycles(int R, int units, int nxb, int th_pad)
+{
+    const int nkb = MM_ND + nxb - 1;
+    return (double)th_pad * ((double)units * MM_ND * 33.0 + (double)(nkb + MM_ND) * 11.0) + units * 2400.0 + 4000.0 + R * 0.0;
+}
+
 MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
 {
     MfmaPlan p;
@@ -477,35 +508,35 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
     p.rw = cols - tw + 1;
     p.nxb = p.rw > 32 ? 2 : 1;
     p.nkb = MM_ND + p.nxb - 1;
-    p.th_pad = mm_th_pad(th);
-    p.nparts = (p.rh + MM_R - 1) / MM_R;
-    p.na = -1;
-    int rows_cov = p.nparts * MM_R;
     p.groups = (nframes + 31) / 32;
-    if (p.nxb == 2) {
-        // Balanced layout: na blocks of 4 full rows + np pairs of 5-row blocks sharing a row (9 rows per
-        // pair), 4 na + 9 np >= rh.  Take the fewest pairs for which all blocks of the batch run at once
-        // (one wave per SIMD, 1024 SIMDs); with none needed the uniform 4-row layout is already balanced.
-        const int simds = 1024;
-        int best_np = -1, best_na = 0;
-        for (int np = 0; 9 * np <= p.rh + 8; ++np) {
-            const int rest = p.rh - 9 * np;
-            const int na = rest > 0 ? (rest + 3) / 4 : 0;
-            if ((long)(na + 2 * np) * p.groups <= simds) { best_np = np; best_na = na; break; }
+    // Layout search: RB full rows per wave (2..5), np pairs of (RB + 1)-row waves sharing their middle row.  The
+    // launch's time is (rounds of waves over the 1024 SIMDs) x (its longest wave); among equals the fewest pairs.
+    const int simds = 1024;
+    int force_rb = 0, force_np = -1;
+    if (const char* e = getenv("MELF_MATCH_LAYOUT")) sscanf(e, "%d,%d", &force_rb, &force_np);  // experiments / tests: "rb,np"
+    double best = 0;
+    p.rb = 0;
+    for (int rb = 2; rb <= 5; ++rb) {
+        if (force_rb && rb != force_rb) continue;
+        const int np_max = (p.nxb == 2 && rb < 5) ? (p.rh + 2 * rb) / (2 * rb + 1) : 0;
+        for (int np = 0; np <= np_max; ++np) {
+            if (force_np >= 0 && np != std::min(force_np, np_max)) continue;
+            const int rest = p.rh - (2 * rb + 1) * np;
+            const int na = rest > 0 ? (rest + rb - 1) / rb : 0;
+            const long waves = (long)(na + 2 * np) * p.groups;
+            const long rounds = (waves + simds - 1) / simds;
+            const int th_pad = mm_th_pad(th, rb, np > 0);
+            const int upr = p.nxb;  // units per full row
+            const double longest = np > 0 ? mm_wave_cycles(rb + 1, upr * rb + 1, p.nxb, th_pad) : mm_wave_cycles(rb, upr * rb, p.nxb, th_pad);
+            const double cost = (double)rounds * longest;
+            if (!p.rb || cost < best * 0.995) {
+                best = cost;
+                p.rb = rb; p.na = na; p.np = np; p.th_pad = th_pad;
+            }
         }
-        if (best_np < 0) { best_np = 0; best_na = (p.rh + 3) / 4; }  // more blocks than SIMDs anyway
-        p.na = best_na;
-        p.nparts = best_na + 2 * best_np;
-        rows_cov = 4 * best_na + 9 * best_np;
     }
-    p.ur = MM_R;
-    if ((long)p.nparts * p.groups * 2 <= 1024) {
-        // few waves (small correlation map or small batch): 2 rows per wave doubles the waves in flight
-        p.na = -1;
-        p.ur = 2;
-        p.nparts = (p.rh + 1) / 2;
-        rows_cov = p.nparts * 2;
-    }
+    p.nparts = p.na + 2 * p.np;
+    const int rows_cov = p.rb * p.na + (2 * p.rb + 1) * p.np;
     p.rows_pad = rows_cov + p.th_pad + MM_PD + 1;   // last row touched: y0 + (th_pad - 1) + R + PD - 1 (prefetched, unused)
     p.lg_bytes = (size_t)p.groups * p.rows_pad * p.nkb * 1024;
     p.r_bytes = (size_t)p.groups * rows * 64 * 32 * sizeof(uint16_t);
@@ -515,13 +546,13 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
 
 size_t mfma_atab_bytes(int th)
 {
-    return (size_t)(mm_th_pad(th) + MM_PD) * MM_ND * 1024;
+    return (size_t)(mm_th_pad_max(th) + MM_PD) * MM_ND * 1024;
 }
 
 // Atab[i][d][lane][j] = T'[i][32 d + 16 (lane >> 5) + j - (lane & 31)], zero outside the template
 void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab)
 {
-    const int th_pad = mm_th_pad(th);
+    const int th_pad = mm_th_pad_max(th);
     for (int i = 0; i < th_pad + MM_PD; ++i)
         for (int d = 0; d < MM_ND; ++d)
             for (int l = 0; l < 64; ++l)
@@ -567,25 +598,37 @@ void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan&
     launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, p.rh, th, tw, d_lg, d_r, d_ws, stream);
 }
 
+template <int NXB, int RB>
+static void launch_mm(bool capped, dim3 grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const int8_t* d_lg,
+                      const int8_t* d_atab, const uint32_t* d_ws, const MfmaGeom& g, float* d_result_map, MatchPartial* d_partials)
+{
+    // ev_start / ev_stop (optional): time stamps taken by the dispatch itself (hipExtLaunchKernelGGL) -- no
+    // hipEventRecord barrier packets in the queue around the kernel
+    if (capped)
+        hipExtLaunchKernelGGL((k_match_mfma_capped<MM_ND, NXB, RB, MM_PD>), grid, dim3(64), 0, stream, ev_start, ev_stop, 0, d_lg, d_atab,
+                              d_ws, g, d_result_map, d_partials);
+    else
+        hipExtLaunchKernelGGL((k_match_mfma<MM_ND, NXB, RB, MM_PD>), grid, dim3(64), 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
+                              d_result_map, d_partials);
+}
+
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
-                       hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
+                       hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool capped)
 {
     MfmaGeom g;
     g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
     g.na = p.na;
-    g.ur = p.ur;
     g.k1 = (int)(128 * (tsum - 128L * th * tw));
     g.tmean = tmean;
-    dim3 grid(p.nparts * p.groups), block(64);
-    // ev_start / ev_stop (optional): time stamps taken by the dispatch itself (hipExtLaunchKernelGGL) -- no
-    // hipEventRecord barrier packets in the queue around the kernel
-    if (p.nxb == 2)
-        hipExtLaunchKernelGGL((k_match_mfma<MM_ND, 2, MM_R, MM_PD>), grid, block, 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
-                              d_result_map, d_partials);
-    else
-        hipExtLaunchKernelGGL((k_match_mfma<MM_ND, 1, MM_R, MM_PD>), grid, block, 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
-                              d_result_map, d_partials);
+    dim3 grid(p.nparts * p.groups);
+#define MM_CASE(NXB_, RB_) \
+    case NXB_ * 8 + RB_: launch_mm<NXB_, RB_>(capped, grid, stream, ev_start, ev_stop, d_lg, d_atab, d_ws, g, d_result_map, d_partials); break;
+    switch (p.nxb * 8 + p.rb) {
+        MM_CASE(1, 2) MM_CASE(1, 3) MM_CASE(1, 4) MM_CASE(1, 5)
+        MM_CASE(2, 2) MM_CASE(2, 3) MM_CASE(2, 4) MM_CASE(2, 5)
+    }
+#undef MM_CASE
 }
 
 }  // namespace melf

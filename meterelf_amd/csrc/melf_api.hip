@@ -207,6 +207,8 @@ extern "C" int melf_blob_params(const void* blob, size_t blob_bytes, melf_params
     return MELF_SUCCESS;
 }
 
+enum { MK_DOT4 = MELF_MATCH_KERNEL_DOT4, MK_FAST = MELF_MATCH_KERNEL_MFMA, MK_GEN = MELF_MATCH_KERNEL_GEN };
+
 // --------------------------------------------------------------- context ----
 struct TimedEvent {
     int kernel;
@@ -299,6 +301,7 @@ struct melf_ctx {
     uint64_t use_clock = 0;
     hipEvent_t ev_order = nullptr;
     std::vector<TimedEvent> events;
+    melf_match_info last_match = {};     // what run_match launched last (melf_ctx_last_match)
     double acc_ms[MELF_K_COUNT] = {0};
     int64_t acc_n[MELF_K_COUNT] = {0};
 };
@@ -629,6 +632,29 @@ extern "C" int melf_ctx_set_frames_resident(melf_ctx* c, int on)
     return MELF_SUCCESS;
 }
 
+extern "C" int melf_match_layout_query(int th, int tw, int rows, int cols, int n, melf_match_info* out)
+{
+    if (!out || n < 1) return fail(MELF_ERR_INVALID, "bad argument");
+    memset(out, 0, sizeof(*out));
+    out->n = n; out->rows = rows; out->cols = cols; out->groups = (n + 31) / 32;
+    if (rows < th || cols < tw || th < 1 || tw < 1) return fail(MELF_ERR_INVALID, "image smaller than the template");
+    if (!mfma_match_ok(th, tw, rows, cols)) { out->kernel = gen_match_ok(th, tw, rows, cols) ? MK_GEN : MK_DOT4; return MELF_SUCCESS; }
+    const MfmaPlan pl = mfma_plan(th, tw, rows, cols, n);
+    out->kernel = MK_FAST;
+    out->rows_per_wave = pl.rb; out->full_waves = pl.na; out->pair_waves = 2 * pl.np;
+    out->waves = pl.nparts * pl.groups;
+    out->tiles = pl.nparts;
+    out->reserved[0] = pl.th_pad; out->reserved[1] = pl.rows_pad;
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_last_match(const melf_ctx* c, melf_match_info* out)
+{
+    if (!c || !out) return fail(MELF_ERR_INVALID, "NULL argument");
+    *out = c->last_match;
+    return MELF_SUCCESS;
+}
+
 extern "C" int melf_ctx_set_profiling(melf_ctx* c, int on)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
@@ -667,7 +693,6 @@ extern "C" int melf_ctx_timings(melf_ctx* c, double ms[MELF_K_COUNT], int64_t la
 // maps too small to fill the chip (it slices the K loop across waves) and map widths a few columns past 32 (it
 // computes those columns in transposed form instead of a whole extra column block).  The VALU kernel (k_match)
 // remains for templates wider than 256 columns and as an independent formulation in the tests.
-enum { MK_DOT4 = 0, MK_FAST = 1, MK_GEN = 2 };
 static int pick_match_kind(const melf_ctx* c, int rows, int cols, int n)
 {
     if (!c->use_mfma) return MK_DOT4;
@@ -762,6 +787,10 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
 {
     const melf_params& P = c->P;
     const int kind = pick_match_kind(c, ms.rows, ms.cols, m);
+    melf_match_info& info = c->last_match;
+    memset(&info, 0, sizeof(info));
+    info.kernel = kind; info.n = m; info.rows = ms.rows; info.cols = ms.cols; info.groups = (m + 31) / 32;
+    static const bool trace = getenv("MELF_MATCH_TRACE") != nullptr;
     TimedEvent ev;
     ev.kernel = MELF_K_MATCH;
     ev.start = ev.stop = nullptr;
@@ -786,8 +815,15 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
             launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ps);
         }
         if (int rc = prep_done(c, bl, ps, ls)) return rc;
+        // under the register cap a wave of the other lane's kernels fits beside a match wave: worth it only when the
+        // context's other lane is in use (another caller stream has work in flight on it)
+        bool capped = false;
+        for (int l = 0; l < melf_ctx::NLANES; ++l) capped = capped || (l != bl && c->lane_owned[l]);
+        if (const char* e = getenv("MELF_MATCH_CAP")) capped = e[0] == '1';  // A/B runs
+        info.rows_per_wave = pl.rb; info.full_waves = pl.na; info.pair_waves = 2 * pl.np; info.capped = capped;
+        info.waves = pl.nparts * pl.groups;
         launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls,
-                          ev.start, ev.stop);
+                          ev.start, ev.stop, capped);
         if (int rc = match_launched(c, bl, ls)) return rc;
     } else if (kind == MK_GEN) {
         melf_ctx::GenEntry* ge = nullptr;
@@ -816,6 +852,7 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
         GenDev dev = ge->dev;
         dev.part = ge->part[bl];
         dev.counters = ge->counters[bl];
+        info.tiles = pl.ntiles; info.waves = pl.ntasks * pl.groups; info.rows_per_wave = pl.rc;
         launch_gen_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls, ev.start, ev.stop);
         if (int rc = match_launched(c, bl, ls)) return rc;
     } else {
@@ -825,7 +862,12 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
         c->match_done_valid[bl] = false;
         KernelTimer t(c, MELF_K_MATCH, ls);
         launch_match(ms, from_bgr, m, c->mg, c->d_tplT, d_map, *parts, nullptr, ls);
+        info.tiles = *nparts;
     }
+    if (trace)
+        fprintf(stderr, "[melf match] n=%d crop %dx%d: %s, %d groups, %d waves, rows per wave %d, full %d + pair %d per group%s\n", m, ms.rows,
+                ms.cols, kind == MK_FAST ? "k_match_mfma" : (kind == MK_GEN ? "k_match_gen" : "k_match (dot4)"), info.groups, info.waves,
+                info.rows_per_wave, info.full_waves, info.pair_waves, info.capped ? ", register cap" : "");
     if (ev.start) c->events.push_back(ev);
     return MELF_SUCCESS;
 }

@@ -46,7 +46,8 @@ int match_parts(const MatchGeom& g, int rows, int cols);
 
 // ---- K2 on the matrix cores (k_match_mfma.hip) --------------------------------
 struct MfmaPlan {
-    int rh, rw, nxb, nkb, th_pad, nparts, rows_pad, groups, na, ur;
+    int rh, rw, nxb, nkb, th_pad, nparts, rows_pad, groups;
+    int rb, na, np;   // layout: na waves of rb full map rows + np pairs of (rb + 1)-row waves sharing their middle row
     size_t lg_bytes, r_bytes, ws_bytes;
 };
 bool mfma_match_ok(int th, int tw, int rows, int cols);
@@ -57,7 +58,7 @@ void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan&
                       uint16_t* d_r, uint32_t* d_ws, hipStream_t stream);
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
-                       hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool capped = false);
 
 // ---- K2, general form (k_match_gen.hip): any template up to 256 columns, any map size ----
 struct GenTask {           // one wave's job

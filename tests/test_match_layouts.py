@@ -1,0 +1,290 @@
+"""The tuned matrix-core match kernel (k_match_mfma) in EVERY wave layout its planner can pick, at default dispatch.
+
+The reference has one code path for every batch size (cv2.matchTemplate + minMaxLoc, meterelf/_utils.py:91-97, called
+per image from meterelf/_image.py:57-66).  Here the batch size selects the kernel (pick_match_kind) and, for the tuned
+kernel, the wave layout (mfma_plan: RB = 2..5 full map rows per wave, with or without pairs of (RB + 1)-row waves that
+share a map row).  These tests launch each of them the way production does -- frames resident in HBM, one
+melf_process_batch_dev call, no MELF_MATCH override -- and ASSERT which kernel and layout ran (melf_ctx_last_match), so
+that a change of a dispatch threshold cannot silently move a test onto another kernel.
+
+CPU part (not gpu): the planner's invariants over every batch size 1..4300.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import hip_runtime
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+REJECTED = ('20180814021309-01-e01.jpg', '20180814021310-00-e02.jpg')
+
+# batch size -> layout the planner must pick for the sample-images1 shape (crop 250 x 250, template 119 x 188, map
+# 132 x 63) on 1024 SIMDs.  320: default dispatch's first tuned-kernel size class; 512 / 700: mid-size batches (an
+# 8-GPU shard of config 5); 1024: the BENCH headline launch and get_meter_values' default chunk; 1056: 33 groups;
+# 2048: two rounds of waves.
+EXPECTED_LAYOUT = {320: 'rb2', 512: 'rb2+pairs', 700: 'rb3', 800: 'rb3+pairs', 900: 'rb4', 1024: 'rb4+pairs',
+                   1056: 'rb4+pairs', 1100: 'rb5', 2048: 'rb4+pairs'}
+
+
+# ------------------------------------------------------------------ CPU: the planner ----
+def test_planner_invariants_every_batch_size():
+    """Host logic, no GPU: for every batch size the layout covers every map row exactly once (full blocks, then pairs
+    sharing their middle row), pads the template to a multiple of every wave type's rotation period, and fills the chip
+    in one round whenever any layout can."""
+    from meterelf_amd import _hip
+    (th, tw, rows, cols) = (119, 188, 250, 250)
+    rh = rows - th + 1
+    for n in range(1, 4301):
+        d = _hip.match_layout_query(th, tw, rows, cols, n)
+        assert d['kernel'] == 'mfma' and d['groups'] == (n + 31) // 32
+        (rb, na, npairs) = (d['rows_per_wave'], d['full_waves'], d['pair_waves'] // 2)
+        assert 2 <= rb <= 5 and (npairs == 0 or rb < 5)
+        covered = rb * na + (2 * rb + 1) * npairs
+        assert rh <= covered < rh + 2 * rb + 1, (n, rb, na, npairs)
+        assert d['waves'] == (na + 2 * npairs) * d['groups']
+        assert d['th_pad'] >= th and d['th_pad'] % (rb + 1) == 0 and (npairs == 0 or d['th_pad'] % (rb + 2) == 0)
+        assert d['rows_pad'] >= covered + d['th_pad'] + 1
+        if 16 <= d['groups'] <= 34:     # 16 x 64 ... 34 x 30 waves: a one-round layout exists
+            assert d['waves'] <= 1024, (n, d)
+            assert d['waves'] >= 880, (n, d)   # and it uses (nearly) every SIMD
+    for (n, want) in EXPECTED_LAYOUT.items():
+        assert _hip.match_layout_query(th, tw, rows, cols, n)['layout'] == want, n
+
+
+def test_planner_other_shapes():
+    from meterelf_amd import _hip
+    # one column block (map <= 32 columns): no pairs possible
+    d = _hip.match_layout_query(119, 188, 250, 210, 1024)
+    assert d['kernel'] == 'mfma' and d['pair_waves'] == 0
+    # outside the tuned kernel's shape class
+    assert _hip.match_layout_query(119, 188, 135, 400, 64)['kernel'] == 'gen'
+    assert _hip.match_layout_query(40, 64, 250, 250, 64)['kernel'] == 'gen'
+    assert _hip.match_layout_query(119, 300, 250, 400, 64)['kernel'] == 'dot4'
+
+
+# ------------------------------------------------------------------ GPU ----
+class _DevBuf:
+    def __init__(self, hip, nbytes):
+        self.hip = hip
+        self.p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(self.p), C.c_size_t(nbytes)) == 0, 'hipMalloc of %d bytes' % nbytes
+
+    def upload(self, arr):
+        assert self.hip.hipMemcpy(self.p, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes), 1) == 0
+
+    def free(self):
+        self.hip.hipFree(self.p)
+
+
+@pytest.fixture(scope='module')
+def lay():
+    """sample-images1 readers: default dispatch, the general matrix-core kernel forced, the VALU kernel forced; and
+    256 distinct synthesised frames + two special ones."""
+    from meterelf_amd import MeterReader, _hip, _params
+    from oracle import pyoracle as po
+    from tests.test_gpu_parity import _good, synth_frames
+    if _hip.device_count() < 1:
+        pytest.fail('GPU tests need an MI355X: no HIP device visible (no CPU fallback exists)')
+    pfile = os.path.join(GOLDEN, 'sample-images1', 'params.yml')
+    params = _params.load(pfile)
+    files = sorted(glob.glob(os.path.join(GOLDEN, 'sample-images1', '*.jpg')))
+    readers = {}
+    saved = os.environ.pop('MELF_MATCH', None)
+    try:
+        readers['default'] = MeterReader(params)
+        for kind in ('gen', 'dot4'):
+            os.environ['MELF_MATCH'] = kind     # read when the context is created
+            readers[kind] = MeterReader(params)
+    finally:
+        os.environ.pop('MELF_MATCH', None)
+        if saved is not None:
+            os.environ['MELF_MATCH'] = saved
+    base = synth_frames(_good(files), 256, 4242, shift=10, sigma=3.0)
+    special = np.empty((2,) + base.shape[1:], np.uint8)
+    special[0] = 97                                                                   # a constant frame: every map value ties
+    special[1] = np.random.default_rng(5).integers(0, 256, size=base.shape[1:], dtype=np.uint8)  # noise: below the threshold
+    out = dict(readers=readers, base=base, special=special, oparams=po.Params(pfile), params=params, files=files)
+    yield out
+    for r in readers.values():
+        r.close()
+
+
+def _batch(lay, n, seed):
+    """n frames: every base frame in a seeded order (repeats when n > 256), the constant frame and the noise frame at
+    seeded places -- so different 32-frame groups and different lanes of a group see different content."""
+    rng = np.random.default_rng(seed)
+    pick = np.concatenate([rng.permutation(256) for _ in range((n + 255) // 256)])[:n]
+    frames = lay['base'][pick]
+    where = rng.choice(n, 4, replace=False)
+    frames[where[0]] = lay['special'][0]
+    frames[where[1]] = lay['special'][1]
+    frames[where[2]] = lay['special'][0]
+    frames[where[3]] = lay['special'][1]
+    return frames, where
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', sorted(EXPECTED_LAYOUT), ids=lambda n: 'n%d_%s' % (n, EXPECTED_LAYOUT[n]))
+def test_tuned_kernel_layouts_full_path(lay, n):
+    """n HBM-resident frames in ONE melf_process_batch_dev call at default dispatch: the records are byte-identical to
+    those of the general matrix-core kernel and of the VALU kernel on the same device buffer, for ALL frames; the
+    oracle agrees on 64 sampled frames plus the constant and the below-threshold ones."""
+    from oracle import pyoracle as po
+    from tests.test_gpu_parity import _compare_records
+    hip = hip_runtime()
+    (frames, where) = _batch(lay, n, 1000 + n)
+    (H, W) = frames.shape[1:3]
+    buf = _DevBuf(hip, frames.nbytes)
+    try:
+        buf.upload(frames)
+        got = {}
+        for (kind, reader) in lay['readers'].items():
+            got[kind] = reader.ctx.process_batch_dev(buf.p.value, n, H, W)
+            info = reader.ctx.last_match()
+            assert info['n'] == n and info['groups'] == (n + 31) // 32
+            if kind == 'default':
+                assert (info['kernel'], info['layout']) == ('mfma', EXPECTED_LAYOUT[n]), info
+                assert not info['capped']            # one caller stream: nothing to leave registers for
+            else:
+                assert info['kernel'] == kind, info
+    finally:
+        buf.free()
+    assert got['default'].tobytes() == got['gen'].tobytes(), 'tuned vs general matrix-core kernel'
+    assert got['default'].tobytes() == got['dot4'].tobytes(), 'tuned vs VALU kernel'
+    rng = np.random.default_rng(n)
+    sample = np.unique(np.concatenate([rng.choice(n, 64, replace=False), where]))
+    _compare_records(got['default'][sample], po.process_frames(frames[sample], lay['oparams']), tag='n=%d' % n)
+    st = got['default']['status']
+    assert (st[where] == 1).all()                      # constant and noise frames: Dials not found
+    assert float(got['default']['match_val'][where[0]]) == 0.0
+    assert (int(got['default']['match_x'][where[0]]), int(got['default']['match_y'][where[0]])) == (0, 0)   # first of all ties
+    assert (st == 0).sum() > n * 0.8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [512, 1024], ids=lambda n: 'n%d_%s' % (n, EXPECTED_LAYOUT[n]))
+def test_tuned_kernel_whole_map(lay, n):
+    """melf_match_ccoeff(want_map=True) at default dispatch: the whole float32 correlation map of every image bit-equal
+    to the VALU kernel's, and to the oracle's on four of them."""
+    from oracle import pyoracle as po
+    (frames, where) = _batch(lay, n, 2000 + n)
+    p = lay['params']
+    ((x0, y0), (x1, y1)) = p.meter_rect.top_left, p.meter_rect.bottom_right
+    # the match stage's input is the L plane of the crop: take the green channel of the crops as "L" (any u8 image does)
+    imgs = np.ascontiguousarray(frames[:, y0:y1, x0:x1, 1])
+    ctx = lay['readers']['default'].ctx
+    (mv, mx, my, rmap) = ctx.match_ccoeff(imgs, want_map=True)
+    info = ctx.last_match()
+    assert (info['kernel'], info['layout']) == ('mfma', EXPECTED_LAYOUT[n]), info
+    (mvd, mxd, myd, rmapd) = lay['readers']['dot4'].ctx.match_ccoeff(imgs, want_map=True)
+    assert lay['readers']['dot4'].ctx.last_match()['kernel'] == 'dot4'
+    assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32))
+    assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mvd.tobytes(), mxd.tobytes(), myd.tobytes())
+    from meterelf_amd._engine import load_template
+    tpl = load_template(p)
+    for i in (0, int(where[0]), n // 2, n - 1):
+        (ev, ex, ey, emap) = po.match_ccoeff(imgs[i], tpl, want_map=True)
+        assert np.array_equal(rmap[i], emap), i
+        assert (float(mv[i]), int(mx[i]), int(my[i])) == (ev, ex, ey), i
+
+
+ALL_LAYOUTS = [(rb, pairs, cols) for rb in (2, 3, 4, 5) for (pairs, cols) in ((0, 250), (3, 250), (0, 215))
+               if not (pairs and rb == 5)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rb,pairs,cols', ALL_LAYOUTS, ids=lambda v: str(v))
+def test_every_instantiation_forced(lay, monkeypatch, rb, pairs, cols):
+    """Every instantiation of the tuned kernel (RB = 2..5, with pairs, one or two column blocks; plain and under the
+    register cap) forced at a small batch (MELF_MATCH=fast, MELF_MATCH_LAYOUT=rb,np): whole maps bit-equal to the VALU
+    kernel's.  The layouts are the planner's choices at other batch sizes; forcing them keeps the check cheap."""
+    from meterelf_amd import MeterReader
+    (frames, where) = _batch(lay, 70, 3000 + rb * 10 + pairs)
+    p = lay['params']
+    ((x0, y0), (x1, y1)) = p.meter_rect.top_left, p.meter_rect.bottom_right
+    imgs = np.ascontiguousarray(frames[:, y0:y1, x0:x0 + cols, 2])
+    (mvd, mxd, myd, rmapd) = lay['readers']['dot4'].ctx.match_ccoeff(imgs, want_map=True)
+    monkeypatch.setenv('MELF_MATCH', 'fast')
+    monkeypatch.setenv('MELF_MATCH_LAYOUT', '%d,%d' % (rb, pairs))
+    r = MeterReader(p)
+    try:
+        for cap in ('0', '1'):
+            monkeypatch.setenv('MELF_MATCH_CAP', cap)
+            (mv, mx, my, rmap) = r.ctx.match_ccoeff(imgs, want_map=True)
+            info = r.ctx.last_match()
+            assert info['kernel'] == 'mfma' and info['rows_per_wave'] == rb and info['capped'] == int(cap), info
+            assert (info['pair_waves'] > 0) == (pairs > 0 and cols == 250), info
+            assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32)), (rb, pairs, cols, cap)
+            assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mvd.tobytes(), mxd.tobytes(), myd.tobytes())
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_second_lane_selects_the_capped_kernel(lay):
+    """Two caller streams in flight on one context: the second lane's match launch (and the first lane's next one) use
+    the register-capped instantiation; records identical to single-stream ones."""
+    hip = hip_runtime()
+    (frames, _w) = _batch(lay, 2 * 1024, 77)
+    (H, W) = frames.shape[1:3]
+    ctx = lay['readers']['default'].ctx
+    from meterelf_amd import _hip
+    rsz = _hip.RESULT_DTYPE.itemsize
+    buf = _DevBuf(hip, frames.nbytes)
+    res = _DevBuf(hip, len(frames) * rsz)
+    streams = [C.c_void_p() for _ in range(2)]
+    for s in streams:
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+    try:
+        buf.upload(frames)
+        ctx.sync()
+        ref = [ctx.process_batch_dev(buf.p.value + b * 1024 * H * W * 3, 1024, H, W) for b in range(2)]
+        assert not ctx.last_match()['capped']
+        ctx.sync()
+        caps = []
+        for rep in range(2):
+            for b in range(2):
+                ctx.process_batch_dev(buf.p.value + b * 1024 * H * W * 3, 1024, H, W, d_results_ptr=res.p.value + b * 1024 * rsz,
+                                      want_host=False, stream=streams[b].value)
+                caps.append(ctx.last_match()['capped'])
+        assert hip.hipDeviceSynchronize() == 0
+        assert caps == [0, 1, 1, 1], caps
+        got = np.zeros(len(frames), _hip.RESULT_DTYPE)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), res.p, C.c_size_t(got.nbytes), 2) == 0
+        assert got[:1024].tobytes() == ref[0].tobytes() and got[1024:].tobytes() == ref[1].tobytes()
+    finally:
+        ctx.sync()
+        for s in streams:
+            hip.hipStreamDestroy(s)
+        buf.free()
+        res.free()
+
+
+@pytest.mark.gpu
+def test_jpeg_process_batch_default_chunk(lay):
+    """melf_jpeg_process_batch with 1024 sample-images1 files -- get_meter_values' default chunk: GPU decode + the tuned
+    kernel in the headline layout -- against the records of the same files decoded on the host."""
+    from meterelf_amd import _hip
+    from meterelf_amd._image import imread_bgr
+    files = [f for f in lay['files'] if os.path.basename(f) not in REJECTED]
+    blobs = [open(f, 'rb').read() for f in files]
+    shapes = [_hip.jpeg_probe(b)[:3] for b in blobs]
+    (H, W, _ok) = shapes[0]
+    keep = [i for (i, s) in enumerate(shapes) if s == (H, W, True)]
+    (files, blobs) = ([files[i] for i in keep], [blobs[i] for i in keep])
+    rng = np.random.default_rng(9)
+    pick = rng.integers(0, len(blobs), 1024)
+    pick[:len(blobs)] = np.arange(len(blobs))
+    ctx = lay['readers']['default'].ctx
+    (recs, status) = ctx.jpeg_process_batch([blobs[i] for i in pick], H, W)
+    info = ctx.last_match()
+    assert (status == 0).all()
+    assert (info['kernel'], info['layout'], info['n']) == ('mfma', 'rb4+pairs', 1024), info
+    host = np.stack([imread_bgr(f) for f in files])
+    href = lay['readers']['gen'].read_frames(host)       # 79 frames: the general kernel
+    assert lay['readers']['gen'].ctx.last_match()['kernel'] == 'gen'
+    assert recs.tobytes() == href[pick].tobytes()
+    assert (recs['status'] == 0).all()
