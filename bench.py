@@ -209,6 +209,34 @@ def timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=
     return elapsed, recs.numpy().view(_hip.RESULT_DTYPE)
 
 
+def step_event_times(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=None):
+    """The same `steps` steps once more with a hipEvent recorded on the stream after every step ("hipEvent
+    timing, median reported").  Kept OUT of the contract's timed region: an event record is a barrier packet in the queue
+    (a few microseconds between two steps).  Returns event-to-event milliseconds per step."""
+    from meterelf_amd import _hip
+    torch = env.torch
+    fs = frame_stride or H * W * 3
+    rsz = _hip.RESULT_DTYPE.itemsize
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    env.sync()
+    with torch.cuda.stream(env.stream_obj):
+        evs[0].record(env.stream_obj)
+        for i in range(steps):
+            b = i % nbuf
+            ctx.process_batch_dev(frames.data_ptr() + b * B * fs, B, H, W, frame_stride=fs,
+                                  d_results_ptr=d_results.data_ptr() + b * B * rsz, want_host=False, stream=env.stream)
+            evs[i + 1].record(env.stream_obj)
+    env.sync()
+    return [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def percentiles(ms):
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    return {'n': int(len(a)), 'median_ms': round(float(np.median(a)), 4), 'p10_ms': round(float(np.percentile(a, 10)), 4),
+            'p90_ms': round(float(np.percentile(a, 90)), 4), 'min_ms': round(float(a[0]), 4), 'max_ms': round(float(a[-1]), 4),
+            'mean_ms': round(float(a.mean()), 4)}
+
+
 def max_over_ranks(env, elapsed):
     """(max over ranks, list of every rank's seconds)"""
     if env.dist is None:
@@ -320,9 +348,17 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     (elapsed, recs) = run(steps, ns)
     kt = ctx.timings()
     (elapsed_max, per_rank) = max_over_ranks(env, elapsed)
+    # per-step distribution: the same K steps again, an event after each (this rank's; single stream)
+    ctx.set_profiling(0)
+    step_ms = step_event_times(env, ctx, frames, B, nbuf, H, W, d_results, max(steps, 20))
+    ctx.set_profiling(2)
+    ctx.timings()
     out = {'ctx': ctx, 'P': P, 'H': H, 'W': W, 'frames': frames, 'recs': recs, 'elapsed': elapsed_max,
            'per_rank_ms': [round(t / steps * 1e3, 4) for t in per_rank], 'kt': kt, 'kt_all': kt_all,
            'roofline': match_roofline(P, H, W, kt, B * steps, traffic.get(label + ':k_match'))}
+    out['step_events'] = dict(percentiles(step_ms), what='event-to-event time of each of %d further steps of the same loop (one '
+                              'hipEvent per step on the stream, rank 0; the timed region itself carries no per-step events)' % len(step_ms))
+    out['match_layout'] = ctx.last_match()
     out['kernel_ms'] = {k: round(ms / n, 4) for (k, (ms, n)) in kt_all.items() if n}
     if sustained_s > 0:
         est = max(elapsed / steps, 1e-5)
@@ -349,11 +385,36 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
                               'frames_per_s': round(env.world * B * k / el2_max, 1),
                               'records_identical_to_single_stream': bool(recs2.tobytes() == recs.tobytes())}
     if cpu_sample > 0:
-        out['cpu'] = cpu_block(pfile, frames, recs, min(cpu_sample, B))
+        # rank 0 runs the CPU sample (and the parity gate) outside every timed region; the other ranks wait at the barrier
+        if env.rank == 0:
+            out['cpu'] = cpu_block(pfile, frames, recs, min(cpu_sample, B), P)
+        env.barrier()
     return out
 
 
-def cpu_block(pfile, frames, recs, S):
+def fft_correlation_rate(P, crows, ccols, nimg=64):
+    """Informational: what ONE stage of the reference's CPU path costs the way OpenCV does it.  cv2.matchTemplate computes
+    TM_CCOEFF with a blocked float32 DFT, an order of magnitude fewer operations than the oracle's exact
+    direct correlation; scipy.signal.fftconvolve of the same 250x250 image with the flipped 119x188 template, float32,
+    one thread, is the closest stand-in available here (cv2 itself is absent).  Match stage only."""
+    try:
+        from scipy.signal import fftconvolve
+    except Exception:
+        return None
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(nimg, crows, ccols)).astype(np.float32)
+    tpl = rng.integers(0, 256, size=(P.th, P.tw)).astype(np.float32)[::-1, ::-1].copy()
+    fftconvolve(img[0], tpl, mode='valid')
+    t0 = time.perf_counter()
+    for i in range(nimg):
+        fftconvolve(img[i], tpl, mode='valid')
+    dt = time.perf_counter() - t0
+    return {'value': round(nimg / dt, 1), 'unit': 'images/s', 'cores': 1,
+            'what': 'scipy.signal.fftconvolve (float32, mode=valid) of %dx%d images with the %dx%d template: the match stage '
+                    'alone, FFT-based as in OpenCV; not bit-exact, not the whole path' % (ccols, crows, P.tw, P.th)}
+
+
+def cpu_block(pfile, frames, recs, S, P=None):
     """The CPU oracle (port of the reference's algorithm; the reference itself needs OpenCV 3.4.5, absent here) on
     the first S frames of batch 0: one thread (the reference is single-threaded) and all of this GPU's host cores.
     The same sample is the in-run parity gate."""
@@ -379,8 +440,17 @@ def cpu_block(pfile, frames, recs, S):
         tm0 = time.perf_counter()
         list(pool.map(lambda part: po.process_frames(part, op), parts))
         tm = time.perf_counter() - tm0
+    fft = None
+    if P is not None:
+        (H, W) = sample.shape[1:3]
+        fft = fft_correlation_rate(P, min(P.rect_y1, H) - min(P.rect_y0, H), min(P.rect_x1, W) - min(P.rect_x0, W))
     return {'value': round(S / tc, 2), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
             'all_cores': {'value': round(S / tm, 2), 'unit': 'frames/s', 'cores': ncores},
+            'note': 'the port computes TM_CCOEFF by exact direct integer correlation (positions x template MACs per frame) so that '
+                    'it can be the bit-exact checker; the reference gets the same map from OpenCV\'s blocked float32 DFT, roughly an '
+                    'order of magnitude fewer operations, so OpenCV on one core would be several times FASTER than this port. '
+                    'fft_match_stage_only is that stage alone done the FFT way (informational).',
+            'fft_match_stage_only': fft,
             'sample': 'first %d frames of batch 0 of the same workload through oracle/melf_oracle.c (exact direct '
                       'correlation, single thread, %.1f s; the reference itself needs OpenCV 3.4.5, absent here)' % (S, tc),
             'parity_mismatches_vs_gpu': mism}
@@ -627,7 +697,7 @@ def main():
     main_label = 'config3' if args.sample_dir == 'sample-images1' else 'config4'
     full = full_path_block(env, pfile, args.sample_dir, 2024, args.steps, args.warmup, args.batch, args.nbuf,
                            args.sustained if 'sustained' in blocks else 0.0, traffic,
-                           args.cpu_sample if (single and 'cpu' in blocks) else 0, main_label,
+                           (args.cpu_sample if single else min(args.cpu_sample, 256)) if 'cpu' in blocks else 0, main_label,
                            two_stream_s=1.0 if 'twostream' in blocks else 0.0)
     (ctx, P, H, W, B) = (full['ctx'], full['P'], full['H'], full['W'], args.batch)
     n_ok = int((full['recs'][:B]['status'] == 0).sum())
@@ -638,8 +708,12 @@ def main():
     fused = None
     if 'fused' in blocks:
         fused = fused_block(env, ctx, 256, 640, 480, 4, args.steps, args.warmup, traffic, 'config2')
-    hostfed = hostfed_block(env, ctx, full['frames'], B, H, W) if (single and 'hostfed' in blocks) else None
-    jpeg = jpeg_block(ctx, args.sample_dir, H, W) if (single and 'jpeg' in blocks) else None
+    # host-side blocks: rank 0 alone (they use the host's cores), the other ranks wait at the barrier
+    (hostfed, jpeg) = (None, None)
+    if rank == 0:
+        hostfed = hostfed_block(env, ctx, full['frames'], B, H, W) if 'hostfed' in blocks else None
+        jpeg = jpeg_block(ctx, args.sample_dir, H, W) if 'jpeg' in blocks else None
+    env.barrier()
 
     cfg5 = None
     if 'config5' in blocks and args.sample_dir == 'sample-images1':
@@ -653,7 +727,7 @@ def main():
         torch.cuda.empty_cache()
         p4 = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
         f4 = full_path_block(env, p4, 'sample-images2', 2025, args.steps, args.warmup, args.batch, args.nbuf, 0.0, traffic,
-                             min(args.cpu_sample, 256) if (single and 'cpu' in blocks) else 0, 'config4',
+                             min(args.cpu_sample, 256) if 'cpu' in blocks else 0, 'config4',
                              two_stream_s=1.0 if 'twostream' in blocks else 0.0, resident_hint=True)
         cfg4 = {'workload': 'Batch=%d per GPU (%d in total), sample-images2 params (crop 135x220, 561 match positions), '
                             'calibration blob broadcast from rank 0%s, %d distinct batches in rotation'
@@ -661,7 +735,8 @@ def main():
                 'frames_resident_hint': not args.no_resident_hint,
                 'frames_per_s': round(world * B * args.steps / f4['elapsed'], 1), 'ms_per_step': round(f4['elapsed'] / args.steps * 1e3, 4),
                 'per_rank_ms_per_step': f4['per_rank_ms'], 'frames_read_ok_batch0': int((f4['recs'][:B]['status'] == 0).sum()),
-                'kernel_ms': f4['kernel_ms'], 'roofline': f4['roofline'], 'two_streams': f4.get('two_streams'),
+                'kernel_ms': f4['kernel_ms'], 'step_events': f4.get('step_events'), 'match_layout': f4.get('match_layout'),
+                'roofline': f4['roofline'], 'two_streams': f4.get('two_streams'),
                 'cpu_baseline': f4.get('cpu')}
         f4['ctx'].close()
 
@@ -679,7 +754,7 @@ def main():
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'frames_read_ok_batch0': n_ok,
                        'untimed_preheat_steps': args.preheat},
             'per_rank_ms_per_step': full['per_rank_ms'], 'rccl_ranks': rccl_ranks, 'backend': env.backend,
-            'kernel_ms': full['kernel_ms'],
+            'kernel_ms': full['kernel_ms'], 'step_events': full.get('step_events'), 'match_layout': full.get('match_layout'),
             'roofline': roofline, 'sustained': full.get('sustained'), 'two_streams': full.get('two_streams'),
             'cpu_baseline': full.get('cpu'),
             'fused_mask': fused, 'config4': cfg4, 'config5': cfg5, 'host_fed': hostfed, 'jpeg_decode': jpeg,
