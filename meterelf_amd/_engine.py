@@ -16,20 +16,32 @@ from .exceptions import (
 
 
 def load_template(params: Params) -> np.ndarray:
-    """cv2.imread(dials_file, IMREAD_GRAYSCALE) (reference: meterelf/_image.py:72-81)."""
+    """cv2.imread(dials_file, IMREAD_GRAYSCALE) (reference: meterelf/_image.py:72-81).
+
+    A grey file is taken as it is.  For a colour file OpenCV 3.4 lets the file format's own library make the grey image:
+    libpng for PNG (png_set_rgb_to_gray with 0.299 / 0.587: 15-bit coefficients 9798 / 19235 / 3735, palettes expanded to
+    RGB first), libjpeg for JPEG (the decoder is asked for JCS_GRAYSCALE: the Y plane itself); every other format is
+    decoded to BGR and goes through cvtColor's 14-bit weights (R 4899, G 9617, B 1868).  Pillow's convert('L') is none of
+    these (other weights, truncation)."""
     from PIL import Image
     try:
         with Image.open(params.dials_file) as im:
-            if im.mode in ('L', '1', 'P') and im.mode != 'L':
-                im = im.convert('L')
+            fmt = (im.format or '').upper()
             if im.mode == 'L':
                 template = np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+            elif im.mode == '1':
+                template = np.ascontiguousarray(np.asarray(im.convert('L'), dtype=np.uint8))
+            elif fmt == 'JPEG' and im.mode in ('RGB', 'YCbCr'):
+                im.draft('L', im.size)      # libjpeg's grayscale output: the luma plane, no colour conversion
+                template = np.ascontiguousarray(np.asarray(im.convert('L'), dtype=np.uint8))
             else:
-                # cv2.IMREAD_GRAYSCALE of a colour file: cv2's fixed-point BGR2GRAY (R 4899, G 9617, B 1868 of 2^14,
-                # rounded) -- Pillow's convert('L') uses other weights and truncation
                 rgb = np.asarray(im.convert('RGB'), dtype=np.int64)
-                template = np.ascontiguousarray(
-                    ((rgb[:, :, 0] * 4899 + rgb[:, :, 1] * 9617 + rgb[:, :, 2] * 1868 + 8192) >> 14).astype(np.uint8))
+                (r, g, b) = (rgb[:, :, 0], rgb[:, :, 1], rgb[:, :, 2])
+                if fmt == 'PNG':
+                    grey = (r * 9798 + g * 19235 + b * 3735 + 16384) >> 15
+                else:
+                    grey = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14
+                template = np.ascontiguousarray(grey.astype(np.uint8))
     except Exception:
         raise IOError("Cannot read dials template: {}".format(params.dials_file))
     assert template.shape == params.dials_template_size

@@ -16,12 +16,19 @@ from .exceptions import ImageLoadingError
 def imread_bgr(filename: str) -> Optional[np.ndarray]:
     """cv2.imread(filename): H x W x 3 uint8 BGR, or None if unreadable.
 
-    Like cv2.imread (OpenCV 3.4): a truncated file yields the part libjpeg could decode (the rest grey) instead of an
-    error, and the EXIF orientation tag is applied."""
-    from PIL import Image, ImageFile, ImageOps
+    Like cv2.imread (OpenCV 3.4) the EXIF orientation tag is applied, and a JPEG file that ends early yields the part
+    that could be decoded with the rest grey: libjpeg's data source answers a premature end of file with a fake EOI
+    marker, after which every remaining block decodes as all-zero coefficients.  The same marker is appended here for
+    the same effect (Pillow's own LOAD_TRUNCATED_IMAGES switch is process-global and leaves the missing rows black)."""
+    import io
+
+    from PIL import Image, ImageOps
     try:
-        ImageFile.LOAD_TRUNCATED_IMAGES = True
-        with Image.open(filename) as im:
+        with open(filename, 'rb') as fp:
+            data = fp.read()
+        if data[:2] == b'\xff\xd8' and data[-2:] != b'\xff\xd9':
+            data += b'\xff\xd9'
+        with Image.open(io.BytesIO(data)) as im:
             im = ImageOps.exif_transpose(im)
             rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
     except Exception:

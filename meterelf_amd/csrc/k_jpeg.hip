@@ -58,6 +58,30 @@ struct JpegHeader {
 static inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
 // Returns 0 = parsed (check h.why for "unsupported"), -1 = not a JPEG / truncated headers.
+// The orientation tag (0x0112) of IFD0 of an EXIF block (TIFF header at `t`): 1..8, or 0 when absent / unreadable.
+static int exif_orientation(const uint8_t* t, int n)
+{
+    if (n < 8) return 0;
+    const bool le = t[0] == 'I' && t[1] == 'I';
+    if (!le && !(t[0] == 'M' && t[1] == 'M')) return 0;
+    auto u16 = [&](int o) { return le ? (t[o] | t[o + 1] << 8) : (t[o] << 8 | t[o + 1]); };
+    auto u32 = [&](int o) { return le ? ((uint32_t)t[o] | (uint32_t)t[o + 1] << 8 | (uint32_t)t[o + 2] << 16 | (uint32_t)t[o + 3] << 24)
+                                      : ((uint32_t)t[o] << 24 | (uint32_t)t[o + 1] << 16 | (uint32_t)t[o + 2] << 8 | (uint32_t)t[o + 3]); };
+    if (u16(2) != 42) return 0;
+    const uint32_t ifd = u32(4);
+    if (ifd > (uint32_t)n - 2) return 0;
+    const int cnt = u16((int)ifd);
+    for (int k = 0; k < cnt; ++k) {
+        const long e = (long)ifd + 2 + 12L * k;
+        if (e + 12 > n) return 0;
+        if (u16((int)e) == 0x0112) {
+            const int v = u16((int)e + 8);   // type SHORT, count 1: the value sits in the first two bytes of the value field
+            return (v >= 1 && v <= 8) ? v : 0;
+        }
+    }
+    return 0;
+}
+
 static int parse_headers(const uint8_t* d, size_t n, JpegHeader& h)
 {
     for (int i = 0; i < 2; ++i) { h.dc[i].set = false; h.ac[i].set = false; }
@@ -133,6 +157,11 @@ static int parse_headers(const uint8_t* d, size_t n, JpegHeader& h)
                 break;
             case 0xE0:
                 if (len >= 5 && !memcmp(s, "JFIF\0", 5)) h.saw_jfif = true;
+                break;
+            case 0xE1:  // APP1: cv2.imread (3.4) applies the EXIF orientation tag; the kernels do not rotate, so a file
+                        // that asks for it goes to the caller's host decoder (which does: meterelf_amd/_image.py)
+                if (len >= 14 && !memcmp(s, "Exif\0\0", 6) && exif_orientation(s + 6, len - 6) > 1)
+                    h.why = "EXIF orientation other than top-left (decoded and rotated on the host)";
                 break;
             case 0xEE:
                 if (len >= 12 && !memcmp(s, "Adobe", 5)) { h.saw_adobe = true; h.adobe_transform = s[11]; }

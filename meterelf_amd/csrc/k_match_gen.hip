@@ -355,7 +355,19 @@ bool gen_match_ok(int th, int tw, int rows, int cols)
 {
     const int rh = rows - th + 1, rw = cols - tw + 1;
     // u16 row-window sums (tw * 255 < 2^16) and the epilogue's modulo-2^32 sum (th * tw * 255^2 < 2^32)
-    return rh >= 1 && rw >= 1 && tw <= 256 && (long)th * tw * 65025L < (1L << 32) && rows < 32768 && cols < 32768;
+    if (!(rh >= 1 && rw >= 1 && tw <= 256 && (long)th * tw * 65025L < (1L << 32) && rows < 32768 && cols < 32768)) return false;
+    // What the launches can hold (shapes beyond go to the VALU kernel, which has no such limits):
+    //  * k_prep_lplane keeps the row prefix of 32 frames in LDS, 64 * (32 nkb + 8) bytes of the 128 KiB it may ask for;
+    //  * GenTask::tile / y0 are 16-bit and a group's partial tiles are addressed with 32-bit byte offsets: bound the
+    //    number of tiles by its worst case (2-row tiles of one column block, 16 slices of up to 32 KiB each).
+    const int nd = (tw + 62) / 32, nxb_full = rw / 32, rem = rw % 32;
+    const int vcols = (rem > 0 && rem <= GEN_VREM_MAX && nxb_full >= 1) ? rem : 0;
+    const int nxb_h = vcols ? nxb_full : nxb_full + (rem ? 1 : 0);
+    const int ndv = vcols ? (vcols - 1 + tw - 1) / 32 + 1 : 0;
+    const int nkb = std::max(std::max(nxb_h + nd - 1, vcols ? nxb_full + ndv : 0), (cols + 31) / 32);
+    if (64L * (32L * nkb + 8) > 128L * 1024) return false;
+    const long ntiles_max = (long)((rh + 1) / 2) * std::max(nxb_h, 1) + (long)vcols * ((rh + 31) / 32);
+    return ntiles_max <= 8000;   // 8000 tiles x 512 KiB of partial tiles < 4 GiB, and < 2^15 for the 16-bit fields
 }
 
 GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes)

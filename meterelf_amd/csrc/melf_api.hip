@@ -726,26 +726,36 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
         delete old;
         c->gen_cache.erase(c->gen_cache.begin());
     }
+    // the entry is built completely -- device tables included -- before the cache sees it: a failed allocation or upload
+    // must not leave a half-built plan behind for the next call with this shape to launch from
     auto* ge = new melf_ctx::GenEntry();
     ge->rows = rows; ge->cols = cols; ge->groups = groups;
     ge->plan = gen_plan(c->P.th, c->P.tw, rows, cols, n);
     const GenPlan& p = ge->plan;
-    c->gen_cache.push_back(ge);
     if (getenv("MELF_GEN_TRACE"))
         fprintf(stderr, "[melf gen] crop %dx%d n=%d: map %dx%d nd=%d tile rows %d, %d tiles (%d V columns), %d waves per group x %d groups, partials %zu KiB\n",
                 rows, cols, n, p.rh, p.rw, p.nd, p.rc, p.ntiles, p.vcols, p.ntasks, p.groups, p.part_bytes / 1024);
-    std::vector<int8_t> atab(p.atab_bytes);
-    gen_build_atab(c->h_templ.data(), c->P.th, c->P.tw, p, atab.data());
-    HIP_TRY(hipMalloc((void**)&ge->dev.atab, atab.size()));
-    HIP_TRY(hipMemcpy(ge->dev.atab, atab.data(), atab.size(), hipMemcpyHostToDevice));
-    if (p.atabv_bytes) {
-        std::vector<int8_t> atabv(p.atabv_bytes);
-        gen_build_atabv(c->h_templ.data(), c->P.th, c->P.tw, p, atabv.data());
-        HIP_TRY(hipMalloc((void**)&ge->dev.atabv, atabv.size()));
-        HIP_TRY(hipMemcpy(ge->dev.atabv, atabv.data(), atabv.size(), hipMemcpyHostToDevice));
+    auto upload = [&]() -> int {
+        std::vector<int8_t> atab(p.atab_bytes);
+        gen_build_atab(c->h_templ.data(), c->P.th, c->P.tw, p, atab.data());
+        HIP_TRY(hipMalloc((void**)&ge->dev.atab, atab.size()));
+        HIP_TRY(hipMemcpy(ge->dev.atab, atab.data(), atab.size(), hipMemcpyHostToDevice));
+        if (p.atabv_bytes) {
+            std::vector<int8_t> atabv(p.atabv_bytes);
+            gen_build_atabv(c->h_templ.data(), c->P.th, c->P.tw, p, atabv.data());
+            HIP_TRY(hipMalloc((void**)&ge->dev.atabv, atabv.size()));
+            HIP_TRY(hipMemcpy(ge->dev.atabv, atabv.data(), atabv.size(), hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMalloc((void**)&ge->dev.tasks, p.tasks.size() * sizeof(GenTask)));
+        HIP_TRY(hipMemcpy(ge->dev.tasks, p.tasks.data(), p.tasks.size() * sizeof(GenTask), hipMemcpyHostToDevice));
+        return MELF_SUCCESS;
+    };
+    if (int rc = upload()) {
+        hipFree(ge->dev.atab); hipFree(ge->dev.atabv); hipFree(ge->dev.tasks);
+        delete ge;
+        return rc;
     }
-    HIP_TRY(hipMalloc((void**)&ge->dev.tasks, p.tasks.size() * sizeof(GenTask)));
-    HIP_TRY(hipMemcpy(ge->dev.tasks, p.tasks.data(), p.tasks.size() * sizeof(GenTask), hipMemcpyHostToDevice));
+    c->gen_cache.push_back(ge);
     *out = ge;
     return MELF_SUCCESS;
 }
@@ -782,8 +792,25 @@ static int match_launched(melf_ctx* c, int bl, hipStream_t ls)
 
 // prep + match of m images on stream ls with lane bl's work buffers; *parts / *nparts: per-frame (max, first arg-max)
 // partials for the consumer (k_dials or the host fold of melf_match_ccoeff)
+static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int bl, hipStream_t ls, float* d_map,
+                          MatchPartial** parts, int* nparts, TimedEvent& ev);
 static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int bl, hipStream_t ls, float* d_map,
                      MatchPartial** parts, int* nparts)
+{
+    TimedEvent ev;
+    ev.kernel = MELF_K_MATCH;
+    ev.start = ev.stop = nullptr;
+    const int rc = run_match_impl(c, ms, from_bgr, m, bl, ls, d_map, parts, nparts, ev);
+    if (rc == MELF_SUCCESS && ev.start && ev.stop) {
+        c->events.push_back(ev);
+    } else {   // nothing was launched with them (an allocation failed on the way)
+        if (ev.start) hipEventDestroy(ev.start);
+        if (ev.stop) hipEventDestroy(ev.stop);
+    }
+    return rc;
+}
+static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int bl, hipStream_t ls, float* d_map,
+                          MatchPartial** parts, int* nparts, TimedEvent& ev)
 {
     const melf_params& P = c->P;
     const int kind = pick_match_kind(c, ms.rows, ms.cols, m);
@@ -791,9 +818,6 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
     memset(&info, 0, sizeof(info));
     info.kernel = kind; info.n = m; info.rows = ms.rows; info.cols = ms.cols; info.groups = (m + 31) / 32;
     static const bool trace = getenv("MELF_MATCH_TRACE") != nullptr;
-    TimedEvent ev;
-    ev.kernel = MELF_K_MATCH;
-    ev.start = ev.stop = nullptr;
     if (c->profiling && kind != MK_DOT4) {  // the dispatch's own time stamps: no event-record packets around the kernel
         // timing only: without the system-scope fence (cache write-back and invalidate) a default event brings along
         // -- that fence put 7 us in front of the kernel and 5 us behind it (rocprofv3 kernel trace, round 2)
@@ -868,7 +892,6 @@ static int run_match(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int 
         fprintf(stderr, "[melf match] n=%d crop %dx%d: %s, %d groups, %d waves, rows per wave %d, full %d + pair %d per group%s\n", m, ms.rows,
                 ms.cols, kind == MK_FAST ? "k_match_mfma" : (kind == MK_GEN ? "k_match_gen" : "k_match (dot4)"), info.groups, info.waves,
                 info.rows_per_wave, info.full_waves, info.pair_waves, info.capped ? ", register cap" : "");
-    if (ev.start) c->events.push_back(ev);
     return MELF_SUCCESS;
 }
 

@@ -276,3 +276,40 @@ def test_debug_mode_stdout_suffix(monkeypatch, capsys):
     assert abs(data['0.0001'] - 6.23) < 0.005 and abs(data['0.001'] - 3.3) < 0.05
     assert abs(data['0.01'] - 5.1) < 0.05 and abs(data['0.1'] - 2.4) < 0.05
     assert abs(data['value'] - 253.62306) < 0.000005
+
+
+def test_colour_template_grey_conversion_follows_the_file_format(tmp_path):
+    """cv2.imread(..., IMREAD_GRAYSCALE) of a COLOUR template: libpng's 15-bit weights for PNG (palettes expanded first),
+    cvtColor's 14-bit weights for formats decoded to BGR; grey files are taken as they are."""
+    import shutil
+    import yaml
+    from PIL import Image
+    src = os.path.join(GOLDEN, 'sample-images1')
+    with open(os.path.join(src, 'params.yml')) as fp:
+        data = yaml.safe_load(fp)
+    (tw, th) = data['dials_template_size']
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, size=(th, tw, 3), dtype=np.uint8)
+    (r, g, b) = (rgb[..., 0].astype(np.int64), rgb[..., 1].astype(np.int64), rgb[..., 2].astype(np.int64))
+
+    def load(name, save):
+        d = tmp_path / name
+        d.mkdir()
+        data2 = dict(data)
+        data2['dials_template'] = name + '.img'
+        save(str(d / data2['dials_template']))
+        with open(d / 'params.yml', 'w') as fp:
+            yaml.safe_dump(data2, fp)
+        return _engine.load_template(_params.load(str(d / 'params.yml')))
+
+    png = load('png', lambda f: Image.fromarray(rgb, 'RGB').save(f, 'PNG'))
+    assert np.array_equal(png, ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8))
+    bmp = load('bmp', lambda f: Image.fromarray(rgb, 'RGB').save(f, 'BMP'))
+    assert np.array_equal(bmp, ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8))
+    assert (png != bmp).any()      # the two formulas are not the same function
+    pal = Image.fromarray(rgb, 'RGB').quantize(64)
+    prgb = np.asarray(pal.convert('RGB'), dtype=np.int64)
+    ppng = load('pal', lambda f: pal.save(f, 'PNG'))
+    assert np.array_equal(ppng, ((prgb[..., 0] * 9798 + prgb[..., 1] * 19235 + prgb[..., 2] * 3735 + 16384) >> 15).astype(np.uint8))
+    grey = rng.integers(0, 256, size=(th, tw), dtype=np.uint8)
+    assert np.array_equal(load('grey', lambda f: Image.fromarray(grey, 'L').save(f, 'PNG')), grey)

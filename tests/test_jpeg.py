@@ -401,3 +401,79 @@ def test_process_files_holds_no_descriptors():
     finally:
         resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
         reader.close()
+
+
+# ---- EXIF orientation and truncated files (cv2.imread 3.4 applies the tag; libjpeg pads a short file with grey) ----
+def _with_orientation(jpeg_bytes, orientation):
+    from PIL import Image
+    im = Image.open(io.BytesIO(jpeg_bytes))
+    exif = Image.Exif()
+    exif[0x0112] = orientation
+    buf = io.BytesIO()
+    im.save(buf, 'JPEG', quality=92, exif=exif)
+    return buf.getvalue()
+
+
+def test_probe_sends_exif_oriented_files_to_the_host():
+    """The kernels do not rotate: a baseline JPEG whose EXIF orientation is not 1 must be reported unsupported (host
+    branch, which applies the tag), one with orientation 1 or no tag stays on the GPU."""
+    from meterelf_amd import _hip
+    data = open(_files('sample-images1')[3], 'rb').read()
+    for (o, want) in ((1, True), (3, False), (6, False), (8, False)):
+        (H, W, ok, why) = _hip.jpeg_probe(_with_orientation(data, o))
+        assert ok == want, (o, why)
+        assert (H, W) == _pillow_bgr(data).shape[:2]      # the stored size, whatever the tag says
+        if not want:
+            assert 'EXIF' in why
+    # big-endian TIFF header ("MM"): Pillow writes little-endian or big-endian depending on version; build one by hand
+    tiff = b'MM\x00\x2a\x00\x00\x00\x08' + b'\x00\x01' + b'\x01\x12\x00\x03\x00\x00\x00\x01\x00\x06\x00\x00' + b'\x00\x00\x00\x00'
+    app1 = b'\xff\xe1' + (len(tiff) + 8).to_bytes(2, 'big') + b'Exif\x00\x00' + tiff
+    (H, W, ok, why) = _hip.jpeg_probe(data[:2] + app1 + data[2:])
+    assert not ok and 'EXIF' in why
+
+
+def test_host_decoder_applies_orientation_and_pads_truncated_files(tmp_path):
+    from meterelf_amd._image import imread_bgr
+    f = _files('sample-images1')[3]
+    data = open(f, 'rb').read()
+    full = imread_bgr(f)
+    q = tmp_path / 'o6.jpg'
+    q.write_bytes(_with_orientation(data, 6))
+    rot = imread_bgr(str(q))
+    assert rot.shape == (full.shape[1], full.shape[0], 3)          # 90 degrees: H and W swap
+    t = tmp_path / 'cut.jpg'
+    t.write_bytes(data[:len(data) * 6 // 10])
+    cut = imread_bgr(str(t))
+    assert cut.shape == full.shape
+    assert np.array_equal(cut[:160], full[:160])                   # what was there decodes as before
+    assert (cut[-16:] == 128).all()                                # the rest: all-zero coefficient blocks = mid grey
+    import PIL.ImageFile
+    assert PIL.ImageFile.LOAD_TRUNCATED_IMAGES is False            # no process-global switch flipped
+
+
+@pytest.mark.gpu
+def test_exif_oriented_file_takes_the_host_branch(tmp_path):
+    """get_meter_values on an orientation-6 file gives what the host decoder's (rotated) frame gives, not the unrotated
+    GPU decode; its neighbours in the same chunk stay on the GPU."""
+    import meterelf_amd
+    from meterelf_amd import MeterReader, _params
+    from meterelf_amd._image import imread_bgr
+    files = _files('sample-images1')[2:6]
+    paths = []
+    for (i, f) in enumerate(files):
+        data = open(f, 'rb').read()
+        p = tmp_path / ('f%d.jpg' % i)
+        p.write_bytes(_with_orientation(data, 6) if i == 1 else data)
+        paths.append(str(p))
+    pfile = os.path.join(GOLDEN, 'sample-images1', 'params.yml')
+    got = list(meterelf_amd.get_meter_values(pfile, paths))
+    reader = MeterReader(_params.load(pfile))
+    try:
+        assert reader.read_jpeg_paths(paths)[1] is None and reader.read_jpeg_paths(paths)[0] is not None
+        for (i, p) in enumerate(paths):
+            ref = reader.read_many([imread_bgr(p)])[0]
+            (values, err) = meterelf_amd._engine.result_to_python(ref, reader.dial_names, p)
+            assert got[i].meter_values == values
+            assert (got[i].error is None) == (err is None)
+    finally:
+        reader.close()

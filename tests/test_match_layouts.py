@@ -288,3 +288,26 @@ def test_jpeg_process_batch_default_chunk(lay):
     assert lay['readers']['gen'].ctx.last_match()['kernel'] == 'gen'
     assert recs.tobytes() == href[pick].tobytes()
     assert (recs['status'] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,cols,want', [(130, 2200, 'dot4'), (200, 2000, 'gen'), (125, 4000, 'dot4')],
+                         ids=lambda v: str(v))
+def test_wide_crops_pick_a_kernel_that_can_launch(lay, rows, cols, want):
+    """Crops wider than the prep kernel's LDS row (about 2000 px, e.g. a wide meter_rect or 4K frames): the dispatch
+    must hand them to a kernel that can launch -- the VALU kernel beyond the limit -- not fail with an invalid launch.
+    Whole map against the oracle."""
+    from meterelf_amd._engine import load_template
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(rows + cols)
+    tpl = load_template(lay['params'])
+    imgs = rng.integers(0, 256, size=(3, rows, cols), dtype=np.uint8)
+    imgs[1, 4:4 + tpl.shape[0], cols - tpl.shape[1] - 7:cols - 7] = tpl      # an exact occurrence near the right edge
+    ctx = lay['readers']['default'].ctx
+    (mv, mx, my, rmap) = ctx.match_ccoeff(imgs, want_map=True)
+    assert ctx.last_match()['kernel'] == want
+    for i in range(3):
+        (ev, ex, ey, emap) = po.match_ccoeff(imgs[i], tpl, want_map=True)
+        assert np.array_equal(rmap[i], emap), i
+        assert (float(mv[i]), int(mx[i]), int(my[i])) == (ev, ex, ey), i
+    assert (int(mx[1]), int(my[1])) == (cols - tpl.shape[1] - 7, 4)
