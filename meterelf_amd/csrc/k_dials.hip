@@ -137,6 +137,29 @@ __device__ __forceinline__ uint32_t load_px3(const uint8_t* p, const uint8_t* bu
     return first ? (v & 0xffffffu) : (v >> 8);
 }
 
+// packed 16-bit arithmetic on two values per register (v_pk_*_u16)
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2v, a), __builtin_bit_cast(u16x2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2v, a), __builtin_bit_cast(u16x2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) + __builtin_bit_cast(u16x2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) - __builtin_bit_cast(u16x2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) * __builtin_bit_cast(u16x2v, b)));
+}
+
 #ifdef MELF_DIALS_STAMP
 // Diagnostic build only: shader-clock stamps at the phase boundaries of each wave (tools/dials_clock.py).
 __device__ uint64_t g_dials_stamps[8 * 8192];
@@ -301,27 +324,42 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         // typically the needle, a tenth of the window -- take the exact float path, 64 at a time: each row's
         // candidates are appended (position and pixel, by the lane that holds it) to a list in LDS as the row is
         // tested.  More candidates than the list holds: every pixel takes the exact path.
+        // The test runs on TWO window rows per instruction, as packed 16-bit halves (v_pk_*_u16): 255 * diff and
+        // den * (bound) stay below 2^16, so the compares  255 diff >= (los - 1) den  and  255 diff <= (his + 1) den  (the
+        // inequalities above halved) are exact in 16 bits; "x outside [lo, hi]" is  x != min(max(x, lo), hi).  Grey pixels
+        // (diff = 0) pass here when los <= 1 although only los = 0 admits them: a candidate more for the exact test.
         int total = 0;  // wave-uniform
+        const uint64_t colb = __ballot(colvalid);
+        const uint32_t LO2 = (uint32_t)max(2 * lol - 1, 0) * 0x00010001u, HI2 = (uint32_t)(2 * hil + 1) * 0x00010001u;
+        const uint32_t SLO = (uint32_t)max(los - 1, 0) * 0x00010001u, SHI = (uint32_t)(his + 1) * 0x00010001u;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int y = k, Y = wy0 + y;
-            const bool valid = y < ws && colvalid && Y >= 0 && Y < P.th;
-            const int b8 = pxv[k] & 255, g8 = (pxv[k] >> 8) & 255, r8 = (pxv[k] >> 16) & 255;
-            const int vmax = max(max(b8, g8), r8), vmin = min(min(b8, g8), r8);
-            const int sum = vmax + vmin, diff = vmax - vmin;
-            const int den = sum <= 255 ? sum : 510 - sum;
-            const bool l_ok = sum >= 2 * lol - 1 && sum <= 2 * hil + 1;
-            const bool s_ok = diff == 0 ? los == 0 : (510 * diff >= (2 * los - 2) * den && 510 * diff <= (2 * his + 2) * den);
-            const bool cand = valid && l_ok && s_ok;
-            const uint64_t cb = __ballot(cand), vb = __ballot(valid);
-            if (lane == y) V = vb;
-            const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
-            if (cand && slot < DIAL_LIST_CAP) {
-                list_pos[slot] = (uint16_t)(y << 6 | lane);
-                list_px[slot] = pxv[k];
+        for (int k2 = 0; k2 < NR; k2 += 2) {
+            const uint32_t p0 = pxv[k2], p1 = pxv[k2 + 1];
+            const uint32_t B2 = __builtin_amdgcn_perm(p1, p0, 0x0c040c00u), G2 = __builtin_amdgcn_perm(p1, p0, 0x0c050c01u),
+                           R2 = __builtin_amdgcn_perm(p1, p0, 0x0c060c02u);
+            const uint32_t vmax = pk_max_u16(pk_max_u16(B2, G2), R2), vmin = pk_min_u16(pk_min_u16(B2, G2), R2);
+            const uint32_t sum = pk_add_u16(vmax, vmin), diff = pk_sub_u16(vmax, vmin);
+            const uint32_t den = pk_min_u16(sum, pk_sub_u16(0x01fe01feu, sum));
+            const uint32_t lbad = pk_min_u16(pk_max_u16(sum, LO2), HI2) ^ sum;
+            const uint32_t a = pk_mul_u16(diff, 0x00ff00ffu);
+            const uint32_t sbad = pk_min_u16(pk_max_u16(a, pk_mul_u16(den, SLO)), pk_mul_u16(den, SHI)) ^ a;
+            const uint32_t bad = lbad | sbad;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k2 + h, y = k, Y = wy0 + y;
+                const bool rowok = y < ws && Y >= 0 && Y < P.th;                      // wave-uniform
+                const bool cand = (h ? bad < 0x10000u : (bad & 0xffffu) == 0u) && colvalid && rowok;
+                const uint64_t cb = __ballot(cand);
+                const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+                if (cand && slot < DIAL_LIST_CAP) {
+                    list_pos[slot] = (uint16_t)(y << 6 | lane);
+                    list_px[slot] = pxv[k];
+                }
+                total += __popcll(cb);
             }
-            total += __popcll(cb);
         }
+        // lane y's row of the window's valid-pixel mask (what the per-row ballots of `valid` used to deliver)
+        V = (lane < ws && wy0 + lane >= 0 && wy0 + lane < P.th && lane < NR) ? colb : 0ull;
         DSTAMP(6);
         if (total > DIAL_LIST_CAP) {
             exact_rows();

@@ -51,7 +51,11 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 
-template <bool FROM_BGR>
+// RFRAG: R in the tuned match kernel's EPILOGUE order instead ([row][k (4)][lane (64)][q (8)], rwp = 64): lane (n, hh) of a
+// match wave finds the row-window sums of its 32 accumulator elements j = 8 k + q = 16 xb + e, i.e. of map columns
+// x = 32 xb + (e & 3) + 8 (e >> 2) + 4 hh, in four lane-contiguous 16-byte pieces -- it adds them up over the template
+// rows itself (match_wave), so neither k_colsum nor the window-sum array exist on that path.
+template <bool FROM_BGR, bool RFRAG>
 __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw, int rwp,
                                                      int8_t* __restrict__ Lg, uint16_t* __restrict__ R)
 {
@@ -89,9 +93,15 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
                     for (int k = 0; k < 32; ++k) {
                         const int j = (3 * k) >> 2, sh = ((3 * k) & 3) * 8;
                         const uint32_t px = sh <= 8 ? (a[j] >> sh) : __builtin_amdgcn_alignbit(a[j + 1 < 24 ? j + 1 : 23], a[j], sh);
-                        const int L = hls_lightness(px & 255, (px >> 8) & 255, (px >> 16) & 255);
-                        const uint32_t v = k < npx ? (uint32_t)((L - 128) & 255) : 0u;
-                        w[k >> 2] |= v << ((k & 3) * 8);
+                        const int L = hls_lightness_fast(px & 255, (px >> 8) & 255, (px >> 16) & 255);
+                        w[k >> 2] |= (uint32_t)((L - 128) & 255) << ((k & 3) * 8);
+                    }
+                    if (npx < 32) {   // the row's last block: bytes beyond the image are padding (L' = 0)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int nb = min(max(npx - 4 * j, 0), 4);
+                            w[j] &= nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+                        }
                     }
                 } else {  // last bytes of the frame buffer: byte loads
                     for (int k = 0; k < npx; ++k) {
@@ -145,6 +155,20 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
         uint16_t* ro = R + (((size_t)grp * src.rows + y) * rwp) * 32;
         const int bias = tw * 128;
         const int pmax = nkb * 32 - 1;
+        if (RFRAG) {
+            const int k = t >> 6, ln = t & 63, nn = ln & 31, hh = ln >> 5;
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = 8 * k + q, xb = j >> 4, e = j & 15;
+                const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int hi = (int)pre_dyn[nn * pstride + min(x + tw - 1, pmax)], lo = x > 0 ? (int)pre_dyn[nn * pstride + min(x - 1, pmax)] : 0;
+                const uint32_t v = (uint32_t)(hi - lo + bias) & 0xffffu;
+                if (q & 1) o[q >> 1] |= v << 16; else o[q >> 1] = v;
+            }
+            u32x4m ov = {o[0], o[1], o[2], o[3]};
+            *(u32x4m*)(ro + (size_t)t * 8) = ov;
+        } else
         for (int e = t; e < rwp * 32; e += 256) {
             const int x = e >> 5, nn = e & 31;
             const int hi = (int)pre_dyn[nn * pstride + min(x + tw - 1, pmax)], lo = x > 0 ? (int)pre_dyn[nn * pstride + min(x - 1, pmax)] : 0;
@@ -207,6 +231,7 @@ struct MfmaGeom {
     int na;              // blocks 0..na-1 own RB full rows each; then pairs of (RB + 1)-row blocks that share their
                          // middle row (one 32-column block of it each): 2 RB + 1 map rows per pair
     int k1;              // 128 * (sum T - 128 * th * tw)
+    int rows, th;        // searched image rows, template rows (fused window sums)
     double tmean;
 };
 
@@ -234,7 +259,11 @@ __device__ inline bool better_m(float v, int i, float bv, int bi)
 // One wave's whole job.  MFIRST / MLAST: which 32-column blocks (bit xb) the first / last of the R
 // rows computes -- the balanced layout gives two neighbouring waves one column block each of a
 // shared row, so that every wave carries 8 or 9 half-row units instead of 10.
-template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST>
+// WSF ("window sums fused"): `ws` then points at the row-window sums R in epilogue order (k_prep_lplane<.., RFRAG>) and the
+// wave adds them up itself -- one 4 KiB row per template row, requested a step ahead like every other operand, the 64
+// additions spread over the step's MFMA sub-blocks (the vector ALU is idle there) -- into the window sums of its first
+// map row; the following rows slide (minus the row that leaves, plus the row that enters) in the epilogue.
+template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST, bool WSF>
 __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                            const uint32_t* __restrict__ ws, const MfmaGeom& g,
                                            float* __restrict__ result_map, MatchPartial* __restrict__ partials,
@@ -281,6 +310,18 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // before.  With the two-row epilogue batches this takes the kernel from 492 to ~390 of the SIMD's 512 registers:
     // a wave of the other pipeline lane's dials kernel (104) or prep kernel (64) fits beside it.
     i32x4 a[ND];
+    // fused window sums: wsa[16 xb + e] of map row y0 for this lane's (frame, half); rwv = the row in flight
+    uint32_t wsa[WSF ? 32 : 1];
+    i32x4 rwv[WSF ? 4 : 1];
+    const i32x4* const Rrows = (const i32x4*)ws + (size_t)grp * g.rows * 256 + lane;                             // row r at + 256 r
+    const i32x4* const Zrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + g.rows) * (size_t)NKB * 1024) + lane;  // an all-zero L' row
+    auto rw_row = [&](int i) -> const i32x4* {   // row-window sums of image row y0 + i; template rows >= th are padding
+        return i < g.th ? Rrows + (size_t)min(y0 + i, g.rows - 1) * 256 : Zrow;
+    };
+    if (WSF) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wsa[j] = 0;
+    }
     for (int phase = 0; phase < 2; ++phase) {
         const int ibeg = phase == 0 ? istart : 0, iend = phase == 0 ? g.th_pad : istart;
         if (ibeg >= iend) continue;
@@ -292,6 +333,11 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                 buf[r][kb] = Lrow[(size_t)(ibeg + r) * ROWV + kb * 64];
 #pragma unroll
         for (int d = 0; d < ND; ++d) a[d] = Ap[((size_t)ibeg * ND + d) * 64];
+        if (WSF) {
+            const i32x4* rp = rw_row(ibeg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rwv[k] = rp[k * 64];
+        }
         for (int i0 = ibeg; i0 < iend; i0 += PERIOD) {
 #pragma unroll
             for (int s = 0; s < PERIOD; ++s) {
@@ -310,13 +356,38 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #pragma unroll
                     for (int kb = (d == 0 ? NKB : d - 1); kb < (d == 0 ? NKB : d); ++kb)
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
+                    // row-window sums: piece d - 1 of the NEXT template row's R row goes into the registers whose previous
+                    // content (this row's piece) was added up in sub-block d - 1
+                    if (WSF && d >= 1 && d <= 4) rwv[d - 1] = rw_row(i + 1)[(d - 1) * 64];
                     __builtin_amdgcn_sched_barrier(0);
+                    if (WSF && d < 4) {   // piece d of this template row's R row, requested a step ago
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t v = (uint32_t)rwv[d][c];
+                            wsa[8 * d + 2 * c] += v & 0xffffu;
+                            wsa[8 * d + 2 * c + 1] += v >> 16;
+                            // an empty, zero-instruction asm keeps the optimiser from reasoning through the chain of several
+                            // hundred additions per accumulator (InstCombine took minutes per instantiation without it)
+                            asm("" : "+v"(wsa[8 * d + 2 * c]));
+                            asm("" : "+v"(wsa[8 * d + 2 * c + 1]));
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < R; ++r)
 #pragma unroll
                         for (int xb = 0; xb < NXB; ++xb)
                             if (on(r, xb))
                                 acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], buf[(s + r) % NBUF][d + xb], acc[r][xb], 0, 0, 0);
+                    if (WSF && d < 4) {
+                        // ... issued BETWEEN the sub-block's MFMAs (a vector instruction that issues while a matrix
+                        // instruction runs is free; a cluster of them in front of the sub-block holds the matrix pipe up)
+                        constexpr int NM = R * NXB - (NXB == 2 ? (MFIRST != 3) + (MLAST != 3) : 0);   // MFMAs of the sub-block
+#define MELF_SGB(MFMAS, VALUS) __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALUS, 0);
+                        if constexpr (NM >= 8) { MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) }
+                        else if constexpr (NM >= 4) { MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) }
+                        else { MELF_SGB(1, 4) MELF_SGB(1, 4) }
+#undef MELF_SGB
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     // fragment d of template row i + 1 (the table carries one extra all-zero row), into the registers the
                     // MFMAs above have just read: issued in the shadow of the running MFMAs
@@ -352,9 +423,36 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     float bestv = -INFINITY;
     int besti = INT_MAX;
     constexpr int RB = 1;
+    // fused window sums: the two R rows that leave / enter the window between map rows r - 1 and r are requested one row
+    // ahead (while row r - 1's arithmetic runs)
+    i32x4 slide[2][4];
+    auto slide_load = [&](int r) {
+        const i32x4* rout = Rrows + (size_t)min(y0 + r - 1, g.rows - 1) * 256;
+        const i32x4* rin = Rrows + (size_t)min(y0 + r - 1 + g.th, g.rows - 1) * 256;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { slide[0][k] = rout[k * 64]; slide[1][k] = rin[k * 64]; }
+    };
 #pragma unroll
     for (int r0 = 0; r0 < R; r0 += RB) {
         uint32_t wsr[RB][NXB][16];
+        if (WSF) {
+            // window sums of row y0 + r0: those of the row above minus the image row that left, plus the one that entered
+            if (r0 > 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t a0 = (uint32_t)slide[1][k][c], b0 = (uint32_t)slide[0][k][c];
+                        wsa[8 * k + 2 * c] += (a0 & 0xffffu) - (b0 & 0xffffu);
+                        wsa[8 * k + 2 * c + 1] += (a0 >> 16) - (b0 >> 16);
+                    }
+            }
+            if (r0 + 1 < R) slide_load(r0 + 1);
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) wsr[0][xb][e] = wsa[16 * xb + e];
+        } else {
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
             const int r = r0 + rr;
@@ -366,6 +464,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     if (on(r, xb)) wsr[rr][xb][e] = wrow[(32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh) * 32];
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -421,7 +520,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 // 32-column blocks) or, in a pair, 2 RB + 1 (RB + 1 rows of which the shared middle row counts half) -- so that
 // na + 2 pairs waves per frame group fill the chip's 1024 SIMDs in ONE round whatever the batch size: RB = 4 with pairs
 // at 1024 frames (8 or 9 units instead of 10), RB = 2 with pairs at 512 (4 or 5 instead of 8), RB = 3 at 640-900 ...
-template <int ND, int NXB, int RB, int PD>
+template <int ND, int NXB, int RB, int PD, bool WSF>
 __device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                             const uint32_t* __restrict__ ws, const MfmaGeom& g,
                                             float* __restrict__ result_map, MatchPartial* __restrict__ partials)
@@ -439,10 +538,10 @@ __device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const
     if (NXB == 2 && RB < 5 && rblk >= g.na) {
         // a pair: two (RB + 1)-row waves, the first owns column block 0 of the shared middle row, the second block 1
         const int q = rblk - g.na, base = RB * g.na + (2 * RB + 1) * (q >> 1);
-        if ((q & 1) == 0) match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 3, 1>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
-        else match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 2, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + RB);
+        if ((q & 1) == 0) match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 3, 1, WSF>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
+        else match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 2, 3, WSF>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + RB);
     } else {
-        match_wave<ND, NXB, RB, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * RB);
+        match_wave<ND, NXB, RB, PD, 3, 3, WSF>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * RB);
     }
 #ifdef MELF_MATCH_STAMP
     if (threadIdx.x == 0 && id < 8192) {
@@ -457,15 +556,16 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
                                                       const uint32_t* __restrict__ ws, MfmaGeom g,
                                                       float* __restrict__ result_map, MatchPartial* __restrict__ partials)
 {
-    match_block<ND, NXB, RB, PD>(Lg, Atab, ws, g, result_map, partials);
+    match_block<ND, NXB, RB, PD, true>(Lg, Atab, ws, g, result_map, partials);   // ws = row-window sums R in epilogue order
 }
-// the same kernel under the register cap (see above)
+// the same kernel under the register cap (see above); its window sums come ready-made from k_colsum (32 accumulators
+// and a row in flight more would not fit under the cap)
 template <int ND, int NXB, int RB, int PD>
 __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_num_vgpr(MELF_MATCH_VGPRS))) void k_match_mfma_capped(
     const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab, const uint32_t* __restrict__ ws, MfmaGeom g,
     float* __restrict__ result_map, MatchPartial* __restrict__ partials)
 {
-    match_block<ND, NXB, RB, PD>(Lg, Atab, ws, g, result_map, partials);
+    match_block<ND, NXB, RB, PD, false>(Lg, Atab, ws, g, result_map, partials);
 }
 
 // ---------------------------------------------------------------------------
@@ -565,7 +665,7 @@ void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab)
 }
 
 void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int rh, int th, int tw,
-                       int8_t* d_lg, uint16_t* d_r, uint32_t* d_ws, hipStream_t stream)
+                       int8_t* d_lg, uint16_t* d_r, uint32_t* d_ws, hipStream_t stream, bool rfrag)
 {
     dim3 grid(rows_pad, groups), block(256);
     const size_t pre_bytes = (size_t)32 * (nkb * 32 + 8) * sizeof(int16_t);
@@ -581,21 +681,28 @@ void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, in
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {  // once per device: dynamic LDS beyond the 64 KiB default
         (void)hipFuncSetAttribute((const void*)k_colsum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_prep_lplane<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_prep_lplane<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_set[dev] = true;
     }
-    if (from_bgr) hipLaunchKernelGGL(k_prep_lplane<true>, grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
-    else hipLaunchKernelGGL(k_prep_lplane<false>, grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+    if (rfrag) {   // the tuned match kernel adds the row-window sums up itself: no column-sum pass, no window-sum array
+        if (from_bgr) hipLaunchKernelGGL((k_prep_lplane<true, true>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+        else hipLaunchKernelGGL((k_prep_lplane<false, true>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+        return;
+    }
+    if (from_bgr) hipLaunchKernelGGL((k_prep_lplane<true, false>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+    else hipLaunchKernelGGL((k_prep_lplane<false, false>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
     static const int colsum_q = getenv("MELF_COLSUM_Q") ? std::min(8, std::max(1, atoi(getenv("MELF_COLSUM_Q")))) : 4;  // threads per column
     hipLaunchKernelGGL(k_colsum, dim3(rwp * 32 / 128, groups, nchunks), dim3(128 * colsum_q), col_bytes, stream, d_r, src.rows, th, rh,
                        rwp * 32, ychunk, d_ws);
 }
 
 void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
-                      uint16_t* d_r, uint32_t* d_ws, hipStream_t stream)
+                      uint16_t* d_r, uint32_t* d_ws, hipStream_t stream, bool rfrag)
 {
-    launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, p.rh, th, tw, d_lg, d_r, d_ws, stream);
+    launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, p.rh, th, tw, d_lg, d_r, d_ws, stream, rfrag);
 }
 
 template <int NXB, int RB>
@@ -620,13 +727,18 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
     g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
     g.na = p.na;
     g.k1 = (int)(128 * (tsum - 128L * th * tw));
+    g.rows = p.rh + th - 1; g.th = th;
     g.tmean = tmean;
     dim3 grid(p.nparts * p.groups);
 #define MM_CASE(NXB_, RB_) \
     case NXB_ * 8 + RB_: launch_mm<NXB_, RB_>(capped, grid, stream, ev_start, ev_stop, d_lg, d_atab, d_ws, g, d_result_map, d_partials); break;
     switch (p.nxb * 8 + p.rb) {
+#ifdef MELF_MATCH_ONLY_RB4   // experiments: one instantiation (fast compile)
+        MM_CASE(2, 4)
+#else
         MM_CASE(1, 2) MM_CASE(1, 3) MM_CASE(1, 4) MM_CASE(1, 5)
         MM_CASE(2, 2) MM_CASE(2, 3) MM_CASE(2, 4) MM_CASE(2, 5)
+#endif
     }
 #undef MM_CASE
 }
