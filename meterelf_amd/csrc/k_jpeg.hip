@@ -1145,26 +1145,51 @@ static hipError_t grow_dev(T** p, size_t* cap, size_t need)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Host half of a batch: parse every file, lay the batch out, fill the pinned stage buffer.
-// host_status[i]: 0 = handed to the GPU, 1 = valid but unsupported, 2 = unreadable, 3 = other size.
-int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
-                       int32_t* host_status, std::string* err)
+// Header parse of n files in one parallel pass (a chunked caller parses the whole call's files once and prepares chunk
+// by chunk): status[i] 0 = for the GPU, 1 = valid but unsupported, 2 = unreadable, 3 = other size.
+struct JpegParsed {
+    std::vector<JpegHeader> hdr;
+};
+JpegParsed* jpeg_parse_files(const uint8_t* const* data, const size_t* sizes, int n, int H, int W, int32_t* host_status)
 {
-    if (!*pws) *pws = new JpegWorkspace();
-    JpegWorkspace* w = *pws;
-    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
-    const auto tp0 = std::chrono::steady_clock::now();
-    std::vector<JpegHeader> hdr(n);
-    std::vector<size_t> scan_off(n + 1, 0);
-    const int nthreads = host_pool().size() + 1;
-    auto par_for = [&](const std::function<void(int)>& fn) { host_pool().run(n, fn); };
-    par_for([&](int i) {
-        JpegHeader& h = hdr[i];
+    JpegParsed* p = new JpegParsed();
+    p->hdr.resize(n);
+    host_pool().run(n, [&](int i) {
+        JpegHeader& h = p->hdr[i];
         if (!data[i] || parse_headers(data[i], sizes[i], h) != 0) { host_status[i] = 2; return; }
         if (h.why) { host_status[i] = 1; return; }
         if (h.H != H || h.W != W) { host_status[i] = 3; return; }
         host_status[i] = 0;
     });
+    return p;
+}
+void jpeg_parsed_free(JpegParsed* p) { delete p; }
+
+// Host half of a batch: parse every file (unless `parsed` holds the headers already: files first .. first + n - 1 of that
+// pass, host_status filled), lay the batch out, fill the pinned stage buffer.
+// host_status[i]: 0 = handed to the GPU, 1 = valid but unsupported, 2 = unreadable, 3 = other size.
+int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                       int32_t* host_status, std::string* err, const JpegParsed* parsed, int first)
+{
+    if (!*pws) *pws = new JpegWorkspace();
+    JpegWorkspace* w = *pws;
+    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    std::vector<JpegHeader> own;
+    std::vector<size_t> scan_off(n + 1, 0);
+    const int nthreads = host_pool().size() + 1;
+    auto par_for = [&](const std::function<void(int)>& fn) { host_pool().run(n, fn); };
+    if (!parsed) {
+        own.resize(n);
+        par_for([&](int i) {
+            JpegHeader& h = own[i];
+            if (!data[i] || parse_headers(data[i], sizes[i], h) != 0) { host_status[i] = 2; return; }
+            if (h.why) { host_status[i] = 1; return; }
+            if (h.H != H || h.W != W) { host_status[i] = 3; return; }
+            host_status[i] = 0;
+        });
+    }
+    const JpegHeader* hdr = parsed ? parsed->hdr.data() + first : own.data();
     const auto tp1 = std::chrono::steady_clock::now();
     // layout
     size_t coef_blocks = 0, plane_bytes = 0;
@@ -1271,9 +1296,29 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
     return MELF_SUCCESS;
 }
 
-// Device half: H2D of the stage buffer, then J1..J3.  `timer(k)` brackets kernel k (0..2) when profiling.
-int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
-                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg, const int* rect)
+// Device half, in two steps so that a caller can pipeline batches: jpeg_upload_batch grows the device buffers and copies
+// the stage buffer (on `copy_stream`), jpeg_decode_batch_kernels runs J1..J3 (on `stream`) and leaves the per-file status
+// in w->d_status.  `timer(k)` brackets kernel k (0..2) when profiling.
+#define JTRY(expr)                                                               \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);   \
+            return MELF_ERR_HIP;                                                 \
+        }                                                                        \
+    } while (0)
+int jpeg_upload_batch(JpegWorkspace* w, int n, hipStream_t copy_stream, std::string* err)
+{
+    JTRY(grow_dev(&w->d_stage, &w->d_cap, w->total));
+    JTRY(grow_dev(&w->d_coefs, &w->coef_cap, w->coef_elems + 64));
+    JTRY(grow_dev(&w->d_planes, &w->plane_cap, w->plane_bytes + 64));
+    JTRY(grow_dev(&w->d_status, &w->status_cap, (size_t)n));
+    JTRY(hipMemcpyAsync(w->d_stage, w->h_stage, w->total, hipMemcpyHostToDevice, copy_stream));
+    return MELF_SUCCESS;
+}
+
+int jpeg_decode_batch_kernels(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, hipStream_t stream, std::string* err,
+                              void (*timer)(void*, int, int), void* timer_arg, const int* rect)
 {
     // window: the caller's rectangle grown by one MCU (chroma filter context) and aligned to 16, or the frame
     JpegWindow win = {0, 0, W, H};
@@ -1283,19 +1328,6 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
         if (win.x1 <= win.x0 || win.y1 <= win.y0) win = {0, 0, W, H};
     }
     const int win_w = win.x1 - win.x0, win_h = win.y1 - win.y0;
-#define JTRY(expr)                                                               \
-    do {                                                                         \
-        hipError_t e_ = (expr);                                                  \
-        if (e_ != hipSuccess) {                                                  \
-            if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);   \
-            return MELF_ERR_HIP;                                                 \
-        }                                                                        \
-    } while (0)
-    JTRY(grow_dev(&w->d_stage, &w->d_cap, w->total));
-    JTRY(grow_dev(&w->d_coefs, &w->coef_cap, w->coef_elems + 64));
-    JTRY(grow_dev(&w->d_planes, &w->plane_cap, w->plane_bytes + 64));
-    JTRY(grow_dev(&w->d_status, &w->status_cap, (size_t)n));
-    JTRY(hipMemcpyAsync(w->d_stage, w->h_stage, w->total, hipMemcpyHostToDevice, stream));
     JTRY(hipMemsetAsync(w->d_status, 0, (size_t)n * sizeof(int32_t), stream));
     const JpegImageDev* imgs = (const JpegImageDev*)(w->d_stage + w->off_imgs);
     const uint16_t* qt = (const uint16_t*)(w->d_stage + w->off_qt);
@@ -1337,12 +1369,23 @@ int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, 
         hipLaunchKernelGGL(k_jpeg_color, dim3((win_w + 1023) / 1024, win_h, n), dim3(256), 0, stream, imgs, w->d_status, w->d_planes, H, W, d_frames, fast420, win);
     if (timer) timer(timer_arg, 2, 1);
     JTRY(hipGetLastError());
+    return MELF_SUCCESS;
+}
+
+const int32_t* jpeg_device_status(const JpegWorkspace* w) { return w->d_status; }
+
+// One batch start to end on one stream (upload, J1..J3, status back, synchronised when status_out_host is given).
+int jpeg_launch_batch(JpegWorkspace* w, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
+                      hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg, const int* rect)
+{
+    if (int rc = jpeg_upload_batch(w, n, stream, err)) return rc;
+    if (int rc = jpeg_decode_batch_kernels(w, n, H, W, d_frames, stream, err, timer, timer_arg, rect)) return rc;
     if (status_out_host) {
         JTRY(hipMemcpyAsync(status_out_host, w->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         JTRY(hipStreamSynchronize(stream));
     }
     return MELF_SUCCESS;
-#undef JTRY
 }
+#undef JTRY
 
 }  // namespace melf

@@ -142,11 +142,18 @@ void launch_inrange3(const uint8_t* d_img, int npx, const int lo[3], const int h
 // ---- k_jpeg.hip: baseline JPEG decode ----
 struct JpegWorkspace;
 int jpeg_probe(const uint8_t* data, size_t size, int* H, int* W, int* supported, std::string* why);
+struct JpegParsed;
+JpegParsed* jpeg_parse_files(const uint8_t* const* data, const size_t* sizes, int n, int H, int W, int32_t* host_status);
+void jpeg_parsed_free(JpegParsed* p);
 int jpeg_prepare_batch(JpegWorkspace** ws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
-                       int32_t* host_status, std::string* err);
+                       int32_t* host_status, std::string* err, const JpegParsed* parsed = nullptr, int first = 0);
 int jpeg_launch_batch(JpegWorkspace* ws, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
                       hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg,
                       const int* rect /* x0, y0, x1, y1: only this part of each frame is needed; NULL = all */);
+int jpeg_upload_batch(JpegWorkspace* ws, int n, hipStream_t copy_stream, std::string* err);
+int jpeg_decode_batch_kernels(JpegWorkspace* ws, int n, int H, int W, uint8_t* d_frames, hipStream_t stream, std::string* err,
+                              void (*timer)(void*, int, int), void* timer_arg, const int* rect);
+const int32_t* jpeg_device_status(const JpegWorkspace* ws);
 void jpeg_workspace_free(JpegWorkspace* ws);
 
 }  // namespace melf

@@ -477,3 +477,33 @@ def test_exif_oriented_file_takes_the_host_branch(tmp_path):
             assert (got[i].error is None) == (err is None)
     finally:
         reader.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('chunk,read', [('512', 'whole'), ('96', 'whole'), ('200', 'chunk')])
+def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read):
+    """melf_jpeg_process_batch decodes in chunks on two alternating streams while the host prepares the next chunk: same
+    records and per-file status as the one-piece path (MELF_JPEG_SERIAL), with a corrupt file, a file of another size,
+    a progressive file and a greyscale file spread over different chunks, and when called twice in a row."""
+    rng = np.random.default_rng(77)
+    good = [open(f, 'rb').read() for f in _files('sample-images1')]
+    from meterelf_amd import _hip
+    (H, W, _ok, _why) = _hip.jpeg_probe(good[2])
+    good = [b for b in good if _hip.jpeg_probe(b)[:2] == (H, W)]
+    batch = [good[i] for i in rng.integers(0, len(good), 700)]
+    batch[5] = batch[5][:len(batch[5]) // 2]                                  # cut short: corrupt scan
+    batch[300] = _encode(_natural_image(rng, 48, 64))                         # another size
+    batch[301] = _encode(_natural_image(rng, H, W), progressive=True)         # unsupported
+    batch[650] = _encode(_natural_image(rng, H, W)[..., 0])                   # greyscale, right size
+    monkeypatch.setenv('MELF_JPEG_SERIAL', '1')
+    (ref, rstat) = ctx.jpeg_process_batch(batch, H, W)
+    monkeypatch.delenv('MELF_JPEG_SERIAL')
+    monkeypatch.setenv('MELF_JPEG_CHUNK', chunk)
+    monkeypatch.setenv('MELF_JPEG_READ', read)
+    for _ in range(2):
+        (got, gstat) = ctx.jpeg_process_batch(batch, H, W)
+        assert np.array_equal(gstat, rstat)
+        ok = rstat == 0
+        assert got[ok].tobytes() == ref[ok].tobytes()
+    assert rstat[5] == 2 and rstat[300] == 3 and rstat[301] == 1 and rstat[650] == 0
+    assert (rstat == 0).sum() == 697

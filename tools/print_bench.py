@@ -33,7 +33,7 @@ if h:
     print('  host_fed %.0f frames/s  %.2f ms/call  crop PCIe %.1f GB/s' % (h['frames_per_s'], h['ms_per_call'], h['pcie_GBps_crop_bytes']))
 j = d.get('jpeg_decode')
 if j:
-    print('  jpeg %.0f files/s  kernels %s' % (j['files_per_s'], j['kernel_ms']))
+    print('  jpeg %.0f files/s  %.2f ms/call  kernels per call %s' % (j['files_per_s'], j['ms_per_call'], j.get('kernel_ms_per_call') or j.get('kernel_ms')))
 c = d.get('cpu_baseline')
 if c:
     print('  cpu %.1f frames/s (1 core), %.0f (%d cores), parity mismatches %d' % (c['value'], c['all_cores']['value'], c['all_cores']['cores'], c['parity_mismatches_vs_gpu']))
