@@ -3,7 +3,7 @@
 Public surface = the reference's (meterelf/__init__.py:1-6) plus the batched
 engine: `MeterReader` (one GPU) and `meterelf_amd._dist` (one process per GPU).
 """
-from ._api import MeterImageData, get_meter_values
+from ._api import MeterImageData, get_meter_values, release_cached_contexts
 from ._engine import MeterReader
 
-__all__ = ['MeterImageData', 'get_meter_values', 'MeterReader']
+__all__ = ['MeterImageData', 'get_meter_values', 'MeterReader', 'release_cached_contexts']

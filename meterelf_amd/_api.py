@@ -13,12 +13,14 @@ library) and decoded on the GPU (METERELF_DECODE=gpu, the default; bit-identical
 everything when METERELF_DECODE=host, is decoded on the host by Pillow on a small thread pool
 (METERELF_DECODE_THREADS, default min(8, cpu count); Pillow releases the GIL).
 """
+import hashlib
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional
 
 from . import _debug, _params
-from ._engine import MeterReader, records_to_python, result_to_python
+from ._engine import MeterReader, make_blob, records_to_python, result_to_python
 from ._image import ImageFile
 from .exceptions import ImageProcessingError
 
@@ -30,6 +32,53 @@ class MeterImageData(NamedTuple):
     meter_values: Dict[str, float]
 
 
+# ---- GPU contexts kept between calls ------------------------------------------------------------------------------
+# Creating a context (device tables, streams) and growing its workspaces on the first chunk cost ~30 ms per call -- more
+# than the 1024 files of a chunk take to read.  The reference keeps its per-Params state in module-level caches too
+# (meterelf/_image.py:69-81, meterelf/_dial_data.py:11-19, keyed by id(params)); here the key is the calibration itself
+# (digest of the blob = params + template + masks, plus the dial names), so a params.yml edited between two calls gets a
+# new context.  An idle context keeps its device workspaces (about 1 GB after 1024-file chunks of 640 x 480 frames);
+# METERELF_CTX_CACHE=0 turns the cache off, release_cached_contexts() empties it.
+_idle_readers: Dict[bytes, MeterReader] = {}
+_idle_lock = threading.Lock()
+_IDLE_MAX = 2
+
+
+def _acquire_reader(params) -> MeterReader:
+    blob = make_blob(params)
+    key = hashlib.sha1(blob.tobytes() + repr(list(params.dial_names)).encode()).digest()
+    with _idle_lock:
+        reader = _idle_readers.pop(key, None)
+    if reader is None:
+        reader = MeterReader(params, blob=blob)
+    reader._cache_key = key
+    return reader
+
+
+def _release_reader(reader: MeterReader) -> None:
+    key = getattr(reader, '_cache_key', None)
+    if key is not None and os.getenv('METERELF_CTX_CACHE', '1') != '0' and type(reader) is MeterReader:
+        with _idle_lock:
+            if key not in _idle_readers and len(_idle_readers) < _IDLE_MAX:
+                _idle_readers[key] = reader
+                return
+    reader.close()
+
+
+def release_cached_contexts() -> None:
+    """Closes the GPU contexts get_meter_values keeps between calls (and frees their device memory)."""
+    with _idle_lock:
+        readers = list(_idle_readers.values())
+        _idle_readers.clear()
+    for r in readers:
+        r.close()
+
+
+import atexit  # noqa: E402
+
+atexit.register(release_cached_contexts)   # before the interpreter tears the library binding down
+
+
 def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
     chunk: List[str] = []
     for item in items:
@@ -39,6 +88,9 @@ def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
             chunk = []
     if chunk:
         yield chunk
+
+
+_REAL_READER = MeterReader   # tests substitute MeterReader with a CPU stand-in: such readers are never cached
 
 
 def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[MeterImageData]:
@@ -61,6 +113,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
     # (melf_jpeg_process_files_begin / _end) while this thread turns chunk k's records into Python objects and the
     # consumer handles them.
     begun = False  # a _begin without its _end
+    clean = False  # the generator ran to its end (or was closed between chunks with nothing in flight)
 
     def _gpu_read(chunk: List[str]):
         if hasattr(reader, 'read_jpeg_paths_batch'):
@@ -74,7 +127,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         chunk = next(chunks, None)
         while chunk is not None:
             if reader is None:
-                reader = MeterReader(params)
+                reader = _acquire_reader(params) if MeterReader is _REAL_READER else MeterReader(params)
             assert len(reader.dial_names) == 4  # meterelf/_reading.py:166
             errors: Dict[int, ImageProcessingError] = {}
             by_index: Dict[int, object] = {}
@@ -125,13 +178,20 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                     raise error
                 yield MeterImageData(filename, meter_values.get('value'), error, meter_values)
             chunk = following
+        clean = True
+    except GeneratorExit:
+        clean = True   # dropped by the consumer half way: whatever is in flight is collected below
+        raise
     finally:
         if begun and reader is not None:
             try:
                 reader.read_jpeg_paths_end()  # the context must be idle before it is closed
             except Exception:
-                pass
+                clean = False
         if pool is not None:
             pool.shutdown(wait=False)
         if reader is not None:
-            reader.close()
+            if clean and MeterReader is _REAL_READER:
+                _release_reader(reader)   # idle and in a known state: the next call with this calibration takes it over
+            else:
+                reader.close()

@@ -484,30 +484,41 @@ static int setup_device_tables(melf_ctx* c)
     HIP_TRY(hipMalloc((void**)&c->d_rowmasks, rowmasks.size() * 8));
     HIP_TRY(hipMemcpy(c->d_rowmasks, rowmasks.data(), rowmasks.size() * 8, hipMemcpyHostToDevice));
 
-    // --- K1b lookup tables for the context's fixed needle bounds ---
-    HIP_TRY(hipMalloc((void**)&c->d_fused_tables, (size_t)FUSED_TABLE_DWORDS * 4));
-    launch_build_fused_tables(P.hue_shift, P.needle_lo, P.needle_hi, c->d_fused_tables, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    uint32_t namb = 0;
-    HIP_TRY(hipMemcpy(&namb, c->d_fused_tables + fused_tables_count_offset(), 4, hipMemcpyDeviceToHost));
+    return MELF_SUCCESS;
+}
+
+// K1b lookup tables for the context's fixed needle bounds: built on the GPU from the exact float path for all 2^24
+// BGR triples -- 1.3 ms of kernel plus three synchronising read-backs, which only the fused full-frame stage
+// (melf_hls_inrange_close*) needs: built on its first use, not at context creation (the reading path never looks at them).
+static int ensure_fused_tables(melf_ctx* c)
+{
+    if (c->d_fused_tables) return MELF_SUCCESS;
+    const melf_params& P = c->P;
+    uint32_t* tables = nullptr;
+    HIP_TRY(hipMalloc((void**)&tables, (size_t)FUSED_TABLE_DWORDS * 4));
+    launch_build_fused_tables(P.hue_shift, P.needle_lo, P.needle_hi, tables, c->stream);
+    uint32_t namb = 0, active = 0, noniv[3] = {1, 1, 1};
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(&namb, tables + fused_tables_count_offset(), 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&active, tables + fused_tables_active_offset(), 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(noniv, tables + fused_tables_noniv_offset(), 12, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        (void)hipFree(tables);
+        return fail(MELF_ERR_HIP, std::string("building the fused-mask tables: ") + hipGetErrorString(e));
+    }
     c->fused_ambiguous = (int)namb;
-    uint32_t active = 0;
-    HIP_TRY(hipMemcpy(&active, c->d_fused_tables + fused_tables_active_offset(), 4, hipMemcpyDeviceToHost));
     c->fused_active_sectors = (int)active;
     // kernel variant: ties -> 4; exactly one hue sector can be in range -> 0/1/2; otherwise 3
     c->fused_variant = namb > 0 ? 4 : (active == 1 ? 0 : (active == 2 ? 1 : (active == 4 ? 2 : 3)));
-    if (c->fused_variant < 3) {  // single sector: interval tables if every row is one contiguous run
-        uint32_t noniv[3] = {1, 1, 1};
-        HIP_TRY(hipMemcpy(noniv, c->d_fused_tables + fused_tables_noniv_offset(), 12, hipMemcpyDeviceToHost));
-        if (noniv[c->fused_variant] == 0) c->fused_variant += 6;
+    if (c->fused_variant < 3 && noniv[c->fused_variant] == 0) c->fused_variant += 6;  // single sector, every row one contiguous run: interval tables
+    if (const char* ev = getenv("MELF_FUSED_VARIANT")) {  // tests: "generic" = 3, "ties" = 4
+        if (!strcmp(ev, "generic") && namb == 0) c->fused_variant = 3;
+        if (!strcmp(ev, "bits") && c->fused_variant >= 6) c->fused_variant -= 6;  // single-sector bit tables
+        if (!strcmp(ev, "ties")) c->fused_variant = 4;
+        if (!strcmp(ev, "memonly")) c->fused_variant = 5;  // timing experiments only: output is garbage
     }
-    if (const char* e = getenv("MELF_FUSED_VARIANT")) {  // tests: "generic" = 3, "ties" = 4
-        if (!strcmp(e, "generic") && namb == 0) c->fused_variant = 3;
-        if (!strcmp(e, "bits") && c->fused_variant >= 6) c->fused_variant -= 6;  // single-sector bit tables
-        if (!strcmp(e, "ties")) c->fused_variant = 4;
-        if (!strcmp(e, "memonly")) c->fused_variant = 5;  // timing experiments only: output is garbage
-    }
+    c->d_fused_tables = tables;
     return MELF_SUCCESS;
 }
 
@@ -632,9 +643,12 @@ extern "C" int melf_ctx_get_masks(const melf_ctx* c, uint8_t* masks)
     return MELF_SUCCESS;
 }
 
-extern "C" int melf_ctx_fused_table_ties(const melf_ctx* c, int* count)
+extern "C" int melf_ctx_fused_table_ties(const melf_ctx* c_, int* count)
 {
-    if (!c || !count) return fail(MELF_ERR_INVALID, "NULL argument");
+    if (!c_ || !count) return fail(MELF_ERR_INVALID, "NULL argument");
+    melf_ctx* c = const_cast<melf_ctx*>(c_);
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = ensure_fused_tables(c)) return rc;
     *count = c->fused_ambiguous;
     return MELF_SUCCESS;
 }
@@ -1165,6 +1179,7 @@ extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int
     if (n == 0) return MELF_SUCCESS;
     if (!d_frames || !d_masks) return fail(MELF_ERR_INVALID, "NULL device pointer");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = ensure_fused_tables(c)) return rc;   // first use: builds them (synchronises the context's stream once)
     hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
         const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;

@@ -507,3 +507,39 @@ def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read
         assert got[ok].tobytes() == ref[ok].tobytes()
     assert rstat[5] == 2 and rstat[300] == 3 and rstat[301] == 1 and rstat[650] == 0
     assert (rstat == 0).sum() == 697
+
+
+@pytest.mark.gpu
+def test_get_meter_values_keeps_its_context_between_calls(tmp_path):
+    """Two calls with the same calibration share one GPU context (taken from and returned to the idle cache); an edited
+    params.yml gets its own; a generator dropped half way returns a usable context; release_cached_contexts() empties
+    the cache.  Results never depend on which context served a call."""
+    import shutil
+    import meterelf_amd
+    from meterelf_amd import _api
+    meterelf_amd.release_cached_contexts()
+    sd = os.path.join(GOLDEN, 'sample-images1')
+    pfile = os.path.join(sd, 'params.yml')
+    files = _files('sample-images1')[:20]
+    first = list(meterelf_amd.get_meter_values(pfile, files))
+    assert len(_api._idle_readers) == 1
+    kept = next(iter(_api._idle_readers.values()))
+    second = list(meterelf_amd.get_meter_values(pfile, files))
+    assert next(iter(_api._idle_readers.values())) is kept          # the same context served the second call
+    assert [(d.filename, d.value, d.meter_values) for d in first] == [(d.filename, d.value, d.meter_values) for d in second]
+    # another calibration: a copy of the directory with a different match threshold
+    other = tmp_path / 'other'
+    shutil.copytree(sd, other)
+    text = (other / 'params.yml').read_text().replace('dials_template_match_threshold: 20000000', 'dials_template_match_threshold: 30000000')
+    (other / 'params.yml').write_text(text)
+    third = list(meterelf_amd.get_meter_values(str(other / 'params.yml'), [str(other / os.path.basename(f)) for f in files]))
+    assert len(_api._idle_readers) == 2
+    assert sum(d.error is not None for d in third) >= sum(d.error is not None for d in first)
+    # a consumer that stops early
+    gen = meterelf_amd.get_meter_values(pfile, files)
+    assert next(gen).filename == files[0]
+    gen.close()
+    again = list(meterelf_amd.get_meter_values(pfile, files))
+    assert [(d.value, d.meter_values) for d in again] == [(d.value, d.meter_values) for d in first]
+    meterelf_amd.release_cached_contexts()
+    assert not _api._idle_readers
