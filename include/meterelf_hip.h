@@ -262,9 +262,8 @@ typedef struct {
     int32_t rows_per_wave;   /* tuned kernel: map rows of a full-row wave (RB); general kernel: tile rows */
     int32_t full_waves;      /* tuned kernel, per group: waves of RB full rows                           */
     int32_t pair_waves;      /* tuned kernel, per group: waves of RB + 1 rows that share a middle row    */
-    int32_t capped;          /* tuned kernel: the register-capped instantiation was launched             */
     int32_t tiles;           /* general / dot4 kernel: tiles (partials) per frame                        */
-    int32_t reserved[5];
+    int32_t reserved[6];
 } melf_match_info;
 int melf_ctx_last_match(const melf_ctx* ctx, melf_match_info* out);
 /* The tuned kernel's wave layout for a template / searched-image shape and a batch of n images, without a GPU or a

@@ -55,7 +55,7 @@ class MelfResult(C.Structure):
 class MelfMatchInfo(C.Structure):
     _fields_ = [('kernel', C.c_int32), ('n', C.c_int32), ('rows', C.c_int32), ('cols', C.c_int32), ('groups', C.c_int32),
                 ('waves', C.c_int32), ('rows_per_wave', C.c_int32), ('full_waves', C.c_int32), ('pair_waves', C.c_int32),
-                ('capped', C.c_int32), ('tiles', C.c_int32), ('reserved', C.c_int32 * 5)]
+                ('tiles', C.c_int32), ('reserved', C.c_int32 * 6)]
 
 
 MATCH_KERNEL_NAMES = ('dot4', 'mfma', 'gen')

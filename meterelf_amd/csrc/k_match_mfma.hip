@@ -259,11 +259,11 @@ __device__ inline bool better_m(float v, int i, float bv, int bi)
 // One wave's whole job.  MFIRST / MLAST: which 32-column blocks (bit xb) the first / last of the R
 // rows computes -- the balanced layout gives two neighbouring waves one column block each of a
 // shared row, so that every wave carries 8 or 9 half-row units instead of 10.
-// WSF ("window sums fused"): `ws` then points at the row-window sums R in epilogue order (k_prep_lplane<.., RFRAG>) and the
-// wave adds them up itself -- one 4 KiB row per template row, requested a step ahead like every other operand, the 64
+// Window sums: `ws` points at the row-window sums R in epilogue order (k_prep_lplane<.., RFRAG>) and the wave adds them
+// up itself -- one 4 KiB row per template row, requested a step ahead like every other operand, the 64
 // additions spread over the step's MFMA sub-blocks (the vector ALU is idle there) -- into the window sums of its first
 // map row; the following rows slide (minus the row that leaves, plus the row that enters) in the epilogue.
-template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST, bool WSF>
+template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST>
 __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                            const uint32_t* __restrict__ ws, const MfmaGeom& g,
                                            float* __restrict__ result_map, MatchPartial* __restrict__ partials,
@@ -311,17 +311,15 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // a wave of the other pipeline lane's dials kernel (104) or prep kernel (64) fits beside it.
     i32x4 a[ND];
     // fused window sums: wsa[16 xb + e] of map row y0 for this lane's (frame, half); rwv = the row in flight
-    uint32_t wsa[WSF ? 32 : 1];
-    i32x4 rwv[WSF ? 4 : 1];
+    uint32_t wsa[32];
+    i32x4 rwv[4];
     const i32x4* const Rrows = (const i32x4*)ws + (size_t)grp * g.rows * 256 + lane;                             // row r at + 256 r
     const i32x4* const Zrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + g.rows) * (size_t)NKB * 1024) + lane;  // an all-zero L' row
     auto rw_row = [&](int i) -> const i32x4* {   // row-window sums of image row y0 + i; template rows >= th are padding
         return i < g.th ? Rrows + (size_t)min(y0 + i, g.rows - 1) * 256 : Zrow;
     };
-    if (WSF) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) wsa[j] = 0;
-    }
+    for (int j = 0; j < 32; ++j) wsa[j] = 0;
     for (int phase = 0; phase < 2; ++phase) {
         const int ibeg = phase == 0 ? istart : 0, iend = phase == 0 ? g.th_pad : istart;
         if (ibeg >= iend) continue;
@@ -333,7 +331,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                 buf[r][kb] = Lrow[(size_t)(ibeg + r) * ROWV + kb * 64];
 #pragma unroll
         for (int d = 0; d < ND; ++d) a[d] = Ap[((size_t)ibeg * ND + d) * 64];
-        if (WSF) {
+        {
             const i32x4* rp = rw_row(ibeg);
 #pragma unroll
             for (int k = 0; k < 4; ++k) rwv[k] = rp[k * 64];
@@ -358,9 +356,9 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                         buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
                     // row-window sums: piece d - 1 of the NEXT template row's R row goes into the registers whose previous
                     // content (this row's piece) was added up in sub-block d - 1
-                    if (WSF && d >= 1 && d <= 4) rwv[d - 1] = rw_row(i + 1)[(d - 1) * 64];
+                    if (d >= 1 && d <= 4) rwv[d - 1] = rw_row(i + 1)[(d - 1) * 64];
                     __builtin_amdgcn_sched_barrier(0);
-                    if (WSF && d < 4) {   // piece d of this template row's R row, requested a step ago
+                    if (d < 4) {   // piece d of this template row's R row, requested a step ago
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const uint32_t v = (uint32_t)rwv[d][c];
@@ -378,7 +376,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                         for (int xb = 0; xb < NXB; ++xb)
                             if (on(r, xb))
                                 acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], buf[(s + r) % NBUF][d + xb], acc[r][xb], 0, 0, 0);
-                    if (WSF && d < 4) {
+                    if (d < 4) {
                         // ... issued BETWEEN the sub-block's MFMAs (a vector instruction that issues while a matrix
                         // instruction runs is free; a cluster of them in front of the sub-block holds the matrix pipe up)
                         constexpr int NM = R * NXB - (NXB == 2 ? (MFIRST != 3) + (MLAST != 3) : 0);   // MFMAs of the sub-block
@@ -407,18 +405,13 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_match_loop_end[blockIdx.x] = __builtin_amdgcn_s_memtime();
 #endif
     // ---- epilogue: exact u8 correlation, OpenCV's float post-pass, first-max reduction ----
-    // All window sums are fetched first (unconditional loads at clamped addresses, one wait), then the
-    // arithmetic runs on registers: with the loads inside the bounds checks every element paid its own
-    // L2 round trip -- a third of the wave's lifetime.
     const int n = lane & 31, hh = lane >> 5;
     const int f = grp * 32 + n;
     // cc = sum T*L is below 2^31 (119*188*255^2 at most for templates this kernel takes), so the three terms
     // can be added modulo 2^32 and converted with one cvt_f64_u32 (an int64 -> double conversion is four
     // instructions, two of them quarter rate).  A lane visits its elements in increasing raster index, so the
-    // first maximum is "strictly greater wins".
-    // Rows in batches of two: a batch's window sums and its accumulators (which leave the accumulator file for the
-    // vector ALU) then fit the 256 architectural VGPRs, and the kernel's register footprint is that of its main loop:
-    // ~400 of 512, which leaves room on every SIMD for a wave of the other pipeline lane's prep or dials kernel.
+    // first maximum is "strictly greater wins".  One map row at a time: a row's window sums and its accumulators
+    // (which leave the accumulator file for the vector ALU) stay within the registers the main loop needs anyway.
     const bool lane_ok = f < g.nframes;
     float bestv = -INFINITY;
     int besti = INT_MAX;
@@ -435,7 +428,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #pragma unroll
     for (int r0 = 0; r0 < R; r0 += RB) {
         uint32_t wsr[RB][NXB][16];
-        if (WSF) {
+        {
             // window sums of row y0 + r0: those of the row above minus the image row that left, plus the one that entered
             if (r0 > 0) {
 #pragma unroll
@@ -452,19 +445,6 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
             for (int xb = 0; xb < NXB; ++xb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) wsr[0][xb][e] = wsa[16 * xb + e];
-        } else {
-#pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
-            const int r = r0 + rr;
-            if (r >= R) continue;
-            const int yc = min(y0 + r, g.rh - 1);
-            const uint32_t* wrow = ws + ((size_t)grp * g.rh + yc) * 64 * 32 + n;
-#pragma unroll
-            for (int xb = 0; xb < NXB; ++xb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (on(r, xb)) wsr[rr][xb][e] = wrow[(32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh) * 32];
-        }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -506,21 +486,16 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 }
 
 
-// Register budget of the kernel.  "amdgpu-num-vgpr" counts architectural VGPRs and the backend doubles it for the unified
-// register file of gfx90a+ (VGPRs + AGPRs): 204 -> 408 of the SIMD's 512, which leaves 104 -- one wave of k_dials -- per
-// SIMD for the other pipeline lane's kernels while a match wave is resident.  Only the CAPPED instantiation carries the
-// limit (under it the 5-row waves spill ~400 bytes per lane to scratch, in the matrix pipe's shadow); the library launches
-// it when the context's other lane is in use, i.e. when there IS another kernel to sit beside the match waves
-// (profiles/r03/match_vgpr_cap_ab.txt), and the uncapped one otherwise.
-#ifndef MELF_MATCH_VGPRS
-#define MELF_MATCH_VGPRS 204
-#endif
-
+// Registers: the 4-row / 5-row-pair instantiation (1024 frames) takes 477 of the SIMD's 512 (accumulators 8-9 x 16, six
+// image rows, the template fragments, 32 window-sum accumulators + the R row in flight), no scratch.  Round 2 capped the
+// kernel at 408 ("amdgpu_num_vgpr(204)", spilling 400 bytes per lane) so that a wave of the other caller stream's dials /
+// prep kernels fits beside a match wave; with this round's layouts the capped build was never faster than the plain
+// one, with one caller stream or with two, and 3x slower for 5-row waves (profiles/r03/match_vgpr_cap_ab.txt): removed.
 // The launch's layout (MfmaGeom::na, template RB): every wave carries 2 RB half-row units (RB full map rows x two
 // 32-column blocks) or, in a pair, 2 RB + 1 (RB + 1 rows of which the shared middle row counts half) -- so that
 // na + 2 pairs waves per frame group fill the chip's 1024 SIMDs in ONE round whatever the batch size: RB = 4 with pairs
 // at 1024 frames (8 or 9 units instead of 10), RB = 2 with pairs at 512 (4 or 5 instead of 8), RB = 3 at 640-900 ...
-template <int ND, int NXB, int RB, int PD, bool WSF>
+template <int ND, int NXB, int RB, int PD>
 __device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                             const uint32_t* __restrict__ ws, const MfmaGeom& g,
                                             float* __restrict__ result_map, MatchPartial* __restrict__ partials)
@@ -538,10 +513,10 @@ __device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const
     if (NXB == 2 && RB < 5 && rblk >= g.na) {
         // a pair: two (RB + 1)-row waves, the first owns column block 0 of the shared middle row, the second block 1
         const int q = rblk - g.na, base = RB * g.na + (2 * RB + 1) * (q >> 1);
-        if ((q & 1) == 0) match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 3, 1, WSF>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
-        else match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 2, 3, WSF>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + RB);
+        if ((q & 1) == 0) match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 3, 1>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
+        else match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 2, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + RB);
     } else {
-        match_wave<ND, NXB, RB, PD, 3, 3, WSF>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * RB);
+        match_wave<ND, NXB, RB, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * RB);
     }
 #ifdef MELF_MATCH_STAMP
     if (threadIdx.x == 0 && id < 8192) {
@@ -556,18 +531,8 @@ __global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__
                                                       const uint32_t* __restrict__ ws, MfmaGeom g,
                                                       float* __restrict__ result_map, MatchPartial* __restrict__ partials)
 {
-    match_block<ND, NXB, RB, PD, true>(Lg, Atab, ws, g, result_map, partials);   // ws = row-window sums R in epilogue order
+    match_block<ND, NXB, RB, PD>(Lg, Atab, ws, g, result_map, partials);   // ws = row-window sums R in epilogue order
 }
-// the same kernel under the register cap (see above); its window sums come ready-made from k_colsum (32 accumulators
-// and a row in flight more would not fit under the cap)
-template <int ND, int NXB, int RB, int PD>
-__global__ __launch_bounds__(64, 1) __attribute__((amdgpu_num_vgpr(MELF_MATCH_VGPRS))) void k_match_mfma_capped(
-    const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab, const uint32_t* __restrict__ ws, MfmaGeom g,
-    float* __restrict__ result_map, MatchPartial* __restrict__ partials)
-{
-    match_block<ND, NXB, RB, PD, false>(Lg, Atab, ws, g, result_map, partials);
-}
-
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -706,22 +671,18 @@ void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan&
 }
 
 template <int NXB, int RB>
-static void launch_mm(bool capped, dim3 grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const int8_t* d_lg,
+static void launch_mm(dim3 grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const int8_t* d_lg,
                       const int8_t* d_atab, const uint32_t* d_ws, const MfmaGeom& g, float* d_result_map, MatchPartial* d_partials)
 {
     // ev_start / ev_stop (optional): time stamps taken by the dispatch itself (hipExtLaunchKernelGGL) -- no
     // hipEventRecord barrier packets in the queue around the kernel
-    if (capped)
-        hipExtLaunchKernelGGL((k_match_mfma_capped<MM_ND, NXB, RB, MM_PD>), grid, dim3(64), 0, stream, ev_start, ev_stop, 0, d_lg, d_atab,
-                              d_ws, g, d_result_map, d_partials);
-    else
-        hipExtLaunchKernelGGL((k_match_mfma<MM_ND, NXB, RB, MM_PD>), grid, dim3(64), 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
+    hipExtLaunchKernelGGL((k_match_mfma<MM_ND, NXB, RB, MM_PD>), grid, dim3(64), 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
                               d_result_map, d_partials);
 }
 
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
-                       hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool capped)
+                       hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     MfmaGeom g;
     g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
@@ -731,7 +692,7 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
     g.tmean = tmean;
     dim3 grid(p.nparts * p.groups);
 #define MM_CASE(NXB_, RB_) \
-    case NXB_ * 8 + RB_: launch_mm<NXB_, RB_>(capped, grid, stream, ev_start, ev_stop, d_lg, d_atab, d_ws, g, d_result_map, d_partials); break;
+    case NXB_ * 8 + RB_: launch_mm<NXB_, RB_>(grid, stream, ev_start, ev_stop, d_lg, d_atab, d_ws, g, d_result_map, d_partials); break;
     switch (p.nxb * 8 + p.rb) {
 #ifdef MELF_MATCH_ONLY_RB4   // experiments: one instantiation (fast compile)
         MM_CASE(2, 4)

@@ -856,29 +856,22 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
     if (kind == MK_FAST) {
         const MfmaPlan pl = mfma_plan(P.th, P.tw, ms.rows, ms.cols, m);
         *nparts = pl.nparts;
-        // under the register cap a wave of the other lane's kernels fits beside a match wave: worth it only when the
-        // context's other lane is in use (another caller stream has work in flight on it).  The uncapped kernel adds up
-        // its window sums itself from R (no k_colsum, no window-sum array); the capped one reads them ready-made.
-        bool capped = false;
-        for (int l = 0; l < melf_ctx::NLANES; ++l) capped = capped || (l != bl && c->lane_owned[l]);
-        if (const char* e = getenv("MELF_MATCH_CAP")) capped = e[0] == '1';  // A/B runs
+        // the tuned kernel adds up its window sums itself from R (no k_colsum launch, no window-sum array)
         if (int rc = grow(&c->d_lg[bl], &c->lg_cap[bl], pl.lg_bytes)) return rc;
         if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
-        if (capped)
-            if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.nparts)) return rc;
         *parts = c->d_lpart[bl];
         hipStream_t ps;
         if (int rc = prep_stream_for(c, bl, ls, &ps)) return rc;
         {
             KernelTimer t(c, MELF_K_LPLANE, ps);
-            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], c->d_wsum[bl], ps, !capped);
+            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], nullptr, ps, true);
         }
         if (int rc = prep_done(c, bl, ps, ls)) return rc;
-        info.rows_per_wave = pl.rb; info.full_waves = pl.na; info.pair_waves = 2 * pl.np; info.capped = capped;
+        info.rows_per_wave = pl.rb; info.full_waves = pl.na; info.pair_waves = 2 * pl.np;
         info.waves = pl.nparts * pl.groups;
-        launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl],
-                          capped ? c->d_wsum[bl] : (const uint32_t*)c->d_rsum[bl], d_map, *parts, ls, ev.start, ev.stop, capped);
+        launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], (const uint32_t*)c->d_rsum[bl], d_map, *parts, ls,
+                          ev.start, ev.stop);
         if (int rc = match_launched(c, bl, ls)) return rc;
     } else if (kind == MK_GEN) {
         melf_ctx::GenEntry* ge = nullptr;
@@ -920,9 +913,9 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
         info.tiles = *nparts;
     }
     if (trace)
-        fprintf(stderr, "[melf match] n=%d crop %dx%d: %s, %d groups, %d waves, rows per wave %d, full %d + pair %d per group%s\n", m, ms.rows,
+        fprintf(stderr, "[melf match] n=%d crop %dx%d: %s, %d groups, %d waves, rows per wave %d, full %d + pair %d per group\n", m, ms.rows,
                 ms.cols, kind == MK_FAST ? "k_match_mfma" : (kind == MK_GEN ? "k_match_gen" : "k_match (dot4)"), info.groups, info.waves,
-                info.rows_per_wave, info.full_waves, info.pair_waves, info.capped ? ", register cap" : "");
+                info.rows_per_wave, info.full_waves, info.pair_waves);
     return MELF_SUCCESS;
 }
 

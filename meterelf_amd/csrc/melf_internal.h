@@ -56,11 +56,10 @@ size_t mfma_atab_bytes(int th);
 void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab);
 void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
                       uint16_t* d_r, uint32_t* d_ws, hipStream_t stream, bool rfrag);
-// launch_mfma_match: capped = the register-capped instantiation, which reads ready-made window sums d_ws (prep with
-// rfrag = false + k_colsum); otherwise d_ws is the row-window sums R in epilogue order (prep with rfrag = true)
+// launch_mfma_match: d_ws = the row-window sums R in epilogue order (prep with rfrag = true); the waves add them up
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
-                       hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool capped = false);
+                       hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- K2, general form (k_match_gen.hip): any template up to 256 columns, any map size ----
 struct GenTask {           // one wave's job

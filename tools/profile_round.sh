@@ -1,30 +1,28 @@
 #!/bin/bash
-# Collects a round's profiles on the GPU box:  tools/profile_round.sh r02
-#  * rocprofv3 --kernel-trace --stats of the default bench command minus its two_streams blocks (`--skip twostream`:
-#    launches that share the chip with another stream's kernels have stretched durations and would blur the per-kernel
-#    averages the roofline lines are checked against)
-#  * HBM traffic counters, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md: they do not fit one
-#    pass; FETCH_SIZE is doubled for wide coalesced reads on gfx950), for each workload bench.py reports a roofline on:
-#      config3  full path, sample-images1, 1024 frames per launch, four batches in rotation
-#      config4  full path, sample-images2
-#      config2  fused mask, B=256 640x480, four buffer pairs in rotation
-#      config5  fused mask, 1080p, B=512
-#      jpeg     1024 fixture files
-#  * traffic.json: bytes per launch for bench.py, stamped with the hash of the kernel sources they were measured on
+# Collects a round's profiles on the GPU box:  tools/profile_round.sh r03
+# Order matters: the PMC passes and traffic.json FIRST, so that the bench run under rocprofv3 finds a fresh traffic.json
+# (round 2 ran the bench first and its line carried `traffic: null (stale)`).
+#  1. HBM traffic counters, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md: they do not fit one
+#     pass; FETCH_SIZE is doubled for wide coalesced reads on gfx950), for each workload bench.py reports a roofline on:
+#       config3  full path, sample-images1, 1024 frames per launch, four batches in rotation
+#       config4  full path, sample-images2
+#       config2  fused mask, B=256 640x480, four buffer pairs in rotation
+#       config5  fused mask, 1080p, B=512
+#       jpeg     1024 fixture files
+#     -> traffic.json: bytes per launch for bench.py, stamped with the hash of the kernel sources they were measured on
+#  2. rocprofv3 --kernel-trace --stats of the default bench command minus its two_streams blocks (`--skip twostream`:
+#     launches that share the chip with another stream's kernels have stretched durations and would blur the per-kernel
+#     averages the roofline lines are checked against) -> bench_kernel_stats.csv + the JSON line of that run
+#  3. one --kernel-trace --stats run PER WORKLOAD whose roofline the line quotes, so that every roofline.frac can be
+#     recomputed from this directory alone: bench_kernel_stats_config2.csv (fused mask B=256 640x480 rotating),
+#     _config5.csv (fused mask 1080p B=512), _config4.csv (full path, sample-images2, single stream, NO resident hint,
+#     no event records: the clean per-kernel table of the 8-GPU headline workload), _config3.csv likewise
 # Everything lands in gpurun_out/prof_<round>/; copy it to profiles/<round>/ to commit it.
 set -e
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/prof_$R
-if [ -z "$STATS_ONLY" ]; then rm -rf $OUT; fi
-rm -rf /tmp/prof && mkdir -p $OUT /tmp/prof
-echo "python3 bench.py --skip twostream" > $OUT/bench_command.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o bench -- python3 bench.py --skip twostream > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-f=$(find /tmp/prof/stats -name '*kernel_stats.csv' | head -1)
-head -1 "$f" > $OUT/bench_kernel_stats.csv
-grep -i 'melf' "$f" >> $OUT/bench_kernel_stats.csv || true
-echo "kernel stats done" >> $OUT/progress.txt
-if [ -n "$STATS_ONLY" ]; then cut -c1-200 $OUT/bench_kernel_stats.csv; exit 0; fi
+rm -rf $OUT /tmp/prof && mkdir -p $OUT /tmp/prof
 pmc() {  # name, command...
   name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -70,4 +68,25 @@ json.dump({'_note': 'HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
           open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
 print(json.dumps(per, indent=1))
 PY
-cat $OUT/bench_kernel_stats.csv | cut -c1-200
+# bench.py looks for profiles/r*/traffic.json: put the fresh one where it will be found (and committed)
+mkdir -p profiles/$R && cp $OUT/traffic.json profiles/$R/traffic.json
+stats() {  # name, command...
+  name=$1; shift
+  rm -rf /tmp/prof/stats_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats_$name -o run -- "$@" > $OUT/${name}_stdout.txt 2> $OUT/${name}_stderr.txt
+  f=$(find /tmp/prof/stats_$name -name '*kernel_stats.csv' | head -1)
+  head -1 "$f" > $OUT/bench_kernel_stats_$name.csv
+  grep -i 'melf' "$f" >> $OUT/bench_kernel_stats_$name.csv || true
+  echo "$*" > $OUT/${name}_command.txt
+  echo "stats $name done" >> $OUT/progress.txt
+}
+stats bench python3 bench.py --skip twostream
+mv $OUT/bench_kernel_stats_bench.csv $OUT/bench_kernel_stats.csv
+mv $OUT/bench_stdout.txt $OUT/bench_under_rocprof.json; mv $OUT/bench_stderr.txt $OUT/bench_under_rocprof.err
+stats config2 python3 tools/run_stage.py fused --iters 60 --hw 640x480 --batch 256 --nbuf 4 --profiling 0
+stats config5 python3 tools/run_stage.py fused --iters 16 --hw 1080x1920 --batch 512 --nbuf 1 --profiling 0
+stats config4 python3 tools/run_stage.py full --iters 60 --sample-dir sample-images2 --device-records --profiling 0
+stats config3 python3 tools/run_stage.py full --iters 60 --device-records --profiling 0
+rm -f $OUT/*_stderr.txt
+cut -c1-160 $OUT/bench_kernel_stats.csv
+for n in config2 config5 config4 config3; do echo "== $n"; cut -c1-160 $OUT/bench_kernel_stats_$n.csv; done

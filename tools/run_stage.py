@@ -47,7 +47,7 @@ def main():
         for i in range(10):  # untimed warm-up launches
             launch(i)
         torch.cuda.synchronize()
-        ctx.set_profiling(True)
+        ctx.set_profiling(bool(a.profiling))
         for i in range(a.iters):
             launch(i)
         torch.cuda.synchronize()
