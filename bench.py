@@ -265,8 +265,10 @@ def match_roofline(P, H, W, kt, frames_total, traffic_entry):
         'unit': 'TFLOP/s', 'frac': round(tops / I8_MFMA_PEAK_TOPS, 5), 'traffic': traffic, 'traffic_source': source,
         'avg_launch_ms': round(match_avg_ms, 4), 'launches': match_n,
         'algorithmic': '%d int MAC/frame x %d frames/launch, 2 ops per MAC' % (mac_per_frame, frames_per_launch),
-        'note': 'exact integer TM_CCOEFF on v_mfma_i32_32x32x32_i8; algorithmic MACs only (Toeplitz zero padding '
-                'is not counted), priced against the dense i8 MFMA peak',
+        'note': 'exact integer TM_CCOEFF on v_mfma_i32_32x32x32_i8; algorithmic MACs only (Toeplitz zero padding is not '
+                'counted), priced against the dense i8 MFMA peak.  Since round 3 the tuned kernel (k_match_mfma) also adds up '
+                'the window sums of TM_CCOEFF itself (round 2: a separate k_colsum launch of 15 us that the prep figure carried): '
+                'its launch is ~10 us longer for that and the step ~14 us shorter',
     }
 
 

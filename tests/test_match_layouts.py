@@ -269,3 +269,42 @@ def test_wide_crops_pick_a_kernel_that_can_launch(lay, rows, cols, want):
         assert np.array_equal(rmap[i], emap), i
         assert (float(mv[i]), int(mx[i]), int(my[i])) == (ev, ex, ey), i
     assert (int(mx[1]), int(my[1])) == (cols - tpl.shape[1] - 7, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('th,tw,rows,cols', [(100, 170, 160, 220), (91, 190, 130, 230), (61, 163, 200, 190), (120, 188, 250, 250)],
+                         ids=lambda v: str(v))
+def test_other_template_heights_in_every_layout(tmp_path, monkeypatch, th, tw, rows, cols):
+    """Templates whose height is NOT one short of the padded height (the fixture's 119 -> 120): up to 29 zero template
+    rows, for which the waves must add an all-zero row-window-sum row, in every layout (forced).  Whole maps against the
+    oracle and the VALU kernel."""
+    from oracle import pyoracle as po
+    from tests.test_gpu_parity import _reader_with_template
+    rng = np.random.default_rng(th * 1000 + tw)
+    tpl = rng.integers(0, 256, size=(th, tw), dtype=np.uint8)
+    n = 40
+    imgs = rng.integers(0, 256, size=(n, rows, cols), dtype=np.uint8)
+    imgs[3, 7:7 + th, 5:5 + tw] = tpl
+    imgs[-1] = 255
+    monkeypatch.setenv('MELF_MATCH', 'dot4')
+    r0 = _reader_with_template(tmp_path / 'dot4', tpl)
+    try:
+        (mvd, mxd, myd, rmapd) = r0.ctx.match_ccoeff(imgs, want_map=True)
+    finally:
+        r0.close()
+    for i in (0, 3, n - 1):
+        (ev, ex, ey, emap) = po.match_ccoeff(imgs[i], tpl, want_map=True)
+        assert np.array_equal(rmapd[i], emap), i
+    assert (int(mxd[3]), int(myd[3])) == (5, 7)
+    monkeypatch.setenv('MELF_MATCH', 'fast')
+    r = _reader_with_template(tmp_path / 'fast', tpl)
+    try:
+        for (rb, pairs) in ((2, 0), (2, 3), (3, 0), (3, 2), (4, 0), (4, 1), (5, 0)):
+            monkeypatch.setenv('MELF_MATCH_LAYOUT', '%d,%d' % (rb, pairs))
+            (mv, mx, my, rmap) = r.ctx.match_ccoeff(imgs, want_map=True)
+            info = r.ctx.last_match()
+            assert info['kernel'] == 'mfma' and info['rows_per_wave'] == rb, info
+            assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32)), (rb, pairs)
+            assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mvd.tobytes(), mxd.tobytes(), myd.tobytes())
+    finally:
+        r.close()
