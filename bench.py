@@ -541,7 +541,7 @@ def config5_block(env, cfg3_frames, steps, warmup, traffic):
         m = min(k, B5 - i0)
         frames[i0:i0 + m, 420:670, 1210:1460] = cfg3_frames[:m, 160:410, 50:300]
     env.sync()
-    fused = fused_block(env, ctx, B5, H5, W5, 1, max(3, steps // 4), 2, traffic, 'config5', frames=frames)
+    fused = fused_block(env, ctx, B5, H5, W5, 1, max(12, steps), 6, traffic, 'config5', frames=frames)
     fused['workload'] = ('B=%d frames of 1920x1080 (%.2f GB in + %.2f GB out per launch), fused HLS+inRange+closing over '
                          'whole frames' % (B5, B5 * H5 * W5 * 3 / 1e9, B5 * H5 * W5 / 1e9))
     d_results = torch.zeros(B5 * _hip.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=env.device)

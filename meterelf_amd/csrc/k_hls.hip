@@ -14,6 +14,8 @@
 #include <stdlib.h>
 
 #include "melf_device.h"
+#include <hip/hip_ext.h>
+
 #include "melf_internal.h"
 
 namespace melf {
@@ -607,6 +609,8 @@ bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W)
 //   2: 1024 threads, 1-2 workgroups/CU (4 waves/SIMD), register prefetch
 //   3: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), no prefetch
 static int g_fused_config = -1;  // -1: per-variant default
+static thread_local hipEvent_t g_fused_ev_start = nullptr, g_fused_ev_stop = nullptr;
+void fused_mask_timing_events(hipEvent_t start, hipEvent_t stop) { g_fused_ev_start = start; g_fused_ev_stop = stop; }
 
 template <int V, int T, int PF, int WPS>
 static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
@@ -638,8 +642,11 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
         }
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, d_frames, n, H, W, hue_shift,
-                       B, d_tables, d_masks, segs, seg_rows, NB, plain_store);
+    // timing events (optional, set by the caller through fused_mask_timing_events): the dispatch's own start / stop stamps,
+    // no event-record packets in the queue around the kernel
+    hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+                          n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, plain_store);
+    g_fused_ev_start = g_fused_ev_stop = nullptr;
 }
 
 template <int V>

@@ -1176,14 +1176,24 @@ extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int
     hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
         const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
-        KernelTimer t(c, MELF_K_FUSED_MASK, st);
         const uint8_t* fin = (const uint8_t*)d_frames + (size_t)f0 * H * W * 3;
         uint8_t* fout = (uint8_t*)d_masks + (size_t)f0 * H * W;
-        if (fused_mask_lut_ok(fin, fout, H, W) && !c->force_generic_mask)
+        if (fused_mask_lut_ok(fin, fout, H, W) && !c->force_generic_mask) {
+            TimedEvent ev;
+            ev.kernel = MELF_K_FUSED_MASK;
+            ev.start = ev.stop = nullptr;
+            if (c->profiling == 1) {   // the dispatch's own time stamps, as for the match kernel (no event-record packets)
+                HIP_TRY(hipEventCreateWithFlags(&ev.start, hipEventDisableSystemFence));
+                HIP_TRY(hipEventCreateWithFlags(&ev.stop, hipEventDisableSystemFence));
+                fused_mask_timing_events(ev.start, ev.stop);
+            }
             launch_fused_mask_lut(fin, m, H, W, c->P.hue_shift, c->P.needle_lo, c->P.needle_hi, c->d_fused_tables,
                                   c->fused_variant, fout, st);
-        else
+            if (ev.start) c->events.push_back(ev);
+        } else {
+            KernelTimer t(c, MELF_K_FUSED_MASK, st);
             launch_fused_mask(fin, m, H, W, c->P.hue_shift, c->P.needle_lo, c->P.needle_hi, fout, st);
+        }
     }
     HIP_TRY(hipGetLastError());
     return MELF_SUCCESS;

@@ -128,6 +128,8 @@ int fused_tables_active_offset();
 int fused_tables_noniv_offset();
 void launch_build_fused_tables(int hue_shift, const int lo[3], const int hi[3], uint32_t* d_tables, hipStream_t stream);
 bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W);
+// the next launch_fused_mask_lut of this thread carries these events as its dispatch's own start / stop stamps
+void fused_mask_timing_events(hipEvent_t start, hipEvent_t stop);
 void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3],
                            const int hi[3], const uint32_t* d_tables, int variant, uint8_t* d_masks,
                            hipStream_t stream);
