@@ -295,14 +295,16 @@ struct melf_ctx {
     // the shadow of the other's match kernel); a third stream, or a call that needs a particular lane, first waits for
     // what the lane's previous stream enqueued (claim_lane).
     // "Frames resident" (melf_ctx_set_frames_resident): the caller guarantees that the frames of a *_dev call are complete in
-    // memory when the call is made.  A call's prep kernels (which only read frames and write the lane's work buffers)
-    // then run on the lane's side stream as soon as the lane's previous match kernel is done, i.e. under the previous
-    // call's dials kernel, instead of behind it.
+    // memory when the call is made.  Consecutive calls -- even on ONE caller stream -- then alternate between the context's
+    // two lanes, each call's kernels on its lane's own stream: prep and match start at once (they read only the frames
+    // and write only the lane's work buffers), the dials kernel (the one that writes the caller's records) first waits for
+    // everything the caller's stream held at the time of the call, and the caller's stream continues when the call is done.
+    // So a call's prep and match run under the previous call's match tail and dials kernel, as with two caller streams.
     bool frames_resident = false;
-    bool ahead_ok = false;               // set by the entry points that may use it, for the duration of the call
-    hipStream_t side_stream[NLANES] = {};
-    hipEvent_t ev_match_done[NLANES] = {}, ev_prep_done[NLANES] = {};
-    bool match_done_valid[NLANES] = {};
+    int resident_next_lane = 0;
+    hipEvent_t ev_call[NLANES] = {};     // caller-stream position at the time of a call (waited for by its dials kernel)
+    hipStream_t order_stream = nullptr;  // during a resident-mode call: the caller's stream (NULL stream: see order_null)
+    bool order_valid = false;
     hipStream_t lane_owner[NLANES] = {};
     bool lane_owned[NLANES] = {};
     uint64_t lane_used[NLANES] = {};
@@ -588,11 +590,8 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_order) hipEventDestroy(c->ev_order);
-    for (int l = 0; l < melf_ctx::NLANES; ++l) {
-        if (c->side_stream[l]) hipStreamDestroy(c->side_stream[l]);
-        if (c->ev_match_done[l]) hipEventDestroy(c->ev_match_done[l]);
-        if (c->ev_prep_done[l]) hipEventDestroy(c->ev_prep_done[l]);
-    }
+    for (int l = 0; l < melf_ctx::NLANES; ++l)
+        if (c->ev_call[l]) hipEventDestroy(c->ev_call[l]);
     hipFree(c->d_tplT); hipFree(c->d_geom); hipFree(c->d_rowmasks); hipFree(c->d_fused_tables);
     hipFree(c->d_results); hipFree(c->d_stage_in); hipFree(c->d_stage_out);
     hipFree(c->d_crops);
@@ -623,7 +622,7 @@ extern "C" int melf_ctx_sync(melf_ctx* c)
         if (c->lane_owned[l]) HIP_TRY(hipStreamSynchronize(c->lane_owner[l]));
         c->lane_owned[l] = false;
         c->lane_owner[l] = nullptr;
-        if (c->side_stream[l]) HIP_TRY(hipStreamSynchronize(c->side_stream[l]));
+        HIP_TRY(hipStreamSynchronize(c->lane_stream[l]));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MELF_SUCCESS;
@@ -657,7 +656,6 @@ extern "C" int melf_ctx_set_frames_resident(melf_ctx* c, int on)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
     c->frames_resident = on != 0;
-    if (!on) for (int l = 0; l < melf_ctx::NLANES; ++l) c->match_done_valid[l] = false;
     return MELF_SUCCESS;
 }
 
@@ -789,36 +787,6 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
     return MELF_SUCCESS;
 }
 
-// Where lane bl's prep kernels go: the lane's side stream, released by the lane's previous match kernel, when the
-// frames are known to be resident; else the call's own stream.
-static int prep_stream_for(melf_ctx* c, int bl, hipStream_t ls, hipStream_t* out)
-{
-    *out = ls;
-    if (!(c->frames_resident && c->ahead_ok && c->match_done_valid[bl])) return MELF_SUCCESS;
-    if (!c->side_stream[bl]) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side_stream[bl], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_prep_done[bl], hipEventDisableTiming));
-    }
-    HIP_TRY(hipStreamWaitEvent(c->side_stream[bl], c->ev_match_done[bl], 0));
-    *out = c->side_stream[bl];
-    return MELF_SUCCESS;
-}
-static int prep_done(melf_ctx* c, int bl, hipStream_t ps, hipStream_t ls)
-{
-    if (ps == ls) return MELF_SUCCESS;
-    HIP_TRY(hipEventRecord(c->ev_prep_done[bl], ps));
-    HIP_TRY(hipStreamWaitEvent(ls, c->ev_prep_done[bl], 0));
-    return MELF_SUCCESS;
-}
-static int match_launched(melf_ctx* c, int bl, hipStream_t ls)
-{
-    if (!(c->frames_resident && c->ahead_ok)) { c->match_done_valid[bl] = false; return MELF_SUCCESS; }
-    if (!c->ev_match_done[bl]) HIP_TRY(hipEventCreateWithFlags(&c->ev_match_done[bl], hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(c->ev_match_done[bl], ls));
-    c->match_done_valid[bl] = true;
-    return MELF_SUCCESS;
-}
-
 // prep + match of m images on stream ls with lane bl's work buffers; *parts / *nparts: per-frame (max, first arg-max)
 // partials for the consumer (k_dials or the host fold of melf_match_ccoeff)
 static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m, int bl, hipStream_t ls, float* d_map,
@@ -861,18 +829,14 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
         if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.nparts)) return rc;
         *parts = c->d_lpart[bl];
-        hipStream_t ps;
-        if (int rc = prep_stream_for(c, bl, ls, &ps)) return rc;
         {
-            KernelTimer t(c, MELF_K_LPLANE, ps);
-            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], nullptr, ps, true);
+            KernelTimer t(c, MELF_K_LPLANE, ls);
+            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], nullptr, ls, true);
         }
-        if (int rc = prep_done(c, bl, ps, ls)) return rc;
         info.rows_per_wave = pl.rb; info.full_waves = pl.na; info.pair_waves = 2 * pl.np;
         info.waves = pl.nparts * pl.groups;
         launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], (const uint32_t*)c->d_rsum[bl], d_map, *parts, ls,
                           ev.start, ev.stop);
-        if (int rc = match_launched(c, bl, ls)) return rc;
     } else if (kind == MK_GEN) {
         melf_ctx::GenEntry* ge = nullptr;
         if (int rc = gen_entry(c, ms.rows, ms.cols, m, &ge)) return rc;
@@ -889,25 +853,20 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
             if (pl.part_bytes) HIP_TRY(hipMalloc(&ge->part[bl], pl.part_bytes));
         }
         *parts = c->d_lpart[bl];
-        hipStream_t ps;
-        if (int rc = prep_stream_for(c, bl, ls, &ps)) return rc;
         {
-            KernelTimer t(c, MELF_K_LPLANE, ps);
+            KernelTimer t(c, MELF_K_LPLANE, ls);
             launch_match_prep(ms, from_bgr, m, pl.groups, pl.rows_pad, pl.nkb, pl.rwp, pl.rh, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl],
-                              c->d_wsum[bl], ps);
+                              c->d_wsum[bl], ls);
         }
-        if (int rc = prep_done(c, bl, ps, ls)) return rc;
         GenDev dev = ge->dev;
         dev.part = ge->part[bl];
         dev.counters = ge->counters[bl];
         info.tiles = pl.ntiles; info.waves = pl.ntasks * pl.groups; info.rows_per_wave = pl.rc;
         launch_gen_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls, ev.start, ev.stop);
-        if (int rc = match_launched(c, bl, ls)) return rc;
     } else {
         *nparts = match_parts(c->mg, ms.rows, ms.cols);
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * *nparts)) return rc;
         *parts = c->d_lpart[bl];
-        c->match_done_valid[bl] = false;
         KernelTimer t(c, MELF_K_MATCH, ls);
         launch_match(ms, from_bgr, m, c->mg, c->d_tplT, d_map, *parts, nullptr, ls);
         info.tiles = *nparts;
@@ -937,15 +896,34 @@ extern "C" int melf_process_batch_dev(melf_ctx* c, const void* d_frames, int n, 
     if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
+    if (c->frames_resident && c->lanes == 1 && n <= MAX_FRAMES_PER_LAUNCH) {
+        // frames promised complete: the call runs on the next lane's own stream, beside the previous call's kernels on the
+        // other lane; only its dials kernel (which writes the records) waits for the caller's stream (process_batch_on)
+        const int lane = c->resident_next_lane;
+        c->resident_next_lane = (lane + 1) % melf_ctx::NLANES;
+        hipStream_t ls = c->lane_stream[lane];
+        if (int rc = claim_lane(c, lane, ls)) return rc;
+        c->active_lane = lane;
+        c->order_stream = st;
+        c->order_valid = true;
+        const int rc = process_batch_on(c, d_frames, n, H, W, frame_stride, d_results, nullptr, ls);
+        c->order_valid = false;
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_join[lane], ls));
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_join[lane], 0));   // what the caller enqueues next sees the records
+        if (out_host) {
+            const melf_result* res_dev = d_results ? (const melf_result*)d_results : c->d_results;
+            HIP_TRY(hipMemcpyAsync(out_host, res_dev, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        return MELF_SUCCESS;
+    }
     if (c->lanes > 1) {  // the batch is split over both lanes
         if (int rc = claim_all_lanes(c, st)) return rc;
     } else if (int rc = acquire_lane(c, st, &c->active_lane)) {
         return rc;
     }
-    c->ahead_ok = c->lanes == 1 && n <= MAX_FRAMES_PER_LAUNCH;  // one prep / match / dials sequence per call
-    const int rc = process_batch_on(c, d_frames, n, H, W, frame_stride, d_results, out_host, st);
-    c->ahead_ok = false;
-    return rc;
+    return process_batch_on(c, d_frames, n, H, W, frame_stride, d_results, out_host, st);
 }
 
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
@@ -995,6 +973,14 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
             DialsSrc ds;
             ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = row_stride;
             ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
+            if (c->order_valid) {
+                // resident mode: prep and match above ran unordered with the caller's stream (they touch only the frames
+                // and the lane's buffers); the kernel that writes the caller's records waits for everything that stream
+                // held when the call was made
+                if (!c->ev_call[bl]) HIP_TRY(hipEventCreateWithFlags(&c->ev_call[bl], hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(c->ev_call[bl], c->order_stream));
+                HIP_TRY(hipStreamWaitEvent(ls, c->ev_call[bl], 0));
+            }
             {
                 KernelTimer t(c, MELF_K_DIALS, ls);
                 launch_dials(ds, false, m, P, c->d_geom, c->d_rowmasks, parts, nparts, rw, res_dev + g0, ls, c->ws_max);
@@ -1511,7 +1497,6 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     const char* rmode = getenv("MELF_JPEG_READ");
     const bool read_chunks = rmode && !strcmp(rmode, "chunk");
     if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
-    c->ahead_ok = false;
     int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks);
     if (rc == MELF_SUCCESS && !read_chunks) {
         if (c->lanes > 1) rc = claim_all_lanes(c, c->stream);

@@ -13,6 +13,9 @@ if s:
 t = d.get('two_streams')
 if t:
     print('  two streams %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t['records_identical_to_single_stream']))
+t = d.get('resident_hint')
+if t:
+    print('  one stream + resident hint %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t['records_identical_to_headline']))
 f = d.get('fused_mask')
 if f:
     print('  fused (config 2) %.4f ms  %.0f GB/s  frac %.4f  | two streams %s' % (f['roofline']['avg_launch_ms'], f['roofline']['achieved'], f['roofline']['frac'], f.get('two_streams')))
