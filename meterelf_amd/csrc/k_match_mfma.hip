@@ -558,12 +558,13 @@ bool mfma_match_ok(int th, int tw, int rows, int cols)
 }
 
 // Cost model of one wave, in shader cycles (measured on MI355X): ~33 cycles per MFMA in the
-// loop, ~11 cycles of matrix-pipe idle per 1 KiB fragment load issued between the MFMA groups, the epilogue (window
-// sums, double-precision post-pass, arg-max) ~2 400 cycles per half-row unit, priming ~4 000.
+// loop, ~11 cycles of matrix-pipe idle per 1 KiB fragment load issued between the MFMA groups, the epilogue
+// (double-precision post-pass, arg-max) ~2 400 cycles per half-row unit + ~1 200 per map row (its window sums slide in:
+// eight loads, 64 additions), priming ~4 000.
 static double mm_wave_cycles(int R, int units, int nxb, int th_pad)
 {
-    const int nkb = MM_ND + nxb - 1;
-    return (double)th_pad * ((double)units * MM_ND * 33.0 + (double)(nkb + MM_ND) * 11.0) + units * 2400.0 + 4000.0 + R * 0.0;
+    const int nkb = MM_ND + nxb - 1;   // image-row fragments per step; + MM_ND template fragments + 4 pieces of the R row
+    return (double)th_pad * ((double)units * MM_ND * 33.0 + (double)(nkb + MM_ND + 4) * 11.0) + units * 2400.0 + 4000.0 + R * 1200.0;
 }
 
 MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)

@@ -576,6 +576,11 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     free(c->file_arena);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (int l = 0; l < melf_ctx::NLANES; ++l)   // resident mode and the split modes run whole calls on the lanes' own streams
+        if (c->lane_stream[l]) hipStreamSynchronize(c->lane_stream[l]);
+    for (int b = 1; b < melf_ctx::NJ; ++b)
+        if (c->jpeg_stream[b]) hipStreamSynchronize(c->jpeg_stream[b]);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     hipFree(c->d_atab);
     for (auto* ge : c->gen_cache) {
