@@ -129,12 +129,13 @@ static_assert(DIAL_LIST_CAP * 4 + DIAL_LIST_CAP * 2 <= 4608 && RING_CAP * 16 + R
 
 // Three bytes of a packed 3-channel pixel with ONE (unaligned) dword load instead of three byte loads: the
 // dword starts one byte early (so it never runs past the buffer's end) except at the buffer's very first pixel.
+// The top byte of the result is unspecified (every user looks at bytes 0..2 only).
 __device__ __forceinline__ uint32_t load_px3(const uint8_t* p, const uint8_t* buffer_start)
 {
-    const bool first = p == buffer_start;
+    const uint32_t back = p == buffer_start ? 0u : 1u;
     uint32_t v;
-    __builtin_memcpy(&v, first ? p : p - 1, 4);
-    return first ? (v & 0xffffffu) : (v >> 8);
+    __builtin_memcpy(&v, p - back, 4);
+    return v >> (8u * back);
 }
 
 // packed 16-bit arithmetic on two values per register (v_pk_*_u16)
@@ -172,10 +173,11 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_dials_stamps(ui
 #define DSTAMP(k) do { } while (0)
 #endif
 
-// Register budget: 104 of the SIMD's 512 ("amdgpu-num-vgpr" is doubled by the backend for gfx90a+'s unified file), so that a
-// wave of this kernel fits beside a resident k_match_mfma wave (408) when two caller streams drive the context's lanes.
+// Register budget: 128 of the SIMD's 512 ("amdgpu-num-vgpr" is doubled by the backend for gfx90a+'s unified file): four waves
+// per SIMD, i.e. all 4 096 waves of a 1024-frame batch resident at once.  (Round 2 held it at 104 so that a wave fitted beside
+// a register-capped match wave of the other caller stream; that variant is gone, and at 128 nothing spills.)
 #ifndef MELF_DIALS_VGPRS
-#define MELF_DIALS_VGPRS 52
+#define MELF_DIALS_VGPRS 64
 #endif
 // NR: window rows whose pixels a lane requests up front (the largest dial window of the context, rounded up to 8)
 template <bool FROM_HLS, int NR>
@@ -244,7 +246,8 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     // ---- one wave per dial ----
     const DialGeom G = geom[d];
     const melf_dial D = P.dial[d];
-    const int wx0 = G.wx0, wy0 = G.wy0, ws = G.ws;
+    // one dial per wave: its geometry is wave-uniform (tell the compiler, so that row / window tests are scalar)
+    const int wx0 = __builtin_amdgcn_readfirstlane(G.wx0), wy0 = __builtin_amdgcn_readfirstlane(G.wy0), ws = __builtin_amdgcn_readfirstlane(G.ws);
 
     // Every pixel this wave needs is requested here, before anything waits: the 5x5 colour core (one pixel per lane)
     // and the lane's column of the window (lane = column, one packed VGPR per window row).  Unconditional loads at
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                     else hls_pixel(px & 255, (px >> 8) & 255, (px >> 16) & 255, tail, P.hue_shift, H, L, S);
                     in = H >= loh && H <= hih && L >= lol && L <= hil && S >= los && S <= his;
                 }
-                const uint64_t b = __ballot(in), vb = __ballot(valid);
+                const uint64_t b = __builtin_amdgcn_ballot_w64(in), vb = __builtin_amdgcn_ballot_w64(valid);
                 if (lane == y) { m0 = b; V = vb; }
             }
         }
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         // inequalities above halved) are exact in 16 bits; "x outside [lo, hi]" is  x != min(max(x, lo), hi).  Grey pixels
         // (diff = 0) pass here when los <= 1 although only los = 0 admits them: a candidate more for the exact test.
         int total = 0;  // wave-uniform
-        const uint64_t colb = __ballot(colvalid);
+        const uint64_t colb = __builtin_amdgcn_ballot_w64(colvalid);
         const uint32_t LO2 = (uint32_t)max(2 * lol - 1, 0) * 0x00010001u, HI2 = (uint32_t)(2 * hil + 1) * 0x00010001u;
         const uint32_t SLO = (uint32_t)max(los - 1, 0) * 0x00010001u, SHI = (uint32_t)(his + 1) * 0x00010001u;
 #pragma unroll
@@ -347,9 +350,9 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = k2 + h, y = k, Y = wy0 + y;
-                const bool rowok = y < ws && Y >= 0 && Y < P.th;                      // wave-uniform
-                const bool cand = (h ? bad < 0x10000u : (bad & 0xffffu) == 0u) && colvalid && rowok;
-                const uint64_t cb = __ballot(cand);
+                const bool rowok = (y < ws) & (Y >= 0) & (Y < P.th);                  // wave-uniform
+                const bool cand = (h ? bad < 0x10000u : (bad & 0xffffu) == 0u) & colvalid & rowok;
+                const uint64_t cb = __builtin_amdgcn_ballot_w64(cand);
                 const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
                 if (cand && slot < DIAL_LIST_CAP) {
                     list_pos[slot] = (uint16_t)(y << 6 | lane);
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
 
     int status = 0;  // 0 ok, 1 no contours, 2 unreadable
     double pos = 0.0, angle = 0.0;
-    if (__ballot(M != 0) == 0) {
+    if (__builtin_amdgcn_ballot_w64(M != 0) == 0) {
         status = 1;  // NeedleContoursNotFoundError (_reading.py:137-138)
     } else {
         // pixels of ~M that are 4-connected to the outside of the disk.  The seed is host-computed:
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
             const uint64_t n = o | ((((o << 1) | (o >> 1)) | row_up(o, lane, ~0ull) | row_down(o, lane, ~0ull)) & freeb);
             const bool ch2 = n != o;
             o = n;
-            if (__ballot(ch2) == 0) break;
+            if (__builtin_amdgcn_ballot_w64(ch2) == 0) break;
         }
         const uint64_t Gf = ~o;  // M plus everything its outer borders enclose
         // 8-connected components of Gf in raster order of their first pixel =
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         uint64_t rem = Gf, bestF = 0;
         int best2 = -1;
         for (;;) {
-            const uint64_t rowsb = __ballot(rem != 0);
+            const uint64_t rowsb = __builtin_amdgcn_ballot_w64(rem != 0);
             if (rowsb == 0) break;
             const int r0 = __builtin_ctzll(rowsb);
             // row r0 of `rem` for every lane: r0 is wave-uniform, so this is two v_readlane (no LDS permute)
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                 const uint64_t n = (h3 | row_up(h3, lane, 0) | row_down(h3, lane, 0)) & Gf;
                 const bool ch2 = n != s;
                 s = n;
-                if (__ballot(ch2) == 0) break;
+                if (__builtin_amdgcn_ballot_w64(ch2) == 0) break;
             }
             const uint64_t a = s, b = row_down(s, lane, 0), a1 = a >> 1, b1 = b >> 1;
             const int c = 2 * __builtin_popcountll(a & a1 & b & b1) + __builtin_popcountll(a & a1 & b & ~b1) +
