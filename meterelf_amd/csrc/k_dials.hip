@@ -353,12 +353,14 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                 const bool rowok = (y < ws) & (Y >= 0) & (Y < P.th);                  // wave-uniform
                 const bool cand = (h ? bad < 0x10000u : (bad & 0xffffu) == 0u) & colvalid & rowok;
                 const uint64_t cb = __builtin_amdgcn_ballot_w64(cand);
-                const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
-                if (cand && slot < DIAL_LIST_CAP) {
-                    list_pos[slot] = (uint16_t)(y << 6 | lane);
-                    list_px[slot] = pxv[k];
+                if (cb) {   // wave-uniform: most rows above and below the needle have no candidate at all
+                    const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+                    if (cand && slot < DIAL_LIST_CAP) {
+                        list_pos[slot] = (uint16_t)(y << 6 | lane);
+                        list_px[slot] = pxv[k];
+                    }
+                    total += __popcll(cb);
                 }
-                total += __popcll(cb);
             }
         }
         // lane y's row of the window's valid-pixel mask (what the per-row ballots of `valid` used to deliver)

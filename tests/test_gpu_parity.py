@@ -885,6 +885,35 @@ def test_frames_resident_hint_same_records(env):
         hip.hipFree(d_res)
 
 
+def test_frames_resident_hint_with_host_records_and_mode_switches(env):
+    """The hint with records returned to the host (each call synchronises), switched on and off between calls, and a
+    non-resident call on a caller stream in between (lane hand-over between a lane's own stream and a caller stream)."""
+    import ctypes as C
+    e = env['sample-images1']
+    frames = synth_frames(_good(e['files']), 2 * 320, 555)
+    ctx = e['reader'].ctx
+    ref = ctx.process_batch(frames)
+    hip = hip_runtime()
+    (n, H, W) = (320, frames.shape[1], frames.shape[2])
+    d_frames = C.c_void_p()
+    st = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_frames), C.c_size_t(frames.nbytes)) == 0
+    assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0
+    try:
+        assert hip.hipMemcpy(d_frames, frames.ctypes.data_as(C.c_void_p), C.c_size_t(frames.nbytes), 1) == 0
+        assert hip.hipDeviceSynchronize() == 0
+        for (i, hint) in enumerate([True, True, False, True, True, True, False, False]):
+            ctx.set_frames_resident(hint)
+            b = i % 2
+            got = ctx.process_batch_dev(d_frames.value + b * n * H * W * 3, n, H, W, want_host=True, stream=st.value if i % 3 else None)
+            assert got.tobytes() == ref[b * n:(b + 1) * n].tobytes(), (i, hint)
+    finally:
+        ctx.set_frames_resident(False)
+        ctx.sync()
+        hip.hipStreamDestroy(st)
+        hip.hipFree(d_frames)
+
+
 # ---- BASELINE.json's full per-GPU sizes: the oracle is too slow there, so what is checked is what cannot depend on the
 # ---- batch -- a frame's record is a function of that frame alone -- plus the oracle on a sample of the same frames
 def _records_equal(a, b):
