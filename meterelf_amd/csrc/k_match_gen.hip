@@ -396,7 +396,7 @@ GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes)
     // tile pays the hand-off and the completing wave's pass over the other slices' partial tiles.
     struct Tile { int y0, R, Rc, xb0, nxb; long work; bool v; };
     const int nvt = p.vcols * ((p.rh + 31) / 32);          // V-form tiles per group
-    const long slots = std::max(64L, 1024L - 6L * nvt * p.groups);   // wave slots for the H form: ~6 slices per V tile reserved
+    const long slots = std::max(64L, 1024L - 4L * nvt * p.groups);   // wave slots for the H form: >= 4 slices per V tile reserved
     double best_cost = 1e30;
     int best_rc = 8, best_nxb = 2, best_ns = 1;
     for (int rc = 8; rc >= 2; rc -= 2)
@@ -404,8 +404,13 @@ GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes)
             if (nx > nxb_h && nx > 1) continue;
             const int ntr = (p.rh + rc - 1) / rc, nstr = (nxb_h + nx - 1) / nx;
             const long ntile = (long)ntr * nstr;
-            const double lpm = (double)(nx + 1) / (rc * nx);
-            const double cyc = std::max(40.0, 90.0 * lpm);
+            // a K step = nx + 1 fragment loads + rc * nx MFMAs: ~42 cycles per load (issue, address arithmetic, the wait it
+            // eventually causes) + ~29 per MFMA (66 / 93 / 117 / 145 ns per step for 2 / 4 / 6 / 8-row tiles of one block); a sliced tile pays its hand-off: ~5 500 cycles + ~220 per KiB of partial
+            // tile the completing wave has to pull (write-through stores drop the lines from L2: those reads come from
+            // beyond it).  Refitted in round 3 to a sweep of 36 shapes at config 4 (tools/gen_shape_sweep.py,
+            // profiles/r03/gen_shape_sweep_config4.txt): round 2's model priced the hand-off six times too cheap and picked
+            // 6-row tiles in 8 slices (0.0405 ms) where 2-row tiles in 3 slices take 0.0322.
+            const double step_cyc = 42.5 * (nx + 1) + 29.0 * rc * nx;
             const long ksteps = (long)p.nd * th;
             const int nq = rc * nx * 4;
             for (int ns = 1; ns <= 16; ++ns) {
@@ -414,8 +419,8 @@ GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes)
                 const long waves = ntile * ns * p.groups;
                 const long rounds = (waves + slots - 1) / slots;
                 const int dpasses = (ns >= p.nd) ? 2 : (p.nd + ns - 1) / ns + (ns > 1 ? 1 : 0);
-                const double per_wave = (double)((ksteps + ns - 1) / ns + rc + 8) * rc * nx * cyc + 2500.0 * dpasses + 6000.0;
-                const double reduce = ns > 1 ? 3000.0 + (double)ns * nq * 35.0 : 0.0;
+                const double per_wave = (double)((ksteps + ns - 1) / ns + rc + 8) * step_cyc + 2500.0 * dpasses + 6000.0;
+                const double reduce = ns > 1 ? 5500.0 + (double)ns * nq * 220.0 : 0.0;
                 const double cost = rounds * per_wave + reduce;
                 if (cost < best_cost * 0.97) { best_cost = cost; best_rc = rc; best_nxb = nx; best_ns = ns; }
             }
