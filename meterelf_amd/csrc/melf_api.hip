@@ -839,7 +839,7 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
             launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], nullptr, ls, true);
         }
         info.rows_per_wave = pl.rb; info.full_waves = pl.na; info.pair_waves = 2 * pl.np;
-        info.waves = pl.nparts * pl.groups;
+        info.waves = pl.nparts * pl.groups; info.tiles = pl.nparts;
         launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], (const uint32_t*)c->d_rsum[bl], d_map, *parts, ls,
                           ev.start, ev.stop);
     } else if (kind == MK_GEN) {
