@@ -29,8 +29,9 @@ frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), NB * n, 2
 stream = torch.cuda.current_stream().cuda_stream
 os.environ['MELF_MATCH'] = 'gen'
 ref = None
-shapes = ['default'] + ['%d,%d,%d' % (rc, nx, ns) for rc in (2, 4, 6, 8) for nx in (1,) for ns in (1, 2, 3, 4, 5, 6, 8, 10, 12)]
-for rep in range(2):
+nxs = (1, 2) if len(sys.argv) > 3 and sys.argv[3] == 'nx2' else (1,)
+shapes = ['default'] + ['%d,%d,%d' % (rc, nx, ns) for rc in (2, 4, 6, 8) for nx in nxs for ns in (1, 2, 3, 4, 5, 6, 8, 10, 12)]
+for rep in range(1 if len(nxs) > 1 else 2):
     for sh in shapes:
         if sh == 'default':
             os.environ.pop('MELF_GEN_SHAPE', None)
