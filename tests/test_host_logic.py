@@ -36,15 +36,16 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / 'layout.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "meterelf_hip.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(melf_params), sizeof(melf_result),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(melf_params), sizeof(melf_result),'
                    'sizeof(melf_dial), offsetof(melf_params, match_threshold), offsetof(melf_params, dial),'
-                   'offsetof(melf_result, pos), offsetof(melf_result, value));return 0;}\n')
+                   'offsetof(melf_result, pos), offsetof(melf_result, value), sizeof(melf_match_info),'
+                   'offsetof(melf_match_info, tiles));return 0;}\n')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     exp = [C.sizeof(_hip.MelfParams), C.sizeof(_hip.MelfResult), C.sizeof(_hip.MelfDial),
            _hip.MelfParams.match_threshold.offset, _hip.MelfParams.dial.offset,
-           _hip.MelfResult.pos.offset, _hip.MelfResult.value.offset]
+           _hip.MelfResult.pos.offset, _hip.MelfResult.value.offset, C.sizeof(_hip.MelfMatchInfo), _hip.MelfMatchInfo.tiles.offset]
     assert got == exp
     assert _hip.RESULT_DTYPE.itemsize == C.sizeof(_hip.MelfResult)
 
