@@ -37,7 +37,7 @@ class MeterImageData(NamedTuple):
 # than the 1024 files of a chunk take to read.  The reference keeps its per-Params state in module-level caches too
 # (meterelf/_image.py:69-81, meterelf/_dial_data.py:11-19, keyed by id(params)); here the key is the calibration itself
 # (digest of the blob = params + template + masks, plus the dial names), so a params.yml edited between two calls gets a
-# new context.  An idle context keeps its device workspaces (about 1 GB after 1024-file chunks of 640 x 480 frames);
+# new context.  An idle context keeps its device workspaces (about 3 GB after 1024-file chunks of 640 x 480 frames);
 # METERELF_CTX_CACHE=0 turns the cache off, release_cached_contexts() empties it.
 _idle_readers: Dict[bytes, MeterReader] = {}
 _idle_lock = threading.Lock()
