@@ -671,7 +671,8 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=200, help='timed steps (default 200 = 60 ms of GPU time: one 1 ms hiccup of the host or the '
+                    'profiler inside a 20-step region is a 17 %% error)')
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=1024, help='frames per GPU per step')
     ap.add_argument('--nbuf', type=int, default=4, help='distinct batches the steps rotate over')
