@@ -10,14 +10,16 @@
 //   B[k][n] = L'_n[y'][32 kb + k]
 // with T' = T - 128 and L' = L - 128 as signed bytes.  The exact u8 correlation follows from
 //   sum T L = sum T' L' + 128 * winsum(L) + 128 * (sum T - 128 N)
-// and window sums come from two tiny exact passes (row sums, sliding column sums).
+// and the window sums are exact too: row-window sums from the prep pass, added up over the template rows by the match waves.
 // 188 useful of every 224 K columns are non-zero (84 % dense); accumulators stay in registers
 // over the whole 119 x 224 K loop, so there is no scatter and no partial-sum traffic.
 //
-// One wave owns R = 5 consecutive output rows x 64 output columns x 32 frames (160 accumulator
-// registers).  At template row i it needs image rows y0+i .. y0+i+4: a sliding window of six
-// register row-buffers (5 live + 1 incoming, rotated by a 6-way unroll), so every image row
-// is fetched once per wave, straight from L2 in B-fragment order (lane * 16 bytes).
+// One wave owns R consecutive output rows x 64 output columns x 32 frames (16 R x 2 accumulator registers).  At template
+// row i it needs image rows y0+i .. y0+i+R-1: a sliding window of R + 1 register row-buffers (R live + 1 incoming, rotated
+// by an (R + 1)-way unroll), so every image row is fetched once per wave, straight from L2 in B-fragment order (lane * 16
+// bytes).  R and the number of waves per frame group follow the batch size (mfma_plan: RB = 2..5 full rows per wave, plus
+// pairs of (RB + 1)-row waves that share a map row), so that one round of ~1024 waves fills the chip from 481 frames up.
+// The window sums of TM_CCOEFF are added up by the same waves from the row-window sums k_prep_lplane leaves (round 3).
 //
 // The operand / result lane maps were verified with exact integer data
 // (tools/ubench/mfma_i8_layout.hip): A lane l = A[l & 31][16 (l >> 5) + j],
