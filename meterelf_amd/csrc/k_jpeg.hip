@@ -315,17 +315,22 @@ struct SegState {
 };
 // First-level lookup of the Huffman kernels, built in LDS by the kernels themselves: four tables (DC 0, DC 1, AC 0,
 // AC 1) of 2^TAB_BITS dwords.  An entry says what the next TAB_BITS bits of the stream start with -- ONE symbol, or
-// TWO when the second code also lies wholly inside the window:
-//   bits  0.. 4  bits1  bits the first symbol occupies, code + magnitude bits (the symbol alone fixes their number)
-//   bits  5..11  adv1   coefficients it advances: DC 1; AC run + 1, ZRL 16, end of block 64 (k leaves the block)
-//   bits 12..16  bits2  bits of both symbols together (0: no second symbol in the entry)
-//   bits 17..23  adv2   coefficients both advance together (64 when the second ends the block)
-//   bits 24..28  len1   code length of the first symbol (bits1 - len1 magnitude bits follow it)
+// TWO when the second code also lies wholly inside the window.  A symbol is the pair (bits it occupies: code +
+// magnitude bits, the symbol alone fixes their number; coefficients it advances: DC 1, AC run + 1, ZRL 16, end of block
+// 64 = k leaves the block), packed so that ONE addition advances the state-only decoder's packed position
+// (bit position in bits 0..15, coefficient index from bit 16):
+//   bits  0.. 4  bits1        bits 16..22  adv1       the first symbol
+//   bits  7..11  bits2        bits 23..29  adv2       both symbols together (adv2 = 64 when the second ends the block);
+//                                                      an entry WITHOUT a second symbol repeats the first here, so that
+//                                                      the decoder need not ask whether there is one
+//   bits 12..15  len1 - 1     code length of the first symbol (bits1 - len1 magnitude bits follow it)
 // 0: the first code is longer than the window (canonical decode from `slow`, rare).
 // The second symbol of a DC entry is the block's first AC symbol, decoded with the AC table that goes with that DC
-// table (McuLayout::pair_bits says for which blocks of the MCU that pairing holds).  The coefficient-writing decoder
-// reads the first symbol only; the state-only decoder of the speculative pass and of the synchronisation rounds takes
-// both: a flat block (DC difference + end of block, 4-6 bits) is one step, most short AC symbols go two at a time.
+// table; a DC table whose blocks do not all use that AC table gets no second symbols (McuLayout::pair_dc).  The
+// coefficient-writing decoder reads the first symbol only; the state-only decoder of the speculative pass and of the
+// synchronisation rounds takes both: a flat block (DC difference + end of block, 4-6 bits) is one step, most short AC
+// symbols go two at a time.
+constexpr uint32_t SYM_MASK = 0x007f001fu;  // bits | adv << 16 of the first symbol; the second sits 7 bits higher
 constexpr int TAB_BITS = 10;
 constexpr uint32_t TAB_MASK = (1u << TAB_BITS) - 1u;
 
@@ -343,7 +348,9 @@ struct McuWindow {  // the same in MCUs of one image
 
 struct McuLayout {
     uint32_t dc_bits, ac_bits, comp_bits;
-    uint32_t pair_bits;  // per block: its AC table is the one the DC entries' second symbols were decoded with
+    uint32_t tsel5;      // per block, 5 bits: DC table id | (2 + AC table id) << 2 (the state-only decoder's table choice)
+    uint32_t nxt5;       // per block, 5 bits: 5 * index of the block that follows it in the MCU
+    uint32_t pair_dc;    // bit t: every block with DC table t uses the AC table its entries' second symbols come from
     int ac_of_dc0, ac_of_dc1;  // that AC table, per DC table
     int bpm, yblocks;
 };
@@ -354,7 +361,8 @@ __device__ __forceinline__ McuLayout jpeg_mcu_layout(const JpegImageDev* R)
     McuLayout L;
     L.yblocks = ncomp == 1 ? 1 : R->hs0 * R->vs0;
     L.bpm = ncomp == 1 ? 1 : L.yblocks + 2;
-    L.dc_bits = L.ac_bits = L.comp_bits = L.pair_bits = 0;
+    L.dc_bits = L.ac_bits = L.comp_bits = L.tsel5 = L.nxt5 = 0;
+    L.pair_dc = 3;
     int a0 = -1, a1 = -1;
     for (int b = 0; b < L.bpm; ++b) {
         const int c = b < L.yblocks ? 0 : 1 + b - L.yblocks;
@@ -362,21 +370,24 @@ __device__ __forceinline__ McuLayout jpeg_mcu_layout(const JpegImageDev* R)
         L.dc_bits |= (uint32_t)td << b;
         L.ac_bits |= (uint32_t)ta << b;
         L.comp_bits |= (uint32_t)c << (2 * b);
+        L.tsel5 |= ((uint32_t)td | (2u + (uint32_t)ta) << 2) << (5 * b);
+        L.nxt5 |= (uint32_t)(5 * (b + 1 == L.bpm ? 0 : b + 1)) << (5 * b);
         if (td == 0 && a0 < 0) a0 = ta;
         if (td == 1 && a1 < 0) a1 = ta;
-        L.pair_bits |= (uint32_t)((td == 0 ? a0 : a1) == ta ? 1 : 0) << b;
+        if ((td == 0 ? a0 : a1) != ta) L.pair_dc &= ~(1u << td);
     }
     L.ac_of_dc0 = a0 < 0 ? 0 : a0;
     L.ac_of_dc1 = a1 < 0 ? 0 : a1;
     return L;
 }
 
-// bits1 | adv1 << 5 | len1 << 24 of a symbol
+// the entry of a single symbol (the second-symbol fields repeat it)
 __device__ __forceinline__ uint32_t huff_step(const bool dc, const int len, const int sym)
 {
     const int sbits = sym & 15, run = sym >> 4;
     const int adv = dc ? 1 : (sbits ? run + 1 : (run == 15 ? 16 : 64));
-    return (uint32_t)(len + sbits) | (uint32_t)adv << 5 | (uint32_t)len << 24;
+    const uint32_t one = (uint32_t)(len + sbits) | (uint32_t)adv << 16;
+    return one | one << 7 | (uint32_t)(len - 1) << 12;
 }
 
 // Canonical decode of the code at the top of the nb-bit window x, looking at its first `avail` bits only: the symbol's
@@ -401,13 +412,14 @@ __device__ __forceinline__ void jpeg_build_tables(uint32_t* __restrict__ tab, co
         const bool dc = t < 2;
         const uint32_t x = (uint32_t)i & TAB_MASK;
         uint32_t e = huff_window_step<TAB_BITS>(slow + t * SLOW_DW, dc, x, TAB_BITS);
-        const int bits1 = (int)(e & 31u), adv1 = (int)((e >> 5) & 127u);
-        if (e && adv1 != 64 && bits1 < TAB_BITS) {  // a second code may lie wholly inside the window
+        const int bits1 = (int)(e & 31u), adv1 = (int)((e >> 16) & 127u);
+        if (e && adv1 != 64 && bits1 < TAB_BITS && (!dc || ((L.pair_dc >> t) & 1u))) {  // a second code may lie wholly inside the window
             const int t2 = dc ? 2 + (t == 0 ? L.ac_of_dc0 : L.ac_of_dc1) : t;
             const uint32_t e2 = huff_window_step<TAB_BITS>(slow + t2 * SLOW_DW, false, (x << bits1) & TAB_MASK, TAB_BITS - bits1);
             if (e2) {
-                const int a2 = (int)((e2 >> 5) & 127u);
-                e |= (uint32_t)(bits1 + (int)(e2 & 31u)) << 12 | (uint32_t)(a2 == 64 ? 64 : adv1 + a2) << 17;
+                const int a2 = (int)((e2 >> 16) & 127u);
+                const uint32_t both = (uint32_t)(bits1 + (int)(e2 & 31u)) | (uint32_t)(a2 == 64 ? 64 : adv1 + a2) << 16;
+                e = (e & ~(SYM_MASK << 7)) | both << 7;
             }
         }
         tab[i] = e;
@@ -433,35 +445,42 @@ __device__ __forceinline__ uint32_t huff_long_step(const uint32_t* __restrict__ 
     return huff_step(dc, len, sym);
 }
 
-// One segment, symbol by symbol, writing the coefficients of the blocks inside the window.
+// Where the coefficients of block `blk` of MCU (mx, my) live, or NULL outside the window (such blocks are decoded --
+// the DC predictors need them -- but not stored).
+struct CoefPlanes {
+    int16_t *c0, *c1, *c2;
+    int hs0, vs0, bxs0, bxs1, yblocks;
+    McuWindow mw;
+};
+__device__ __forceinline__ int16_t* coef_block_ptr(const CoefPlanes& cp, const int mx, const int my, const int blk)
+{
+    if (mx < cp.mw.mx0 || mx >= cp.mw.mx1 || my < cp.mw.my0 || my >= cp.mw.my1) return nullptr;
+    if (blk < cp.yblocks) {
+        const int sub_y = blk >= cp.hs0 ? 1 : 0;
+        return cp.c0 + (size_t)((my * cp.vs0 + sub_y) * cp.bxs0 + mx * cp.hs0 + (blk - sub_y * cp.hs0)) * 64;
+    }
+    return (blk == cp.yblocks ? cp.c1 : cp.c2) + (size_t)(my * cp.bxs1 + mx) * 64;
+}
+
+// One segment, symbol by symbol, writing the coefficients of the blocks inside the window.  pred0..2: the DC predictors
+// at the segment's entry (in), at its exit (out); ndc: DC symbols decoded.
 __device__ __forceinline__ void jpeg_decode_segment(
     const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow,
     const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk,
-    int nb, const int total_blocks, int pred0, int pred1, int pred2, const int hs0, const int vs0, const int mcus_x,
-    const int bxs0, const int bxs1, int16_t* __restrict__ c0, int16_t* __restrict__ c1, int16_t* __restrict__ c2, int& bad,
-    const McuWindow mw = McuWindow{0, 1 << 30, 0, 1 << 30})
+    int nb, const int total_blocks, int& pred0, int& pred1, int& pred2, int& ndc, const int mcus_x, const CoefPlanes& cp, int& bad)
 {
     uint32_t p = s.p;
     int blk = s.blk, k = s.k;
     int mx = 0, my = 0;
-    int16_t* cb = nullptr;
-    auto block_ptr = [&]() {
-        if (mx < mw.mx0 || mx >= mw.mx1 || my < mw.my0 || my >= mw.my1) {
-            cb = nullptr;  // outside the window: decoded (the DC predictors need it) but not stored
-        } else if (blk < L.yblocks) {
-            const int sub_y = blk >= hs0 ? 1 : 0;
-            cb = c0 + (size_t)((my * vs0 + sub_y) * bxs0 + mx * hs0 + (blk - sub_y * hs0)) * 64;
-        } else {
-            cb = (blk == L.yblocks ? c1 : c2) + (size_t)(my * bxs1 + mx) * 64;
-        }
-    };
     {
         const int mcu = nb / L.bpm;
         my = mcu / mcus_x;
         mx = mcu - my * mcus_x;
-        block_ptr();
     }
+    int16_t* cb = coef_block_ptr(cp, mx, my, blk);
     nblk = 0;
+    ndc = 0;
+    int a0 = pred0, a1 = pred1, a2 = pred2;
     // bit buffer over the scan in global memory (dwords in file byte order): the top `bitcnt` bits are valid
     uint32_t di = (p >> 5) + 2;
     uint64_t bitbuf = (((uint64_t)__builtin_bswap32(W[di - 2]) << 32) | __builtin_bswap32(W[di - 1])) << (p & 31u);
@@ -481,7 +500,7 @@ __device__ __forceinline__ void jpeg_decode_segment(
             e = huff_long_step(slow + t * SLOW_DW, isdc, w, invalid);
             if (invalid) bad = 1;
         }
-        const int used = (int)(e & 31u), adv = (int)((e >> 5) & 127u), sbits = used - (int)((e >> 24) & 31u);
+        const int used = (int)(e & 31u), adv = (int)((e >> 16) & 127u), sbits = used - 1 - (int)((e >> 12) & 15u);
         const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - used, sbits);  // width 0 -> 0
         const int half = (1 << sbits) >> 1;
         const int v = raw < half ? raw - 2 * half + 1 : raw;  // EXTEND (F.2.2.1); sbits = 0 -> 0
@@ -490,9 +509,11 @@ __device__ __forceinline__ void jpeg_decode_segment(
         bitcnt -= used;
         if (isdc) {
             const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
-            int pr;
-            if (comp == 0) pr = (pred0 += v); else if (comp == 1) pr = (pred1 += v); else pr = (pred2 += v);
-            if (cb) cb[0] = (int16_t)pr;
+            a0 += comp == 0 ? v : 0;
+            a1 += comp == 1 ? v : 0;
+            a2 += comp == 2 ? v : 0;
+            if (cb) cb[0] = (int16_t)(comp == 0 ? a0 : comp == 1 ? a1 : a2);
+            ++ndc;
         } else {
             const int pos = k + adv - 1;  // run zeros, then this coefficient
             if (sbits && pos < 64 && cb) cb[nat[pos]] = (int16_t)v;
@@ -506,69 +527,84 @@ __device__ __forceinline__ void jpeg_decode_segment(
                 if (++mx == mcus_x) { mx = 0; ++my; }
             }
             ++nb;
-            block_ptr();
+            cb = coef_block_ptr(cp, mx, my, blk);
         }
     }
     s.p = p; s.blk = blk; s.k = k;
+    pred0 = a0; pred1 = a1; pred2 = a2;
 }
 
-// What a segment's decode does to the decoder state, without the coefficients: exit state, blocks completed, DC
-// differences summed per component.  The same walk as jpeg_decode_segment (same tables, same treatment of impossible
-// codes, same stop at p_end; the second symbol of an entry is taken only where the one-at-a-time decoder would decode
-// it next: same block, before p_end), so a segment entered in the true state leaves in the true state.
+// What a segment's decode does to the decoder STATE, without coefficients or DC values: exit state and blocks completed.
+// The same walk as jpeg_decode_segment (same tables, same treatment of impossible codes, same stop at p_end; the second
+// symbol of an entry is taken only where the one-at-a-time decoder would decode it next: same block, before p_end), so a
+// segment entered in the true state leaves in the true state.
+// The synchronisation rounds are a chain of dependent steps of ONE wave, and a lone wave pays ~6 cycles per instruction
+// whatever it is, ~20 more per VALU -> SALU -> VALU hop, 20-55 per branch (tools/ubench/wave_latency.hip): what counts
+// is the number of instructions per step.  Hence: no data-dependent branches but the rare long code; bit position
+// (relative to `base`, 16 bits) and coefficient index packed into one register X that an entry's symbol advances with one
+// addition; both conditions for the second symbol from one packed 16-bit subtraction; the stream as three byte-swapped
+// dwords d0 d1 d2 that rotate when the position crosses a dword, the dword after them requested a step ahead; table
+// id and next block from 5-bit-per-block lookup words in scalar registers.  No DC values here: the output pass sums
+// them per segment and a fix-up adds the predictors (k_jpeg_huff).
+typedef short melf_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void jpeg_state_segment(
     const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow, const McuLayout L,
-    SegState& s, const uint32_t p_end, int& nblk, int64_t& dsum, int* diag = nullptr)
+    SegState& s, const uint32_t p_end, int& nblk, int* diag = nullptr)
 {
-    uint32_t p = s.p;
-    int blk = s.blk, k = s.k;
-    nblk = 0;
-    dsum = 0;
-    uint32_t di = (p >> 5) + 2;
-    uint64_t bitbuf = (((uint64_t)__builtin_bswap32(W[di - 2]) << 32) | __builtin_bswap32(W[di - 1])) << (p & 31u);
-    int bitcnt = 64 - (int)(p & 31u);
-    while (p < p_end) {
-        if (bitcnt < 32) {
-            bitbuf |= (uint64_t)__builtin_bswap32(W[di++]) << (32 - bitcnt);
-            bitcnt += 32;
-        }
-        const uint32_t w = (uint32_t)(bitbuf >> 32);
-        const bool isdc = k == 0;
-        const uint32_t t = isdc ? (L.dc_bits >> blk) & 1u : 2u + ((L.ac_bits >> blk) & 1u);
-        uint32_t e = tab[(t << TAB_BITS) + (w >> (32 - TAB_BITS))];
+    const uint32_t base = s.p & ~31u;
+    const uint32_t* __restrict__ Wp = W + (base >> 5);
+    uint32_t X = (s.p - base) | (uint32_t)s.k << 16;           // position | coefficient index << 16
+    uint32_t Xs = X << 27;                                      // the position's low five bits on top: their carry = "next dword"
+    const uint32_t C = (p_end - base) | 64u << 16;             // their limits (p_end - base < 32768: checked by the kernel)
+    uint32_t bs = 5u * (uint32_t)s.blk;
+    int nb = 0;
+    uint32_t d0 = __builtin_bswap32(Wp[0]), d1 = __builtin_bswap32(Wp[1]), d2 = __builtin_bswap32(Wp[2]);
+    uint32_t off = 3;
+    uint32_t nraw = Wp[3];
+    uint32_t t = __builtin_amdgcn_ubfe(L.tsel5, bs + (s.k == 0 ? 0u : 2u), 2);
+    uint32_t b0 = (uint32_t)(((((uint64_t)d0 << 32) | d1) << (Xs >> 27)) >> 32);
+    while ((X & 0xffffu) < (C & 0xffffu)) {
+        uint32_t e = tab[__builtin_amdgcn_alignbit(t, b0, 32 - TAB_BITS)];  // (t << TAB_BITS) | (b0 >> (32 - TAB_BITS))
 #ifdef MELF_JPEG_ROUNDS
         if (diag) ++diag[0];
 #endif
-        if (!e) {
-            bool invalid = false;
-            e = huff_long_step(slow + t * SLOW_DW, isdc, w, invalid);
+        if (__builtin_amdgcn_uicmp(e, 0u, 32 /* == */) != 0ull) {  // some lane met a long code (one compare + scalar branch)
+            asm volatile("");  // keeps the compiler from folding the two conditions into one divergent branch
+            if (e == 0u) {
+                bool invalid = false;
+                e = huff_long_step(slow + t * SLOW_DW, (X >> 16) == 0u, b0, invalid);
+            }
         }
-        const int bits1 = (int)(e & 31u), adv1 = (int)((e >> 5) & 127u), bits2 = (int)((e >> 12) & 31u), adv2 = (int)((e >> 17) & 127u);
-        if (isdc) {  // the value is needed: DC predictors of the segments behind this one
-            const int sbits = bits1 - (int)((e >> 24) & 31u);
-            const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - bits1, sbits);
-            const int half = (1 << sbits) >> 1;
-            const int v = raw < half ? raw - 2 * half + 1 : raw;
-            const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
-            dsum += (int64_t)v << (16 * comp);  // three 16-bit lanes, separated again after the scan
-        }
-        const bool pair_ok = !isdc || ((L.pair_bits >> blk) & 1u);
-        const bool two = bits2 != 0 && pair_ok && k + adv1 < 64 && p + (uint32_t)bits1 < p_end;
+        const uint32_t sym1 = e & SYM_MASK, sym2 = (e >> 7) & SYM_MASK;
+        const uint32_t Y = X + sym1;  // after the first symbol
+        const melf_s16x2 z = __builtin_bit_cast(melf_s16x2, Y) - __builtin_bit_cast(melf_s16x2, C);
+        // both still inside: position < p_end and coefficient index < 64 -> the second symbol is the decoder's next
+        const bool two = (__builtin_bit_cast(uint32_t, z) & 0x80008000u) == 0x80008000u;
 #ifdef MELF_JPEG_ROUNDS
-        if (diag && two) ++diag[1];
+        if (diag && two && sym1 != sym2) ++diag[1];
 #endif
-        const int used = two ? bits2 : bits1;
-        k += two ? adv2 : adv1;
-        p += (uint32_t)used;
-        bitbuf <<= used;
-        bitcnt -= used;
-        if (k >= 64) {
-            k = 0;
-            ++nblk;
-            if (++blk == L.bpm) blk = 0;
-        }
+        const uint32_t sel = two ? sym2 : sym1;
+        uint32_t Xn = X + sel;
+        const bool rot = __builtin_uadd_overflow(Xs, sel << 27, &Xs);  // crossed into the next dword (a step consumes < 32 bits)
+        d0 = rot ? d1 : d0;
+        d1 = rot ? d2 : d1;
+        d2 = rot ? __builtin_bswap32(nraw) : d2;
+        off += rot ? 1u : 0u;
+        nraw = Wp[off];  // requested here, consumed a whole step later (an L1 hit takes most of a step)
+        __builtin_amdgcn_sched_barrier(0);
+        const bool end = Xn >= (64u << 16);       // the block is complete
+        Xn = end ? (Xn & 0xffffu) : Xn;
+        nb += end ? 1 : 0;
+        const uint32_t nxt = __builtin_amdgcn_ubfe(L.nxt5, bs, 5);
+        bs = end ? nxt : bs;
+        t = __builtin_amdgcn_ubfe(L.tsel5, bs + (end ? 0u : 2u), 2);
+        X = Xn;
+        b0 = (uint32_t)(((((uint64_t)d0 << 32) | d1) << (Xs >> 27)) >> 32);
     }
-    s.p = p; s.blk = blk; s.k = k;
+    s.p = base + (X & 0xffffu);
+    s.k = (int)(X >> 16);
+    s.blk = (int)((bs * 13u) >> 6);  // bs / 5 for bs <= 25
+    nblk = nb;
 }
 
 // the three 16-bit lanes of a packed DC-difference sum (each true sum fits: it is a difference of two DC values)
@@ -582,7 +618,7 @@ __device__ __forceinline__ void unpack_dsum(int64_t d, int& a, int& b, int& c)
 }
 
 #ifdef MELF_JPEG_ROUNDS
-__device__ uint64_t g_jpeg_stamps[8 * 8192];  // per image: start, tables built, round 0 done, rounds done, scan done, end
+__device__ uint64_t g_jpeg_stamps[8 * 8192];  // per image: start, tables built, round 0 done, rounds done, scan done, output pass done, end
 extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_stamps(uint64_t* out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jpeg_stamps), sizeof(uint64_t) * 8 * (size_t)(n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1;
@@ -642,7 +678,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     __shared__ uint32_t e_p[T], e_s[T];  // exit state of each segment: bit position, blk << 8 | k
     __shared__ uint32_t n_p[T], n_s[T];  // entry state its last decode started from
     __shared__ int sc_n[T];              // blocks completed in the segment (then: prefix sums)
-    __shared__ int64_t sc_d[T];          // packed DC-difference sums (then: prefix sums)
+    __shared__ int64_t sc_d[T];          // packed DC-difference sums of the output pass (then: prefix sums)
     __shared__ uint16_t todo[T];         // segments to decode again this round, compacted
     __shared__ int wcount[T / 64];
 #ifdef MELF_JPEG_ROUNDS
@@ -661,6 +697,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     // different LDS banks
     const uint32_t S = 32u * (max(8u, (bits + 32u * T - 1) / (32u * T)) | 1u);
     const int nseg = (int)((bits + S - 1) / S);
+    if (S > 32000u) {  // the state-only decoder keeps positions inside a segment in 16 bits (host: a larger T, or its own decoder)
+        if (tid == 0) status[img] = 2;
+        return;
+    }
     {
         const uint32_t* ssrc = (const uint32_t*)(g_slow + (size_t)img * 4);
         for (int i = tid; i < 4 * SLOW_DW; i += T) slow[i] = ssrc[i];
@@ -669,12 +709,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     __syncthreads();
     const McuLayout L = jpeg_mcu_layout(R);
     jpeg_build_tables<T>(tab, slow, L, tid);
-    const int hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
+    const int mcus_x = R->mcus_x;
     const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
-    const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
-    int16_t* c0 = coefs + (size_t)R->coef_blk[0] * 64;
-    int16_t* c1 = coefs + (size_t)R->coef_blk[1] * 64;
-    int16_t* c2 = coefs + (size_t)R->coef_blk[2] * 64;
+    const CoefPlanes cp = {coefs + (size_t)R->coef_blk[0] * 64, coefs + (size_t)R->coef_blk[1] * 64, coefs + (size_t)R->coef_blk[2] * 64,
+                           R->hs0, R->vs0, R->blocks_x[0], R->blocks_x[1], L.yblocks, mwin};
     __syncthreads();
 
     JSTAMP(1);
@@ -687,14 +725,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     {
         SegState ex = {(uint32_t)tid * S, 0, 0};
         int nblk = 0;
-        int64_t dsum = 0;
-        if (mine) jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(tid + 1) * S, bits + 32u), nblk, dsum);
+        if (mine) jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(tid + 1) * S, bits + 32u), nblk);
         n_p[tid] = (uint32_t)tid * S;  // entry of the last decode
         n_s[tid] = 0;
         e_p[tid] = ex.p;
         e_s[tid] = (uint32_t)(ex.blk << 8 | ex.k);
         sc_n[tid] = mine ? nblk : 0;
-        sc_d[tid] = mine ? dsum : 0;
     }
     __syncthreads();
     JSTAMP(2);
@@ -736,20 +772,18 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
             ++redone;
             SegState ex = {n_p[i], (int)(n_s[i] >> 8), (int)(n_s[i] & 255u)};
             int nblk;
-            int64_t dsum;
 #ifdef MELF_JPEG_ROUNDS
             int diag[2] = {0, 0};
-            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, dsum, diag);
+            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, diag);
             atomicMax(&s_diag[0], diag[0]);
             atomicAdd(&s_diag[1], diag[0]);
             atomicAdd(&s_diag[2], diag[1]);
 #else
-            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, dsum);
+            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk);
 #endif
             e_p[i] = ex.p;  // nobody reads exit states before the next barrier
             e_s[i] = (uint32_t)(ex.blk << 8 | ex.k);
             sc_n[i] = nblk;
-            sc_d[i] = dsum;
         }
         __syncthreads();
 #ifdef MELF_JPEG_ROUNDS
@@ -764,34 +798,74 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
 #endif
     }
     JSTAMP(3);
-    // exclusive prefix over the segments: blocks completed, packed DC differences per component
+    // exclusive prefix over the segments: blocks completed
     const int nblk = sc_n[tid];
-    const int64_t dsum = sc_d[tid];
     const SegState entry = {n_p[tid], (int)(n_s[tid] >> 8), (int)(n_s[tid] & 255u)};
     const uint32_t p_end = min((uint32_t)(tid + 1) * S, bits + 32u);
     __syncthreads();
     for (int off = 1; off < T; off <<= 1) {
         const int a = tid >= off ? sc_n[tid - off] : 0;
-        const int64_t b = tid >= off ? sc_d[tid - off] : 0;
         __syncthreads();
         sc_n[tid] += a;
-        sc_d[tid] += b;
         __syncthreads();
     }
     JSTAMP(4);
     const int done_blocks = sc_n[T - 1];
     const int nb_in = sc_n[tid] - (mine ? nblk : 0);
-    int p0, p1, p2;
-    unpack_dsum(sc_d[tid] - (mine ? dsum : 0), p0, p1, p2);
-    if (mine && nb_in < total_blocks) {
+    // output pass: every segment from its true entry state and first block, DC predictors starting at ZERO -- the DC
+    // coefficients it stores are sums of the segment's own differences; what they lack is known only after a prefix sum
+    // over the segments of those sums (three 16-bit lanes of one 64-bit word), and a fix-up pass adds it
+    const bool ran = mine && nb_in < total_blocks;
+    int q0 = 0, q1 = 0, q2 = 0, ndc = 0;
+    if (ran) {
         if (entry.blk != nb_in % L.bpm) bad = 1;  // the propagated state and the block count disagree: corrupt stream
         SegState st = entry;
         int n2;
-        jpeg_decode_segment(W, tab, slow, nat, L, st, p_end, n2, nb_in, total_blocks, p0, p1, p2, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2,
-                            bad, mwin);
+        jpeg_decode_segment(W, tab, slow, nat, L, st, p_end, n2, nb_in, total_blocks, q0, q1, q2, ndc, mcus_x, cp, bad);
+    }
+    const int64_t dsum = (int64_t)q0 + ((int64_t)q1 << 16) + ((int64_t)q2 << 32);
+    sc_d[tid] = dsum;
+    __syncthreads();
+    JSTAMP(5);
+    for (int off = 1; off < T; off <<= 1) {
+        const int64_t b = tid >= off ? sc_d[tid - off] : 0;
+        __syncthreads();
+        sc_d[tid] += b;
+        __syncthreads();
+    }
+    if (ran && ndc > 0) {
+        int pr0, pr1, pr2;
+        unpack_dsum(sc_d[tid] - dsum, pr0, pr1, pr2);  // the predictors at the segment's entry
+        if ((pr0 | pr1 | pr2) != 0) {
+            // the blocks whose DC symbol this segment decoded: from the first block that BEGINS here
+            const int b0 = nb_in + (entry.k != 0 ? 1 : 0);
+            const int mcu = b0 / L.bpm;
+            int blk = b0 - mcu * L.bpm, my = mcu / mcus_x, mx = mcu - (mcu / mcus_x) * mcus_x;
+            // four blocks at a time: their loads are in flight together (a load that follows the lane's own store misses L1)
+            for (int i = 0; i < ndc; i += 4) {
+                int16_t* cb[4];
+                int add[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cb[u] = i + u < ndc ? coef_block_ptr(cp, mx, my, blk) : nullptr;
+                    const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
+                    add[u] = comp == 0 ? pr0 : comp == 1 ? pr1 : pr2;
+                    if (++blk == L.bpm) {
+                        blk = 0;
+                        if (++mx == mcus_x) { mx = 0; ++my; }
+                    }
+                }
+                int16_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = cb[u] ? cb[u][0] : (int16_t)0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (cb[u]) cb[u][0] = (int16_t)(v[u] + add[u]);
+            }
+        }
     }
     const int anybad = __syncthreads_or(bad);
-    JSTAMP(5);
+    JSTAMP(6);
 #ifdef MELF_JPEG_ROUNDS  // diagnostic build: rounds and re-decoded segments per image (tools/jpeg_rounds.py)
     {
         __shared__ int s_redone;
@@ -833,23 +907,21 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
     __syncthreads();
     const McuLayout L = jpeg_mcu_layout(R);
     jpeg_build_tables<T>(tab, slow, L, tid);
-    const int hs0 = R->hs0, vs0 = R->vs0, mcus_x = R->mcus_x;
+    const int mcus_x = R->mcus_x;
     const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
     const int per_interval = (int)R->restart_interval * L.bpm;
     const int nint = (int)R->rst_cnt;
     const int expected = (total_blocks + per_interval - 1) / per_interval;
     const uint32_t bits = R->scan_len * 8u;
-    const int bxs0 = R->blocks_x[0], bxs1 = R->blocks_x[1];
-    int16_t* c0 = coefs + (size_t)R->coef_blk[0] * 64;
-    int16_t* c1 = coefs + (size_t)R->coef_blk[1] * 64;
-    int16_t* c2 = coefs + (size_t)R->coef_blk[2] * 64;
+    const CoefPlanes cp = {coefs + (size_t)R->coef_blk[0] * 64, coefs + (size_t)R->coef_blk[1] * 64, coefs + (size_t)R->coef_blk[2] * 64,
+                           R->hs0, R->vs0, R->blocks_x[0], R->blocks_x[1], L.yblocks, mwin};
     __syncthreads();
     int bad = nint != expected ? 1 : 0;  // markers missing or surplus: corrupt stream
     for (int it = tid; it < min(nint, expected); it += T) {
         SegState st = {rst[it] * 8u, 0, 0};
         const int nb0 = it * per_interval, nb1 = min(nb0 + per_interval, total_blocks);
-        int n2;
-        jpeg_decode_segment(W, tab, slow, nat, L, st, bits + 32u, n2, nb0, nb1, 0, 0, 0, hs0, vs0, mcus_x, bxs0, bxs1, c0, c1, c2, bad, mwin);
+        int n2, ndc, q0 = 0, q1 = 0, q2 = 0;  // every interval starts with zero predictors
+        jpeg_decode_segment(W, tab, slow, nat, L, st, bits + 32u, n2, nb0, nb1, q0, q1, q2, ndc, mcus_x, cp, bad);
         if (n2 < nb1 - nb0) bad = 1;  // ran out of data before the interval's last block
     }
     const int anybad = __syncthreads_or(bad);

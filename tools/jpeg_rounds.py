@@ -41,13 +41,24 @@ print('  histogram of rounds:', dict(zip(*np.unique(rounds, return_counts=True))
 n2 = min(n, 8192)
 stamps = np.zeros((n2, 8), np.uint64)
 assert L.melf_debug_jpeg_stamps(stamps.ctypes.data_as(C.c_void_p), n2) == 0
-t = stamps[:, :6].astype(np.float64)
-names = ['zero window + tables', 'round 0 (speculative decode)', 'synchronisation rounds', 'prefix scan', 'output pass']
-tot = t[:, 5] - t[:, 0]
+t = stamps[:, :7].astype(np.float64)
+names = ['zero window + tables', 'round 0 (speculative decode)', 'synchronisation rounds', 'prefix scan', 'output pass', 'DC prefix scan + fix-up']
+tot = t[:, 6] - t[:, 0]
 print('cycles per workgroup: median %.0f max %.0f' % (np.median(tot), tot.max()))
-for k in range(5):
+for k in range(6):
     dlt = t[:, k + 1] - t[:, k]
     print('  %-30s median %8.0f (%4.1f %%)  max %8.0f' % (names[k], np.median(dlt), 100 * np.median(dlt) / np.median(tot), dlt.max()))
+
+# the kernel ends with its slowest workgroup: which images are those?
+order = np.argsort(-tot)[:6]
+print('  slowest workgroups (image: cycles | per phase | rounds | file bytes):')
+for i in order:
+    print('    %4d: %8.0f | %s | %2d rounds | %6d B' % (i, tot[i], ' '.join('%7.0f' % (t[i, k + 1] - t[i, k]) for k in range(6)), rounds[i] if i < len(rounds) else -1, len(blobs[i])))
+sizes_b = np.array([len(b) for b in blobs[:n2]], dtype=np.float64)
+valid = tot > 0
+if valid.sum() > 2:
+    print('  correlation of a workgroup\'s cycles with: file size %.2f, rounds %.2f' % (np.corrcoef(tot[valid], sizes_b[valid])[0, 1], np.corrcoef(tot[valid], rounds[:n2][valid])[0, 1]))
+    print('  cycles: p50 %.0f p90 %.0f p99 %.0f max %.0f' % tuple(np.percentile(tot[valid], [50, 90, 99, 100])))
 
 if hasattr(L, 'melf_debug_jpeg_round_log'):
     log = np.zeros((8, 32, 5), np.uint32)
