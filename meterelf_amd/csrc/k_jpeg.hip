@@ -324,7 +324,11 @@ struct SegState {
 //                                                      an entry WITHOUT a second symbol repeats the first here, so that
 //                                                      the decoder need not ask whether there is one
 //   bits 12..15  len1 - 1     code length of the first symbol (bits1 - len1 magnitude bits follow it)
-// 0: the first code is longer than the window (canonical decode from `slow`, rare).
+// Bit 31 set: the first code is longer than the window.  For the AC tables the entry then carries (bits 0..11) where
+// the window's 2^6 continuations start in `longtab`, a direct table over the 16-bit windows that begin with a long code
+// (LONG_N of them per AC table; their Kraft sum is small: 319 for the standard tables); bit 30: not covered (a DC table,
+// or a code set with more long-code space) -- canonical compares from `slow`.  A full wave meets a long code in most of
+// its steps, so what it costs is paid by every step: one more lookup instead of ~40 instructions.
 // The second symbol of a DC entry is the block's first AC symbol, decoded with the AC table that goes with that DC
 // table; a DC table whose blocks do not all use that AC table gets no second symbols (McuLayout::pair_dc).  The
 // coefficient-writing decoder reads the first symbol only; the state-only decoder of the speculative pass and of the
@@ -332,6 +336,7 @@ struct SegState {
 // symbols go two at a time.
 constexpr uint32_t SYM_MASK = 0x007f001fu;  // bits | adv << 16 of the first symbol; the second sits 7 bits higher
 constexpr int TAB_BITS = 10;
+constexpr int LONG_N = 512;  // entries of the long-code table per AC table
 constexpr uint32_t TAB_MASK = (1u << TAB_BITS) - 1u;
 
 // Per-MCU-position tables packed into registers: 1 bit of DC table id, 1 bit of AC table id and 2 bits
@@ -403,9 +408,12 @@ __device__ __forceinline__ uint32_t huff_window_step(const uint32_t* __restrict_
     return huff_step(dc, len, ((const uint8_t*)(sl + 32))[idx & 255]);
 }
 
-// The four tables, by all T threads of the workgroup (slow[] complete; a barrier must follow).
+__device__ __forceinline__ uint32_t huff_long_step(const uint32_t* __restrict__ sl, const bool dc, const uint32_t w, bool& invalid);
+
+// The four tables and the long-code table, by all T threads of the workgroup (slow[] complete; a barrier must follow).
 template <int T>
-__device__ __forceinline__ void jpeg_build_tables(uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow, const McuLayout L, const int tid)
+__device__ __forceinline__ void jpeg_build_tables(uint32_t* __restrict__ tab, uint32_t* __restrict__ longtab, const uint32_t* __restrict__ slow,
+                                                  const McuLayout L, const int tid)
 {
     for (int i = tid; i < (4 << TAB_BITS); i += T) {
         const int t = i >> TAB_BITS;
@@ -422,7 +430,23 @@ __device__ __forceinline__ void jpeg_build_tables(uint32_t* __restrict__ tab, co
                 e = (e & ~(SYM_MASK << 7)) | both << 7;
             }
         }
+        if (!e) {  // a long code: where its 16-bit windows start in longtab, if they are there
+            const uint32_t first = slow[t * SLOW_DW + TAB_BITS - 1] << (16 - TAB_BITS);  // the first 16-bit window with a long code
+            const uint32_t off = (x << (16 - TAB_BITS)) - first;
+            e = (!dc && off + (1u << (16 - TAB_BITS)) <= (uint32_t)LONG_N) ? 0x80000000u | ((uint32_t)(t - 2) * LONG_N + off) : 0xC0000000u;
+        }
         tab[i] = e;
+    }
+    for (int i = tid; i < 2 * LONG_N; i += T) {
+        const uint32_t* sl = slow + (2 + i / LONG_N) * SLOW_DW;
+        const uint32_t w16 = (sl[TAB_BITS - 1] << (16 - TAB_BITS)) + (uint32_t)(i % LONG_N);
+        uint32_t e = 0;
+        if (w16 <= 0xffffu) {
+            bool invalid = false;
+            e = huff_long_step(sl, false, w16 << 16, invalid);
+            if (invalid) e |= 0x80000000u;
+        }
+        longtab[i] = e;
     }
 }
 
@@ -445,6 +469,19 @@ __device__ __forceinline__ uint32_t huff_long_step(const uint32_t* __restrict__ 
     return huff_step(dc, len, sym);
 }
 
+// An entry with bit 31 set: the first symbol's code is longer than the window (w: the next 32 bits).  Returns the
+// symbol's entry; bit 31 of the result: no code at all (see huff_long_step).
+__device__ __forceinline__ uint32_t huff_long_entry(const uint32_t e, const uint32_t* __restrict__ longtab, const uint32_t* __restrict__ slow,
+                                                    const uint32_t t, const bool dc, const uint32_t w)
+{
+    if (e & 0x40000000u) {
+        bool invalid = false;
+        const uint32_t r = huff_long_step(slow + t * SLOW_DW, dc, w, invalid);
+        return invalid ? r | 0x80000000u : r;
+    }
+    return longtab[(e & 0xfffu) + ((w >> 16) & ((1u << (16 - TAB_BITS)) - 1u))];
+}
+
 // Where the coefficients of block `blk` of MCU (mx, my) live, or NULL outside the window (such blocks are decoded --
 // the DC predictors need them -- but not stored).
 struct CoefPlanes {
@@ -465,7 +502,7 @@ __device__ __forceinline__ int16_t* coef_block_ptr(const CoefPlanes& cp, const i
 // One segment, symbol by symbol, writing the coefficients of the blocks inside the window.  pred0..2: the DC predictors
 // at the segment's entry (in), at its exit (out); ndc: DC symbols decoded.
 __device__ __forceinline__ void jpeg_decode_segment(
-    const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow,
+    const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ longtab, const uint32_t* __restrict__ slow,
     const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk,
     int nb, const int total_blocks, int& pred0, int& pred1, int& pred2, int& ndc, const int mcus_x, const CoefPlanes& cp, int& bad)
 {
@@ -495,10 +532,9 @@ __device__ __forceinline__ void jpeg_decode_segment(
         const bool isdc = k == 0;
         const uint32_t t = isdc ? (L.dc_bits >> blk) & 1u : 2u + ((L.ac_bits >> blk) & 1u);
         uint32_t e = tab[(t << TAB_BITS) + (w >> (32 - TAB_BITS))];
-        if (!e) {
-            bool invalid = false;
-            e = huff_long_step(slow + t * SLOW_DW, isdc, w, invalid);
-            if (invalid) bad = 1;
+        if ((int32_t)e < 0) {
+            e = huff_long_entry(e, longtab, slow, t, isdc, w);
+            if ((int32_t)e < 0) bad = 1;
         }
         const int used = (int)(e & 31u), adv = (int)((e >> 16) & 127u), sbits = used - 1 - (int)((e >> 12) & 15u);
         const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - used, sbits);  // width 0 -> 0
@@ -548,7 +584,7 @@ __device__ __forceinline__ void jpeg_decode_segment(
 // them per segment and a fix-up adds the predictors (k_jpeg_huff).
 typedef short melf_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void jpeg_state_segment(
-    const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slow, const McuLayout L,
+    const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ longtab, const uint32_t* __restrict__ slow, const McuLayout L,
     SegState& s, const uint32_t p_end, int& nblk, int* diag = nullptr)
 {
     const uint32_t base = s.p & ~31u;
@@ -568,12 +604,9 @@ __device__ __forceinline__ void jpeg_state_segment(
 #ifdef MELF_JPEG_ROUNDS
         if (diag) ++diag[0];
 #endif
-        if (__builtin_amdgcn_uicmp(e, 0u, 32 /* == */) != 0ull) {  // some lane met a long code (one compare + scalar branch)
+        if (__builtin_amdgcn_sicmp((int32_t)e, 0, 40 /* < */) != 0ull) {  // some lane met a long code (one compare + scalar branch)
             asm volatile("");  // keeps the compiler from folding the two conditions into one divergent branch
-            if (e == 0u) {
-                bool invalid = false;
-                e = huff_long_step(slow + t * SLOW_DW, (X >> 16) == 0u, b0, invalid);
-            }
+            if ((int32_t)e < 0) e = huff_long_entry(e, longtab, slow, t, (X >> 16) == 0u, b0);
         }
         const uint32_t sym1 = e & SYM_MASK, sym2 = (e >> 7) & SYM_MASK;
         const uint32_t Y = X + sym1;  // after the first symbol
@@ -673,6 +706,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
                                                  int32_t* __restrict__ status, JpegWindow win)
 {
     __shared__ uint32_t tab[4 << TAB_BITS];
+    __shared__ uint32_t longtab[2 * LONG_N];
     __shared__ uint32_t slow[4 * SLOW_DW];
     __shared__ uint8_t nat[64];
     __shared__ uint32_t e_p[T], e_s[T];  // exit state of each segment: bit position, blk << 8 | k
@@ -708,7 +742,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     }
     __syncthreads();
     const McuLayout L = jpeg_mcu_layout(R);
-    jpeg_build_tables<T>(tab, slow, L, tid);
+    jpeg_build_tables<T>(tab, longtab, slow, L, tid);
     const int mcus_x = R->mcus_x;
     const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
     const CoefPlanes cp = {coefs + (size_t)R->coef_blk[0] * 64, coefs + (size_t)R->coef_blk[1] * 64, coefs + (size_t)R->coef_blk[2] * 64,
@@ -725,7 +759,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     {
         SegState ex = {(uint32_t)tid * S, 0, 0};
         int nblk = 0;
-        if (mine) jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(tid + 1) * S, bits + 32u), nblk);
+        if (mine) jpeg_state_segment(W, tab, longtab, slow, L, ex, min((uint32_t)(tid + 1) * S, bits + 32u), nblk);
         n_p[tid] = (uint32_t)tid * S;  // entry of the last decode
         n_s[tid] = 0;
         e_p[tid] = ex.p;
@@ -774,12 +808,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
             int nblk;
 #ifdef MELF_JPEG_ROUNDS
             int diag[2] = {0, 0};
-            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, diag);
+            jpeg_state_segment(W, tab, longtab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk, diag);
             atomicMax(&s_diag[0], diag[0]);
             atomicAdd(&s_diag[1], diag[0]);
             atomicAdd(&s_diag[2], diag[1]);
 #else
-            jpeg_state_segment(W, tab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk);
+            jpeg_state_segment(W, tab, longtab, slow, L, ex, min((uint32_t)(i + 1) * S, bits + 32u), nblk);
 #endif
             e_p[i] = ex.p;  // nobody reads exit states before the next barrier
             e_s[i] = (uint32_t)(ex.blk << 8 | ex.k);
@@ -821,7 +855,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
         if (entry.blk != nb_in % L.bpm) bad = 1;  // the propagated state and the block count disagree: corrupt stream
         SegState st = entry;
         int n2;
-        jpeg_decode_segment(W, tab, slow, nat, L, st, p_end, n2, nb_in, total_blocks, q0, q1, q2, ndc, mcus_x, cp, bad);
+        jpeg_decode_segment(W, tab, longtab, slow, nat, L, st, p_end, n2, nb_in, total_blocks, q0, q1, q2, ndc, mcus_x, cp, bad);
     }
     const int64_t dsum = (int64_t)q0 + ((int64_t)q1 << 16) + ((int64_t)q2 << 32);
     sc_d[tid] = dsum;
@@ -890,6 +924,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
                                                      int32_t* __restrict__ status, JpegWindow win)
 {
     __shared__ uint32_t tab[4 << TAB_BITS];
+    __shared__ uint32_t longtab[2 * LONG_N];
     __shared__ uint32_t slow[4 * SLOW_DW];
     __shared__ uint8_t nat[64];
     const int tid = threadIdx.x;
@@ -906,7 +941,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
     }
     __syncthreads();
     const McuLayout L = jpeg_mcu_layout(R);
-    jpeg_build_tables<T>(tab, slow, L, tid);
+    jpeg_build_tables<T>(tab, longtab, slow, L, tid);
     const int mcus_x = R->mcus_x;
     const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
     const int per_interval = (int)R->restart_interval * L.bpm;
@@ -921,7 +956,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
         SegState st = {rst[it] * 8u, 0, 0};
         const int nb0 = it * per_interval, nb1 = min(nb0 + per_interval, total_blocks);
         int n2, ndc, q0 = 0, q1 = 0, q2 = 0;  // every interval starts with zero predictors
-        jpeg_decode_segment(W, tab, slow, nat, L, st, bits + 32u, n2, nb0, nb1, q0, q1, q2, ndc, mcus_x, cp, bad);
+        jpeg_decode_segment(W, tab, longtab, slow, nat, L, st, bits + 32u, n2, nb0, nb1, q0, q1, q2, ndc, mcus_x, cp, bad);
         if (n2 < nb1 - nb0) bad = 1;  // ran out of data before the interval's last block
     }
     const int anybad = __syncthreads_or(bad);
