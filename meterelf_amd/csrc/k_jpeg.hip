@@ -323,7 +323,7 @@ struct SegState {
 //   bits  7..11  bits2        bits 23..29  adv2       both symbols together (adv2 = 64 when the second ends the block);
 //                                                      an entry WITHOUT a second symbol repeats the first here, so that
 //                                                      the decoder need not ask whether there is one
-//   bits 12..15  len1 - 1     code length of the first symbol (bits1 - len1 magnitude bits follow it)
+//   bits 12..15  sbits        magnitude bits of the first symbol (the last sbits of its bits1)
 // Bit 31 set: the first code is longer than the window.  For the AC tables the entry then carries (bits 0..11) where
 // the window's 2^6 continuations start in `longtab`, a direct table over the 16-bit windows that begin with a long code
 // (LONG_N of them per AC table; their Kraft sum is small: 319 for the standard tables); bit 30: not covered (a DC table,
@@ -355,6 +355,7 @@ struct McuLayout {
     uint32_t dc_bits, ac_bits, comp_bits;
     uint32_t tsel5;      // per block, 5 bits: DC table id | (2 + AC table id) << 2 (the state-only decoder's table choice)
     uint32_t nxt5;       // per block, 5 bits: 5 * index of the block that follows it in the MCU
+    uint32_t oh0, oh1, oh2;  // per block, at bit 5 * block: the block belongs to component 0 / 1 / 2
     uint32_t pair_dc;    // bit t: every block with DC table t uses the AC table its entries' second symbols come from
     int ac_of_dc0, ac_of_dc1;  // that AC table, per DC table
     int bpm, yblocks;
@@ -367,6 +368,7 @@ __device__ __forceinline__ McuLayout jpeg_mcu_layout(const JpegImageDev* R)
     L.yblocks = ncomp == 1 ? 1 : R->hs0 * R->vs0;
     L.bpm = ncomp == 1 ? 1 : L.yblocks + 2;
     L.dc_bits = L.ac_bits = L.comp_bits = L.tsel5 = L.nxt5 = 0;
+    L.oh0 = L.oh1 = L.oh2 = 0;
     L.pair_dc = 3;
     int a0 = -1, a1 = -1;
     for (int b = 0; b < L.bpm; ++b) {
@@ -377,6 +379,9 @@ __device__ __forceinline__ McuLayout jpeg_mcu_layout(const JpegImageDev* R)
         L.comp_bits |= (uint32_t)c << (2 * b);
         L.tsel5 |= ((uint32_t)td | (2u + (uint32_t)ta) << 2) << (5 * b);
         L.nxt5 |= (uint32_t)(5 * (b + 1 == L.bpm ? 0 : b + 1)) << (5 * b);
+        L.oh0 |= (c == 0 ? 1u : 0u) << (5 * b);
+        L.oh1 |= (c == 1 ? 1u : 0u) << (5 * b);
+        L.oh2 |= (c == 2 ? 1u : 0u) << (5 * b);
         if (td == 0 && a0 < 0) a0 = ta;
         if (td == 1 && a1 < 0) a1 = ta;
         if ((td == 0 ? a0 : a1) != ta) L.pair_dc &= ~(1u << td);
@@ -392,7 +397,7 @@ __device__ __forceinline__ uint32_t huff_step(const bool dc, const int len, cons
     const int sbits = sym & 15, run = sym >> 4;
     const int adv = dc ? 1 : (sbits ? run + 1 : (run == 15 ? 16 : 64));
     const uint32_t one = (uint32_t)(len + sbits) | (uint32_t)adv << 16;
-    return one | one << 7 | (uint32_t)(len - 1) << 12;
+    return one | one << 7 | (uint32_t)sbits << 12;
 }
 
 // Canonical decode of the code at the top of the nb-bit window x, looking at its first `avail` bits only: the symbol's
@@ -500,7 +505,11 @@ __device__ __forceinline__ int16_t* coef_block_ptr(const CoefPlanes& cp, const i
 }
 
 // One segment, symbol by symbol, writing the coefficients of the blocks inside the window.  pred0..2: the DC predictors
-// at the segment's entry (in), at its exit (out); ndc: DC symbols decoded.
+// at the segment's entry (in), at its exit (out); ndc: DC symbols decoded.  Every lane of a full wave is at another
+// place of its block, so whatever any symbol kind needs is executed in every step: the loop is written for the UNION --
+// one value extraction, one store (DC: predictor sum at index 0; AC: the value at its natural position), predictor sums
+// by multiply-add with a one-hot component vector that changes with the block, the stream window of the state-only
+// decoder -- and only the block change (next block's pointer, tables, component) sits behind a branch.
 __device__ __forceinline__ void jpeg_decode_segment(
     const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ longtab, const uint32_t* __restrict__ slow,
     const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk,
@@ -508,66 +517,79 @@ __device__ __forceinline__ void jpeg_decode_segment(
 {
     uint32_t p = s.p;
     int blk = s.blk, k = s.k;
-    int mx = 0, my = 0;
+    int mx, my;
     {
         const int mcu = nb / L.bpm;
         my = mcu / mcus_x;
         mx = mcu - my * mcus_x;
     }
     int16_t* cb = coef_block_ptr(cp, mx, my, blk);
-    nblk = 0;
-    ndc = 0;
+    int nbl = 0, nd = 0;
     int a0 = pred0, a1 = pred1, a2 = pred2;
-    // bit buffer over the scan in global memory (dwords in file byte order): the top `bitcnt` bits are valid
-    uint32_t di = (p >> 5) + 2;
-    uint64_t bitbuf = (((uint64_t)__builtin_bswap32(W[di - 2]) << 32) | __builtin_bswap32(W[di - 1])) << (p & 31u);
-    int bitcnt = 64 - (int)(p & 31u);
-    while (p < p_end) {
-        if (nb >= total_blocks) break;
-        if (bitcnt < 32) {
-            bitbuf |= (uint64_t)__builtin_bswap32(W[di++]) << (32 - bitcnt);
-            bitcnt += 32;
+    uint32_t bs = 5u * (uint32_t)blk;
+    int c0 = (int)__builtin_amdgcn_ubfe(L.oh0, bs, 1), c1 = (int)__builtin_amdgcn_ubfe(L.oh1, bs, 1), c2 = (int)__builtin_amdgcn_ubfe(L.oh2, bs, 1);
+    // the stream: three byte-swapped dwords that rotate when the position crosses a dword, the next one requested a step ahead
+    const uint32_t* __restrict__ Wp = W + (p >> 5);
+    uint32_t Xs = p << 27;
+    uint32_t d0 = __builtin_bswap32(Wp[0]), d1 = __builtin_bswap32(Wp[1]), d2 = __builtin_bswap32(Wp[2]);
+    uint32_t off = 3;
+    uint32_t nraw = Wp[3];
+    uint32_t t = __builtin_amdgcn_ubfe(L.tsel5, bs + (k == 0 ? 0u : 2u), 2);
+    uint32_t b0 = (uint32_t)(((((uint64_t)d0 << 32) | d1) << (Xs >> 27)) >> 32);
+    while (p < p_end && nb < total_blocks) {
+        uint32_t e = tab[__builtin_amdgcn_alignbit(t, b0, 32 - TAB_BITS)];
+        if (__builtin_amdgcn_sicmp((int32_t)e, 0, 40 /* < */) != 0ull) {  // some lane met a long code
+            asm volatile("");
+            if ((int32_t)e < 0) {
+                e = huff_long_entry(e, longtab, slow, t, k == 0, b0);
+                if ((int32_t)e < 0) bad = 1;
+            }
         }
-        const uint32_t w = (uint32_t)(bitbuf >> 32);  // the next 32 bits: code + magnitude fit (<= 16 + 15)
+        const int used = (int)(e & 31u), adv = (int)((e >> 16) & 127u), sbits = (int)((e >> 12) & 15u);
+        const int raw = (int)__builtin_amdgcn_ubfe(b0, 32 - used, sbits);  // width 0 -> 0
+        const int m = 1 << sbits;
+        const int v = 2 * raw < m ? raw - m + 1 : raw;  // EXTEND (F.2.2.1); sbits = 0 -> 0
         const bool isdc = k == 0;
-        const uint32_t t = isdc ? (L.dc_bits >> blk) & 1u : 2u + ((L.ac_bits >> blk) & 1u);
-        uint32_t e = tab[(t << TAB_BITS) + (w >> (32 - TAB_BITS))];
-        if ((int32_t)e < 0) {
-            e = huff_long_entry(e, longtab, slow, t, isdc, w);
-            if ((int32_t)e < 0) bad = 1;
-        }
-        const int used = (int)(e & 31u), adv = (int)((e >> 16) & 127u), sbits = used - 1 - (int)((e >> 12) & 15u);
-        const int raw = (int)__builtin_amdgcn_ubfe(w, 32 - used, sbits);  // width 0 -> 0
-        const int half = (1 << sbits) >> 1;
-        const int v = raw < half ? raw - 2 * half + 1 : raw;  // EXTEND (F.2.2.1); sbits = 0 -> 0
-        p += (uint32_t)used;
-        bitbuf <<= used;
-        bitcnt -= used;
-        if (isdc) {
-            const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
-            a0 += comp == 0 ? v : 0;
-            a1 += comp == 1 ? v : 0;
-            a2 += comp == 2 ? v : 0;
-            if (cb) cb[0] = (int16_t)(comp == 0 ? a0 : comp == 1 ? a1 : a2);
-            ++ndc;
-        } else {
-            const int pos = k + adv - 1;  // run zeros, then this coefficient
-            if (sbits && pos < 64 && cb) cb[nat[pos]] = (int16_t)v;
-        }
+        const int vd = isdc ? v : 0;
+        a0 = __mul24(vd, c0) + a0;
+        a1 = __mul24(vd, c1) + a1;
+        a2 = __mul24(vd, c2) + a2;
+        const int pr = c0 ? a0 : c1 ? a1 : a2;
+        nd += isdc ? 1 : 0;
         k += adv;  // DC: 0 -> 1
+        const int pos = k - 1;  // run zeros, then this coefficient
+        const int zz = nat[pos & 63];
+        const bool st = cb != nullptr && (isdc || (sbits != 0 && pos < 64));
+        if (st) cb[isdc ? 0 : zz] = (int16_t)(isdc ? pr : v);
+        p += (uint32_t)used;
+        const bool rot = __builtin_uadd_overflow(Xs, (uint32_t)used << 27, &Xs);
+        d0 = rot ? d1 : d0;
+        d1 = rot ? d2 : d1;
+        d2 = rot ? __builtin_bswap32(nraw) : d2;
+        off += rot ? 1u : 0u;
+        nraw = Wp[off];
+        __builtin_amdgcn_sched_barrier(0);
         if (k >= 64) {
             k = 0;
-            ++nblk;
+            ++nbl;
+            ++nb;
             if (++blk == L.bpm) {
                 blk = 0;
                 if (++mx == mcus_x) { mx = 0; ++my; }
             }
-            ++nb;
+            bs = 5u * (uint32_t)blk;
             cb = coef_block_ptr(cp, mx, my, blk);
+            c0 = (int)__builtin_amdgcn_ubfe(L.oh0, bs, 1);
+            c1 = (int)__builtin_amdgcn_ubfe(L.oh1, bs, 1);
+            c2 = (int)__builtin_amdgcn_ubfe(L.oh2, bs, 1);
         }
+        t = __builtin_amdgcn_ubfe(L.tsel5, bs + (k == 0 ? 0u : 2u), 2);
+        b0 = (uint32_t)(((((uint64_t)d0 << 32) | d1) << (Xs >> 27)) >> 32);
     }
     s.p = p; s.blk = blk; s.k = k;
     pred0 = a0; pred1 = a1; pred2 = a2;
+    nblk = nbl;
+    ndc = nd;
 }
 
 // What a segment's decode does to the decoder STATE, without coefficients or DC values: exit state and blocks completed.
