@@ -337,6 +337,9 @@ struct SegState {
 constexpr uint32_t SYM_MASK = 0x007f001fu;  // bits | adv << 16 of the first symbol; the second sits 7 bits higher
 constexpr int TAB_BITS = 10;
 constexpr int LONG_N = 512;  // entries of the long-code table per AC table
+// k_jpeg_huff keeps bit positions inside a segment in 16 bits: segments of at most 32 000 bits, i.e. scans of at most
+// 4 MB with 1024 lanes (2 MB with the usual 512); larger baseline files without restart markers go to the host decoder
+constexpr size_t JPEG_MAX_PAR_SCAN = 4000000;
 constexpr uint32_t TAB_MASK = (1u << TAB_BITS) - 1u;
 
 // Per-MCU-position tables packed into registers: 1 bit of DC table id, 1 bit of AC table id and 2 bits
@@ -1407,6 +1410,10 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
             r.rst_cnt = (uint32_t)found;
         }
         r.ok = h.restart_interval != 0 ? 2 : 1;
+        if (!h.restart_interval && len > JPEG_MAX_PAR_SCAN) {  // longer than 1024 lanes x the segment length k_jpeg_huff can address
+            r.ok = 0;
+            host_status[i] = 1;  // valid, but for the host decoder
+        }
     });
     w->n_par = w->n_seq = w->n_420 = 0;
     w->max_par_scan = 0;
@@ -1464,8 +1471,10 @@ int jpeg_decode_batch_kernels(JpegWorkspace* w, int n, int H, int W, uint8_t* d_
     const uint8_t* scan = w->d_stage + w->off_scan;
     if (timer) timer(timer_arg, 0, 0);
     if (w->n_par > 0) {  // one workgroup per image, one lane per stream segment
-        static int tsel = -1;
-        if (tsel < 0) { const char* e = getenv("MELF_JPEG_T"); tsel = e ? atoi(e) : 512; }
+        static int tenv = -1;
+        if (tenv < 0) { const char* e = getenv("MELF_JPEG_T"); tenv = e ? atoi(e) : 0; }
+        // 512 lanes per image; a batch with a scan too long for 512 segments of the length the kernel can address takes 1024
+        const int tsel = tenv ? tenv : (w->max_par_scan > JPEG_MAX_PAR_SCAN / 2 ? 1024 : 512);
 #define LAUNCH_HUFF(TT) \
     hipLaunchKernelGGL(k_jpeg_huff<TT>, dim3(n), dim3(TT), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status, win)
         if (tsel == 128) LAUNCH_HUFF(128);

@@ -131,6 +131,24 @@ def test_synthetic_files(ctx, subsampling, shape):
 
 
 @pytest.mark.gpu
+def test_long_scans(ctx):
+    """Scans of megabytes: 1.9 MB decodes with the usual 512 lanes, 3.3 MB takes 1024 lanes (a batch is launched with the
+    lane count its longest scan needs), 4.9 MB is beyond what the kernel addresses: reported unsupported, never wrong."""
+    from meterelf_amd import _hip
+    rng = np.random.default_rng(77)
+    for ((H, W), kw, expect) in (((1000, 1200), dict(quality=98, subsampling='4:2:0'), _hip.JPEG_OK),
+                                 ((800, 1000), dict(quality=100, subsampling='4:4:4'), _hip.JPEG_OK),
+                                 ((1000, 1200), dict(quality=100, subsampling='4:4:4'), _hip.JPEG_UNSUPPORTED)):
+        noise = _encode(rng.integers(0, 256, (H, W, 3), dtype=np.uint8), **kw)
+        small = _encode(_natural_image(rng, H, W), quality=60, subsampling=kw['subsampling'])
+        (frames, status) = ctx.jpeg_decode([small, noise, small], H, W)
+        assert list(status) == [_hip.JPEG_OK, expect, _hip.JPEG_OK], (len(noise), status)
+        assert np.array_equal(frames[0], _pillow_bgr(small)) and np.array_equal(frames[2], frames[0])
+        if expect == _hip.JPEG_OK:
+            assert np.array_equal(frames[1], _pillow_bgr(noise)), len(noise)
+
+
+@pytest.mark.gpu
 def test_restart_intervals_and_greyscale(ctx):
     rng = np.random.default_rng(77)
     (H, W) = (120, 200)
