@@ -490,21 +490,18 @@ __device__ __forceinline__ uint32_t huff_long_entry(const uint32_t e, const uint
     return longtab[(e & 0xfffu) + ((w >> 16) & ((1u << (16 - TAB_BITS)) - 1u))];
 }
 
-// Where the coefficients of block `blk` of MCU (mx, my) live, or NULL outside the window (such blocks are decoded --
-// the DC predictors need them -- but not stored).
-struct CoefPlanes {
-    int16_t *c0, *c1, *c2;
-    int hs0, vs0, bxs0, bxs1, yblocks;
+// The coefficient blocks of an image are stored in DECODE ORDER (block n of the scan at n * 64 coefficients: MCU after
+// MCU, the MCU's blocks in scan order), so that the decoders' "next block" is the next 128 bytes and the IDCT kernel does
+// the little arithmetic of finding a plane position's block.  Where block n of MCU (mx, my) lives, or NULL outside the
+// window (such blocks are decoded -- the DC predictors need them -- but not stored):
+struct CoefBlocks {
+    int16_t* base;
     McuWindow mw;
 };
-__device__ __forceinline__ int16_t* coef_block_ptr(const CoefPlanes& cp, const int mx, const int my, const int blk)
+__device__ __forceinline__ int16_t* coef_block_ptr(const CoefBlocks& cp, const int mx, const int my, const int n)
 {
-    if (mx < cp.mw.mx0 || mx >= cp.mw.mx1 || my < cp.mw.my0 || my >= cp.mw.my1) return nullptr;
-    if (blk < cp.yblocks) {
-        const int sub_y = blk >= cp.hs0 ? 1 : 0;
-        return cp.c0 + (size_t)((my * cp.vs0 + sub_y) * cp.bxs0 + mx * cp.hs0 + (blk - sub_y * cp.hs0)) * 64;
-    }
-    return (blk == cp.yblocks ? cp.c1 : cp.c2) + (size_t)(my * cp.bxs1 + mx) * 64;
+    const bool inside = (unsigned)(mx - cp.mw.mx0) < (unsigned)(cp.mw.mx1 - cp.mw.mx0) && (unsigned)(my - cp.mw.my0) < (unsigned)(cp.mw.my1 - cp.mw.my0);
+    return inside ? cp.base + (size_t)n * 64 : nullptr;
 }
 
 // One segment, symbol by symbol, writing the coefficients of the blocks inside the window.  pred0..2: the DC predictors
@@ -516,7 +513,7 @@ __device__ __forceinline__ int16_t* coef_block_ptr(const CoefPlanes& cp, const i
 __device__ __forceinline__ void jpeg_decode_segment(
     const uint32_t* __restrict__ W, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ longtab, const uint32_t* __restrict__ slow,
     const uint8_t* __restrict__ nat, const McuLayout L, SegState& s, const uint32_t p_end, int& nblk,
-    int nb, const int total_blocks, int& pred0, int& pred1, int& pred2, int& ndc, const int mcus_x, const CoefPlanes& cp, int& bad)
+    int nb, const int total_blocks, int& pred0, int& pred1, int& pred2, int& ndc, const int mcus_x, const CoefBlocks& cp, int& bad)
 {
     uint32_t p = s.p;
     int blk = s.blk, k = s.k;
@@ -526,7 +523,7 @@ __device__ __forceinline__ void jpeg_decode_segment(
         my = mcu / mcus_x;
         mx = mcu - my * mcus_x;
     }
-    int16_t* cb = coef_block_ptr(cp, mx, my, blk);
+    int16_t* cb = coef_block_ptr(cp, mx, my, nb);
     int nbl = 0, nd = 0;
     int a0 = pred0, a1 = pred1, a2 = pred2;
     uint32_t bs = 5u * (uint32_t)blk;
@@ -581,7 +578,7 @@ __device__ __forceinline__ void jpeg_decode_segment(
                 if (++mx == mcus_x) { mx = 0; ++my; }
             }
             bs = 5u * (uint32_t)blk;
-            cb = coef_block_ptr(cp, mx, my, blk);
+            cb = coef_block_ptr(cp, mx, my, nb);
             c0 = (int)__builtin_amdgcn_ubfe(L.oh0, bs, 1);
             c1 = (int)__builtin_amdgcn_ubfe(L.oh1, bs, 1);
             c2 = (int)__builtin_amdgcn_ubfe(L.oh2, bs, 1);
@@ -705,15 +702,13 @@ __device__ __forceinline__ McuWindow jpeg_zero_window(const JpegImageDev* R, con
     McuWindow m;
     m.mx0 = win.x0 / mwid; m.mx1 = min((win.x1 + mwid - 1) / mwid, (int)R->mcus_x);
     m.my0 = win.y0 / mhei; m.my1 = min((win.y1 + mhei - 1) / mhei, (int)R->mcus_y);
-    for (int c = 0; c < ncomp; ++c) {
-        const int fx = c == 0 ? hs0 : 1, fy = c == 0 ? vs0 : 1;
-        const int bx0 = m.mx0 * fx, by0 = m.my0 * fy, w16 = (m.mx1 - m.mx0) * fx * 8, rows = (m.my1 - m.my0) * fy;
-        uint4* base = (uint4*)(coefs + (size_t)R->coef_blk[c] * 64);
-        const int bxs = R->blocks_x[c];
-        for (int i = tid; i < rows * w16; i += T) {
-            const int r = i / w16, q = i - r * w16;
-            base[((size_t)(by0 + r) * bxs + bx0) * 8 + q] = make_uint4(0u, 0u, 0u, 0u);
-        }
+    // decode order: the window's MCUs of one MCU row are one run of bpm * 128 bytes each
+    const int bpm = ncomp == 1 ? 1 : hs0 * vs0 + 2;
+    const int run16 = (m.mx1 - m.mx0) * bpm * 8, rows = m.my1 - m.my0;  // uint4s per row of MCUs
+    uint4* base = (uint4*)(coefs + (size_t)R->coef_blk[0] * 64);
+    for (int i = tid; i < rows * run16; i += T) {
+        const int r = i / run16, q = i - r * run16;
+        base[((size_t)(m.my0 + r) * R->mcus_x + m.mx0) * bpm * 8 + q] = make_uint4(0u, 0u, 0u, 0u);
     }
     return m;
 }
@@ -770,8 +765,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     jpeg_build_tables<T>(tab, longtab, slow, L, tid);
     const int mcus_x = R->mcus_x;
     const int total_blocks = mcus_x * (int)R->mcus_y * L.bpm;
-    const CoefPlanes cp = {coefs + (size_t)R->coef_blk[0] * 64, coefs + (size_t)R->coef_blk[1] * 64, coefs + (size_t)R->coef_blk[2] * 64,
-                           R->hs0, R->vs0, R->blocks_x[0], R->blocks_x[1], L.yblocks, mwin};
+    const CoefBlocks cp = {coefs + (size_t)R->coef_blk[0] * 64, mwin};
     __syncthreads();
 
     JSTAMP(1);
@@ -906,7 +900,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
                 int add[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    cb[u] = i + u < ndc ? coef_block_ptr(cp, mx, my, blk) : nullptr;
+                    cb[u] = i + u < ndc ? coef_block_ptr(cp, mx, my, b0 + i + u) : nullptr;
                     const int comp = (int)((L.comp_bits >> (2 * blk)) & 3u);
                     add[u] = comp == 0 ? pr0 : comp == 1 ? pr1 : pr2;
                     if (++blk == L.bpm) {
@@ -973,8 +967,7 @@ __global__ __launch_bounds__(T) void k_jpeg_huff_rst(const JpegImageDev* __restr
     const int nint = (int)R->rst_cnt;
     const int expected = (total_blocks + per_interval - 1) / per_interval;
     const uint32_t bits = R->scan_len * 8u;
-    const CoefPlanes cp = {coefs + (size_t)R->coef_blk[0] * 64, coefs + (size_t)R->coef_blk[1] * 64, coefs + (size_t)R->coef_blk[2] * 64,
-                           R->hs0, R->vs0, R->blocks_x[0], R->blocks_x[1], L.yblocks, mwin};
+    const CoefBlocks cp = {coefs + (size_t)R->coef_blk[0] * 64, mwin};
     __syncthreads();
     int bad = nint != expected ? 1 : 0;  // markers missing or surplus: corrupt stream
     for (int it = tid; it < min(nint, expected); it += T) {
@@ -1040,7 +1033,11 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImageDev* __restric
     if (j >= nb0) { j -= nb0; c = 1; if (j >= nbc) { j -= nbc; c = 2; } }
     const int ww = c == 0 ? w0 : wc;
     const int by = (c == 0 ? my0 * I.vs0 : my0) + j / ww, bx = (c == 0 ? mx0 * I.hs0 : mx0) + j % ww;
-    const int16_t* src = coefs + ((size_t)I.coef_blk[c] + (size_t)by * I.blocks_x[c] + bx) * 64;
+    // the block's place in decode order (CoefBlocks): its MCU, then its index among the MCU's blocks
+    const int fx = c == 0 ? I.hs0 : 1, fy = c == 0 ? I.vs0 : 1, bpm = I.ncomp == 1 ? 1 : I.hs0 * I.vs0 + 2;
+    const int mcu = (by / fy) * I.mcus_x + bx / fx;
+    const int inb = c == 0 ? (by % fy) * I.hs0 + bx % fx : I.hs0 * I.vs0 + c - 1;
+    const int16_t* src = coefs + ((size_t)I.coef_blk[0] + (size_t)mcu * bpm + inb) * 64;
     const uint16_t* q = g_qt + ((size_t)img * 4 + I.tq[c]) * 64;
     int ws[64];
     // pass 1: columns
