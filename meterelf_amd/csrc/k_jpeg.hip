@@ -11,7 +11,7 @@
 //   host   parse markers, canonical Huffman data, strip byte stuffing / RSTn markers (recording where the
 //          restart intervals begin)
 //   J1     k_jpeg_huff      one workgroup per image, one lane per bit-stream segment (speculative decode until
-//                           the segments' exit states reach a fixed point) -> int16 coefficient blocks
+//                           the segments' exit states reach a fixed point) -> int16 coefficient blocks in decode order
 //          k_jpeg_huff_rst  streams with restart intervals: one lane per interval, no speculation needed
 //   J2     k_jpeg_idct      one thread per 8x8 block: dequantise + ISLOW IDCT -> u8 planes
 //   J3     k_jpeg_color420  8 pixels per thread: fancy upsample + YCC->BGR -> NHWC frame (k_jpeg_color: other modes)
@@ -301,14 +301,18 @@ __device__ __constant__ uint8_t c_zz2nat[64] = {
 // ------------------------------------------------- J1: Huffman, segment-parallel ----
 // One workgroup per image, one lane per bit-stream segment.  A Huffman stream can only be decoded from
 // a known state (bit position, block within the MCU, coefficient index), but decoders started from a
-// wrong state fall into step with the true one after a few hundred bits (self-synchronisation), so:
-//   round 0   every lane decodes its segment from a guessed state and publishes its exit state;
-//   round r   a lane whose predecessor's exit state changed decodes again from that state; the true
-//             state of lane 0 propagates at least one lane per round and in practice the states stop
-//             changing after 2-4 rounds (fixed point: exit[i] = F_i(exit[i-1]) for all i);
-//   scan      blocks completed and DC differences summed per segment -> exclusive prefix over lanes;
-//   output    one more decode that writes coefficients at the right block with absolute DC values.
-// The scan (byte-swapped dwords) and all decode tables of the image sit in LDS.
+// wrong state fall into step with the true one by themselves (self-synchronisation), so:
+//   round 0   every lane walks its segment from a guessed state (state only: no values) and publishes its exit state;
+//   round r   a lane whose predecessor's exit state changed walks again from that state (the changed segments
+//             compacted onto the first lanes); the true state of lane 0 propagates at least one lane per round; the
+//             fixtures need 8-19 rounds (fixed point: exit[i] = F_i(exit[i-1]) for all i);
+//   scan      blocks completed per segment -> exclusive prefix over the lanes = each segment's first block;
+//   output    one more decode that writes the coefficients, DC predictors starting at zero in every segment;
+//   fix-up    prefix over the lanes of the segments' DC-difference sums -> the predictors at each segment's entry,
+//             added to the DC coefficients the segment stored.
+// The decode tables of the image sit in LDS, the stream is read through L1 a dword ahead.  What bounds the kernel is
+// the number of INSTRUCTIONS per decode step (tools/ubench/wave_latency.hip: a lone wave issues one per ~6 cycles
+// whatever it is, four waves on a SIMD one per ~4 between them), so both decoders are written to be short.
 struct SegState {
     uint32_t p;      // bit position
     int blk, k;      // block within the MCU, coefficient index (0 = DC symbol comes next)
