@@ -198,7 +198,9 @@ int melf_process_stream_dev(melf_ctx* ctx, const void* d_frames, int nbatches, s
  * Baseline sequential 8-bit Huffman JPEGs (one interleaved scan; YCbCr 4:2:0 / 4:2:2 / 4:4:4 or
  * greyscale; restart intervals allowed) are decoded on the GPU to the bytes libjpeg produces with its
  * defaults (ISLOW IDCT, fancy upsampling), i.e. what cv2.imread returns: H x W x 3 BGR u8.
- * Per-file status: 0 decoded, 1 valid JPEG outside that subset (decode it on the host instead),
+ * Per-file status: 0 decoded, 1 valid JPEG outside that subset (decode it on the host instead) -- also a file
+ * WITHOUT restart markers whose entropy-coded data exceed 4 MB (the segment-parallel Huffman kernel addresses
+ * 1024 segments of at most 32 000 bits; melf_jpeg_probe cannot tell, the decode calls report it) --,
  * 2 unreadable / corrupt, 3 its size is not H x W.  Frames with a non-zero status are zero-filled. */
 enum { MELF_JPEG_OK = 0, MELF_JPEG_UNSUPPORTED = 1, MELF_JPEG_CORRUPT = 2, MELF_JPEG_SIZE_MISMATCH = 3,
        MELF_JPEG_UNREADABLE = 4 /* melf_jpeg_process_files: the file could not be opened or read */ };
