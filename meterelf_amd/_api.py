@@ -5,7 +5,7 @@
 Lazy, yields in input order, per-image ImageProcessingError becomes the `error`
 field (re-raised only when DEBUG is set).  Unlike the reference's one-at-a-time
 loop, files go to the GPU in chunks (METERELF_BATCH, default 1024) and the library already
-works on the next chunk while the current chunk's results are consumed, so up to two chunks
+works on the next two chunks while the current chunk's results are consumed, so up to three chunks
 are read ahead of the consumer.
 
 cv2.imread of the reference (meterelf/_image.py:49): baseline JPEG files are read (on threads, inside the
@@ -109,11 +109,11 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         except ImageProcessingError as e:
             return e
 
-    # GPU decode: the library works on chunk k + 1 (file reads, Huffman tables, kernels) on its own thread
-    # (melf_jpeg_process_files_begin / _end) while this thread turns chunk k's records into Python objects and the
-    # consumer handles them.
-    begun = False  # a _begin without its _end
+    # GPU decode: the library works on the chunks k + 1 and k + 2 on its own threads (melf_jpeg_process_files_begin / _end,
+    # two calls in flight: chunk k + 2's files are read while chunk k + 1 decodes) while this thread turns chunk k's
+    # records into Python objects and the consumer handles them.
     clean = False  # the generator ran to its end (or was closed between chunks with nothing in flight)
+    DEPTH = 2
 
     def _gpu_read(chunk: List[str]):
         if hasattr(reader, 'read_jpeg_paths_batch'):
@@ -124,29 +124,40 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
 
     try:
         chunks = _chunks(filenames, batch)
+        begun: List[List[str]] = []  # chunks handed to the library, oldest first
+
+        def _begin_more() -> None:
+            while len(begun) < DEPTH:
+                nxt = next(chunks, None)
+                if nxt is None:
+                    return
+                reader.read_jpeg_paths_begin(nxt)
+                begun.append(nxt)
+
         chunk = next(chunks, None)
         while chunk is not None:
             if reader is None:
                 reader = _acquire_reader(params) if MeterReader is _REAL_READER else MeterReader(params)
             assert len(reader.dial_names) == 4  # meterelf/_reading.py:166
+            pipelined = gpu_decode and batch > 1 and hasattr(reader, 'read_jpeg_paths_begin')
             errors: Dict[int, ImageProcessingError] = {}
             by_index: Dict[int, object] = {}
             converted: list = [None] * len(chunk)  # (meter_values, error) of the files the GPU decoded
             raw = None
             if gpu_decode:  # files are read inside the library
                 if begun:
+                    assert begun[0] is chunk
+                    begun.pop(0)
                     raw = reader.read_jpeg_paths_end()
                     raw = (raw[0], raw[1].tolist())
-                    begun = False
                 else:
                     raw = _gpu_read(chunk)
-            following = next(chunks, None)
-            overlap = following is not None and gpu_decode and batch > 1 and hasattr(reader, 'read_jpeg_paths_begin')
+            if pipelined:
+                _begin_more()  # before this chunk's records are touched: the library has DEPTH chunks to work on
+                following = begun[0] if begun else None
+            else:
+                following = next(chunks, None)
             if isinstance(raw, tuple):
-                # a chunk whose files all went through the GPU decoder needs the context no more: the next one may start
-                if overlap and all(raw[1]):
-                    reader.read_jpeg_paths_begin(following)
-                    begun = True
                 converted = records_to_python(raw[0], raw[1], reader.dial_names, chunk)
             elif raw is not None:
                 converted = raw
@@ -163,6 +174,8 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                     else:
                         frames.append(item)
                         where.append(i)
+                if frames and pipelined:
+                    reader.drain_jpeg_paths()  # host-decoded frames go through the context: nothing may be in flight on it
                 records = reader.read_many(frames) if frames else []
                 by_index.update(zip(where, records))
             for (i, filename) in enumerate(chunk):
@@ -183,9 +196,9 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         clean = True   # dropped by the consumer half way: whatever is in flight is collected below
         raise
     finally:
-        if begun and reader is not None:
+        if reader is not None and hasattr(reader, 'jpeg_paths_in_flight') and reader.jpeg_paths_in_flight():
             try:
-                reader.read_jpeg_paths_end()  # the context must be idle before it is closed
+                reader.discard_jpeg_paths()  # the context must be idle before it is closed or handed on
             except Exception:
                 clean = False
         if pool is not None:

@@ -108,6 +108,8 @@ class MeterReader:
         self.blob = blob if blob is not None else make_blob(params)
         self.ctx = _hip.Context(self.blob, device)
         self._crop_ctx: Dict[Tuple[int, int], _hip.Context] = {}
+        self._begun: list = []      # read_jpeg_paths_begin: path lists in flight, oldest first
+        self._collected: list = []  # their results taken out of the library early (drain_jpeg_paths), oldest first
 
     def close(self) -> None:
         self.ctx.close()
@@ -165,20 +167,40 @@ class MeterReader:
 
     def read_jpeg_paths_begin(self, paths: List[str]) -> None:
         """read_jpeg_paths_batch in two halves: the library works on `paths` on its own thread until
-        read_jpeg_paths_end() collects (records, ok).  Nothing else may use this reader in between."""
-        self._begun = list(paths)
-        self.ctx.jpeg_process_files_begin(self._begun)
+        read_jpeg_paths_end() collects (records, ok) of the OLDEST list begun.  Up to two lists may be in flight (the
+        second one's files are read while the first decodes); nothing else may use this reader while any is --
+        drain_jpeg_paths() first."""
+        paths = list(paths)
+        self.ctx.jpeg_process_files_begin(paths)
+        self._begun.append(paths)
 
-    def read_jpeg_paths_end(self) -> Tuple[np.ndarray, np.ndarray]:
-        paths = self._begun
-        self._begun = None
+    def jpeg_paths_in_flight(self) -> int:
+        return len(self._begun) + len(self._collected)
+
+    def _collect_one(self):
+        paths = self._begun.pop(0)
         (recs, status, _hw) = self.ctx.jpeg_process_files_end()
         status = np.asarray(status)
         ok = status == _hip.JPEG_OK
         records = np.zeros(len(paths), _hip.RESULT_DTYPE)
         records[ok] = recs[ok]
-        again = np.flatnonzero(status == _hip.JPEG_SIZE_MISMATCH)
-        if len(again):  # files of another frame size: their own call(s), now
+        return (paths, records, ok, np.flatnonzero(status == _hip.JPEG_SIZE_MISMATCH))
+
+    def drain_jpeg_paths(self) -> None:
+        """Waits for every list in flight and keeps the results for read_jpeg_paths_end(): afterwards the context is
+        free for other calls (host-decoded frames, files of another frame size)."""
+        while self._begun:
+            self._collected.append(self._collect_one())
+
+    def discard_jpeg_paths(self) -> None:
+        """Waits for every list in flight and forgets the results (a consumer that stopped early)."""
+        self.drain_jpeg_paths()
+        self._collected.clear()
+
+    def read_jpeg_paths_end(self) -> Tuple[np.ndarray, np.ndarray]:
+        (paths, records, ok, again) = self._collected.pop(0) if self._collected else self._collect_one()
+        if len(again):  # files of another frame size: their own call(s), now -- with the context to ourselves
+            self.drain_jpeg_paths()
             (r2, ok2) = self.read_jpeg_paths_batch([paths[i] for i in again])
             records[again] = r2
             ok[again] = ok2

@@ -405,7 +405,8 @@ class Context:
 
     def jpeg_process_files_begin(self, paths):
         """Starts jpeg_process_files(paths) on a thread of the library and returns at once; jpeg_process_files_end()
-        waits for it.  One call in flight per context, no other call on it in between."""
+        waits for the oldest call begun.  Up to two calls in flight per context (the second one's files are read while
+        the first decodes), no other call on the context in between."""
         n = len(paths)
         out = np.zeros(n, dtype=RESULT_DTYPE)
         status = np.zeros(n, np.int32)
@@ -413,13 +414,17 @@ class Context:
         enc = [os.fsencode(p) for p in paths]
         arr = (C.c_char_p * max(n, 1))(*enc)
         check(self._L.melf_jpeg_process_files_begin(self._h, arr, n, C.byref(hw[0]), C.byref(hw[1]), _ptr(out), _ptr(status)))
-        self._files_pending = (out, status, hw, arr, enc)  # everything the library points into, alive until _end
+        if getattr(self, '_files_pending', None) is None:
+            self._files_pending = []
+        self._files_pending.append((out, status, hw, arr, enc))  # everything the library points into, alive until its _end
 
     def jpeg_process_files_end(self):
-        (out, status, hw, _arr, _enc) = self._files_pending
-        self._files_pending = None
+        (out, status, hw, _arr, _enc) = self._files_pending.pop(0)  # the library forgets the call whatever it returns
         check(self._L.melf_jpeg_process_files_end(self._h))
         return out, status, (hw[0].value, hw[1].value)
+
+    def files_in_flight(self):
+        return len(getattr(self, '_files_pending', None) or ())
 
     def set_frames_resident(self, on):
         """Promise that the frames of every process_batch_dev call are complete in HBM when the call is made: a call's prep

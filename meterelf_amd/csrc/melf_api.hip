@@ -12,6 +12,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -281,12 +284,21 @@ struct melf_ctx {
     size_t jstatus_cap = 0;
     // melf_jpeg_process_files: the files' bytes (grow-only: no per-file allocation, no zero fill, and after the first
     // call no fresh pages to fault in), and the call in flight of the begin / end pair
-    uint8_t* file_arena = nullptr;
-    size_t file_arena_cap = 0;
-    std::thread files_thread;
-    bool files_in_flight = false;
-    int files_rc = 0;
-    std::string files_err;
+    // Up to NFJ begin / end calls in flight: each on its own thread, which READS its files at once (into the arena of its
+    // slot) and then waits for its turn at the context (decode + reading path, in the order of the _begin calls).
+    static const int NFJ = 2;
+    struct FilesJob {
+        std::thread th;
+        int rc = 0;
+        std::string err;
+    };
+    uint8_t* file_arena[NFJ] = {};
+    size_t file_arena_cap[NFJ] = {};
+    std::deque<FilesJob*> files_jobs;      // oldest first
+    uint64_t files_next_ticket = 0;        // of the next _begin
+    uint64_t files_decode_turn = 0;        // the ticket whose decode stage may run
+    std::mutex files_m;
+    std::condition_variable files_cv;
     // profiling
     bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
     int profiling = 0;                // 0 off, 1 every kernel, 2 only the dominant kernel (k_match)
@@ -572,8 +584,9 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
 extern "C" void melf_ctx_destroy(melf_ctx* c)
 {
     if (!c) return;
-    if (c->files_thread.joinable()) c->files_thread.join();
-    free(c->file_arena);
+    for (auto* j : c->files_jobs) { if (j->th.joinable()) j->th.join(); delete j; }
+    c->files_jobs.clear();
+    for (int a = 0; a < melf_ctx::NFJ; ++a) free(c->file_arena[a]);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int l = 0; l < melf_ctx::NLANES; ++l)   // resident mode and the split modes run whole calls on the lanes' own streams
@@ -1526,18 +1539,25 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
 
 // get_meter_values' inner loop for file names (meterelf/_api.py:22-33): the files are read here, on threads,
 // so that a scripting host pays one call per chunk instead of an open/read per file.
-static int jpeg_process_files_impl(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
-                                   melf_result* out_host, int32_t* status)
+struct FilesRead {  // what the read stage hands to the decode stage
+    std::vector<int> hs, ws, oks;
+    std::vector<size_t> off;
+    uint8_t* base = nullptr;
+};
+
+// Stage 1: the files' bytes into arena `slot` of the context, header check.  Touches nothing else of the context.
+static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
+                           melf_result* out_host, int32_t* status, FilesRead& R)
 {
     if (n == 0) return MELF_SUCCESS;
     if (!paths || !out_host || !status || !H_used || !W_used || n < 0 || n > 32768) return fail(MELF_ERR_INVALID, "bad argument");
-    // Two passes on the host pool: open + size, then -- the offsets known -- read into the context's ONE grow-only
-    // arena (no per-file allocation, no zero fill, no fresh pages to fault in after the first call: with sixteen
-    // threads faulting pages of the same address space the per-file buffers cost more than the reads).
+    // Two passes on the host pool: open + size, then -- the offsets known -- read into ONE grow-only arena (no per-file
+    // allocation, no zero fill, no fresh pages to fault in after the first call: with sixteen threads faulting pages
+    // of the same address space the per-file buffers cost more than the reads).
     static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<int> hs, ws, oks;
-    std::vector<size_t> off;
+    std::vector<int>&hs = R.hs, &ws = R.ws, &oks = R.oks;
+    std::vector<size_t>& off = R.off;
     try {
         hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0);
         off.assign((size_t)n + 1, 0);
@@ -1548,7 +1568,7 @@ static int jpeg_process_files_impl(melf_ctx* c, const char* const* paths, int n,
     const off_t max_file = (off_t)64 << 20;
     // pass 1: sizes only.  No descriptor stays open between the passes: a chunk of 1024 files would sit right at the
     // usual soft limit of 1024 open files, and a call may carry 32 768.
-    host_pool().run(n, [&](int i) {
+    io_pool().run(n, [&](int i) {
         struct stat sb;
         const bool regular = paths[i] && stat(paths[i], &sb) == 0 && S_ISREG(sb.st_mode);
         if (!regular || sb.st_size <= 0 || sb.st_size > max_file) {
@@ -1560,18 +1580,18 @@ static int jpeg_process_files_impl(melf_ctx* c, const char* const* paths, int n,
     });
     const auto t_opened = std::chrono::steady_clock::now();
     for (int i = 0; i < n; ++i) off[(size_t)i + 1] += off[i];
-    if (off[n] > c->file_arena_cap) {
+    if (off[n] > c->file_arena_cap[slot]) {
         const size_t want = off[n] + off[n] / 4 + (1u << 20);
-        uint8_t* q = (uint8_t*)realloc(c->file_arena, want);
+        uint8_t* q = (uint8_t*)realloc(c->file_arena[slot], want);
         if (!q) return fail(MELF_ERR_INVALID, "out of host memory");
-        c->file_arena = q;
-        c->file_arena_cap = want;
+        c->file_arena[slot] = q;
+        c->file_arena_cap[slot] = want;
     }
-    uint8_t* const base = c->file_arena;
+    uint8_t* const base = R.base = c->file_arena[slot];
     const auto t_arena = std::chrono::steady_clock::now();
     // pass 2: open, read the size seen in pass 1, close (a file that shrank meanwhile is unreadable; of one that grew
     // the decoder sees the first part and reports a corrupt stream: both go to the caller's host branch)
-    host_pool().run(n, [&](int i) {
+    io_pool().run(n, [&](int i) {
         if (status[i] != MELF_JPEG_OK) return;
         const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
         if (fd < 0) { status[i] = MELF_JPEG_UNREADABLE; return; }
@@ -1594,19 +1614,26 @@ static int jpeg_process_files_impl(melf_ctx* c, const char* const* paths, int n,
         fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): sizes %.2f ms, arena %.2f ms, open + read + probe %.2f ms\n", n, off[n] / 1e6,
                 ms(t0, t_opened), ms(t_opened, t_arena), ms(t_arena, std::chrono::steady_clock::now()));
     }
+    return MELF_SUCCESS;
+}
+
+// Stage 2: decode + reading path of the files stage 1 accepted (the context's GPU state: one call at a time).
+static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_used, melf_result* out_host, int32_t* status, const FilesRead& R)
+{
+    if (n == 0) return MELF_SUCCESS;
     // the batch shape: that of the first file the decoder takes
     int H = 0, W = 0;
     for (int i = 0; i < n && !H; ++i)
-        if (status[i] == MELF_JPEG_OK && oks[i]) { H = hs[i]; W = ws[i]; }
+        if (status[i] == MELF_JPEG_OK && R.oks[i]) { H = R.hs[i]; W = R.ws[i]; }
     *H_used = H; *W_used = W;
     std::vector<const uint8_t*> ptr;
     std::vector<size_t> len;
     std::vector<int> where;
     for (int i = 0; i < n; ++i) {
         if (status[i] != MELF_JPEG_OK) continue;
-        if (!oks[i]) { status[i] = hs[i] > 0 ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_CORRUPT; continue; }
-        if (hs[i] != H || ws[i] != W) { status[i] = MELF_JPEG_SIZE_MISMATCH; continue; }
-        ptr.push_back(base + off[i]); len.push_back(off[(size_t)i + 1] - off[i]); where.push_back(i);
+        if (!R.oks[i]) { status[i] = R.hs[i] > 0 ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_CORRUPT; continue; }
+        if (R.hs[i] != H || R.ws[i] != W) { status[i] = MELF_JPEG_SIZE_MISMATCH; continue; }
+        ptr.push_back(R.base + R.off[i]); len.push_back(R.off[(size_t)i + 1] - R.off[i]); where.push_back(i);
     }
     if (ptr.empty()) return MELF_SUCCESS;
     const int m = (int)ptr.size();
@@ -1621,41 +1648,80 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
                                        melf_result* out_host, int32_t* status)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
-    if (c->files_in_flight) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files: a _begin is waiting for its _end on this context");
-    return jpeg_process_files_impl(c, paths, n, H_used, W_used, out_host, status);
+    if (!c->files_jobs.empty()) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files: a _begin is waiting for its _end on this context");
+    try {
+        FilesRead R;
+        if (int rc = jpeg_files_read(c, 0, paths, n, H_used, W_used, out_host, status, R)) return rc;
+        return jpeg_files_decode(c, n, H_used, W_used, out_host, status, R);
+    } catch (const std::exception& e) {
+        return fail(MELF_ERR_INVALID, std::string("out of host memory: ") + e.what());
+    }
 }
 
 // The same call split in two for a scripting host: _begin returns at once, the work (file reads, Huffman tables,
-// upload, kernels, records) runs on a thread of the library, _end waits for it and returns its code.  Between the two
-// the caller can turn the PREVIOUS chunk's records into its own objects -- with a helper thread of the host language
-// instead, the interpreter lock's hand-over (5 ms in CPython) eats the overlap.  One call in flight per context; all
-// pointers must stay valid until _end; no other call on the context in between.
+// upload, kernels, records) runs on a thread of the library, _end waits for the OLDEST call begun and returns its
+// code.  Between the two the caller can turn the previous chunk's records into its own objects -- with a helper thread
+// of the host language instead, the interpreter lock's hand-over (5 ms in CPython) eats the overlap.  Up to two calls
+// may be in flight per context: the second one's files are read while the first one decodes (the decode stages run
+// one after the other, in the order of the _begin calls).  All pointers must stay valid until the call's _end; no
+// other call on the context while any is in flight.
 extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                                              melf_result* out_host, int32_t* status)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
-    if (c->files_in_flight) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_begin: a call is already in flight on this context");
-    if (c->files_thread.joinable()) c->files_thread.join();
-    c->files_rc = 0;
-    c->files_err.clear();
+    if ((int)c->files_jobs.size() >= melf_ctx::NFJ)
+        return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_begin: two calls are already in flight on this context");
+    melf_ctx::FilesJob* job = nullptr;
     try {
-        c->files_thread = std::thread([=]() {
-            c->files_rc = jpeg_process_files_impl(c, paths, n, H_used, W_used, out_host, status);
-            if (c->files_rc) c->files_err = g_err;  // this thread's message, for the thread that calls _end
+        job = new melf_ctx::FilesJob();
+        const uint64_t ticket = c->files_next_ticket;
+        job->th = std::thread([=]() {
+            // whatever happens in the stages, the ticket must be handed on: the next call's decode stage waits for it
+            int rc = MELF_SUCCESS;
+            FilesRead R;
+            try {
+                rc = jpeg_files_read(c, (int)(ticket % melf_ctx::NFJ), paths, n, H_used, W_used, out_host, status, R);
+            } catch (const std::exception& e) {
+                rc = fail(MELF_ERR_INVALID, std::string("out of host memory: ") + e.what());
+            }
+            {
+                std::unique_lock<std::mutex> lk(c->files_m);
+                c->files_cv.wait(lk, [&]() { return c->files_decode_turn == ticket; });
+            }
+            if (rc == MELF_SUCCESS) {
+                try {
+                    rc = jpeg_files_decode(c, n, H_used, W_used, out_host, status, R);
+                } catch (const std::exception& e) {
+                    rc = fail(MELF_ERR_INVALID, std::string("out of host memory: ") + e.what());
+                }
+            }
+            job->rc = rc;
+            if (rc) job->err = g_err;  // this thread's message, for the thread that calls _end
+            {
+                std::lock_guard<std::mutex> lk(c->files_m);
+                ++c->files_decode_turn;
+            }
+            c->files_cv.notify_all();
         });
     } catch (const std::exception& e) {
+        delete job;
         return fail(MELF_ERR_INVALID, std::string("cannot start a thread: ") + e.what());
     }
-    c->files_in_flight = true;
+    ++c->files_next_ticket;
+    c->files_jobs.push_back(job);
     return MELF_SUCCESS;
 }
 
 extern "C" int melf_jpeg_process_files_end(melf_ctx* c)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
-    if (!c->files_in_flight) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_end without _begin");
-    c->files_thread.join();
-    c->files_in_flight = false;
-    if (c->files_rc) return fail(c->files_rc, c->files_err);
+    if (c->files_jobs.empty()) return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_end without _begin");
+    melf_ctx::FilesJob* job = c->files_jobs.front();
+    c->files_jobs.pop_front();
+    job->th.join();
+    const int rc = job->rc;
+    const std::string err = job->err;
+    delete job;
+    if (rc) return fail(rc, err);
     return MELF_SUCCESS;
 }

@@ -101,4 +101,13 @@ inline WorkerPool& host_pool()
     return *pool;
 }
 
+// A second, smaller pool for the file reads of melf_jpeg_process_files: with two calls in flight the next chunk's
+// reads run WHILE the current chunk is prepared and decoded, and one pool (one parallel loop at a time) made each wait
+// for the other (read stage 0.9 -> 1.5 ms, the decode stage's host part 0.8 -> 2.2 ms).
+inline WorkerPool& io_pool()
+{
+    static WorkerPool* pool = new WorkerPool((int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency() / 2, 2u) - 1u, 7u));
+    return *pool;
+}
+
 }  // namespace melf

@@ -335,25 +335,35 @@ def test_get_meter_values_never_touches_the_host_decoder_for_fixtures(sd, monkey
 
 @pytest.mark.gpu
 def test_process_files_in_two_halves(tmp_path):
-    """melf_jpeg_process_files_begin / _end: the records of the one-piece call; a second _begin before _end and an
-    _end without _begin are refused; files of two frame sizes and an unreadable one are routed as in the one-piece call."""
+    """melf_jpeg_process_files_begin / _end: the records of the one-piece call; TWO calls may be in flight (the second one's
+    files are read while the first decodes) and come back in order; a third _begin, the one-piece call meanwhile and an _end
+    without _begin are refused; files of two frame sizes and an unreadable one are routed as in the one-piece call."""
     from meterelf_amd import MeterReader, _hip, _params
     reader = MeterReader(_params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml')))
     try:
         files = _files('sample-images1') + [str(tmp_path / 'missing.jpg')]
+        other = [f for f in reversed(_files('sample-images1'))][:40]
         (ref, ref_status, ref_hw) = reader.ctx.jpeg_process_files(files)
+        (ref2, ref2_status, ref2_hw) = reader.ctx.jpeg_process_files(other)
         with pytest.raises(_hip.HipError):
-            reader.ctx._files_pending = (None, None, (None, None), None, None)
+            reader.ctx._files_pending = [(None, None, (None, None), None, None)]
             reader.ctx.jpeg_process_files_end()  # nothing in flight
+        assert reader.ctx.files_in_flight() == 0
         reader.ctx.jpeg_process_files_begin(files)
-        pending = reader.ctx._files_pending
+        reader.ctx.jpeg_process_files_begin(other)
+        assert reader.ctx.files_in_flight() == 2
+        pending = list(reader.ctx._files_pending)
         with pytest.raises(_hip.HipError):
-            reader.ctx.jpeg_process_files_begin(files[:3])  # one call in flight per context
+            reader.ctx.jpeg_process_files_begin(files[:3])  # two calls in flight per context, not three
         with pytest.raises(_hip.HipError):
             reader.ctx.jpeg_process_files(files[:3])  # nor the one-piece call meanwhile
         reader.ctx._files_pending = pending
         (got, status, hw) = reader.ctx.jpeg_process_files_end()
+        (got2, status2, hw2) = reader.ctx.jpeg_process_files_end()
         assert hw == ref_hw and np.array_equal(status, ref_status)
+        assert hw2 == ref2_hw and np.array_equal(status2, ref2_status)
+        ok2 = status2 == _hip.JPEG_OK
+        assert ok2.any() and got2[ok2].tobytes() == ref2[ok2].tobytes()
         ok = status == _hip.JPEG_OK
         # the first file the decoder takes sets the call's frame size (the two 640 x 480 frames come first in
         # sample-images1); the 480 x 640 ones come back as 'another size' for a call of their own
@@ -365,6 +375,17 @@ def test_process_files_in_two_halves(tmp_path):
         reader.read_jpeg_paths_begin(files)
         (r2, ok2) = reader.read_jpeg_paths_end()
         assert np.array_equal(ok1, ok2) and r1[ok1].tobytes() == r2[ok2].tobytes() and ok1.sum() == len(files) - 1
+        # two lists in flight, the first with files of another size: its _end drains the second before it calls again
+        (q1, qok1) = reader.read_jpeg_paths_batch(other)
+        reader.read_jpeg_paths_begin(files)
+        reader.read_jpeg_paths_begin(other)
+        assert reader.jpeg_paths_in_flight() == 2
+        (r3, ok3) = reader.read_jpeg_paths_end()
+        assert reader.jpeg_paths_in_flight() == 1 and reader.ctx.files_in_flight() == 0  # collected early, kept for its _end
+        (r4, ok4) = reader.read_jpeg_paths_end()
+        assert reader.jpeg_paths_in_flight() == 0
+        assert np.array_equal(ok1, ok3) and r1[ok1].tobytes() == r3[ok3].tobytes()
+        assert np.array_equal(qok1, ok4) and q1[qok1].tobytes() == r4[ok4].tobytes()
     finally:
         reader.close()
 
