@@ -628,9 +628,22 @@ def jpeg_block(ctx, sample_dir, H, W):
     ctx.jpeg_process_batch(batch, H, W)
     jt = ctx.timings()
     ctx.set_profiling(0)
+    # the reference's own entry point on file NAMES (meterelf/_api.py:9-33): get_meter_values reads, decodes and reads out
+    # 1024-file chunks inside the library (two chunks in flight) and turns the records into MeterImageData objects
+    from meterelf_amd import get_meter_values, release_cached_contexts
+    pfile = os.path.join(GOLDEN, sample_dir, 'params.yml')
+    names = [jfiles[i % len(jfiles)] for i in range(16 * 1024)]
+    sum(1 for _ in get_meter_values(pfile, names[:2048]))  # warm-up: the context the API keeps between calls
+    tg0 = time.perf_counter()
+    n_api = sum(1 for r in get_meter_values(pfile, names) if r.error is None)
+    tg = time.perf_counter() - tg0
+    release_cached_contexts()
     return {'workload': '%d JPEG files (%d distinct %s fixtures, %.1f KB average) -> decode + full reading path, '
                         'file bytes in host memory to result records' % (JB, len(blobs), sample_dir, sum(map(len, blobs)) / len(blobs) / 1024),
             'files_per_s': round(JB / tj, 1), 'ms_per_call': round(tj * 1e3, 3),
+            'get_meter_values': {'files_per_s': round(len(names) / tg, 1), 'files': len(names), 'values_read': n_api,
+                                 'what': 'meterelf_amd.get_meter_values(params.yml, file names): the reference API, files read '
+                                         'from the page cache inside the library, MeterImageData objects out'},
             'kernel_ms_per_call': {k: round(ms, 4) for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
             'kernel_launches_per_call': {k: c for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
             'decoded_frames_equal_libjpeg_turbo': same, 'files_ok': int((jstatus == 0).sum())}

@@ -37,6 +37,8 @@ if h:
 j = d.get('jpeg_decode')
 if j:
     print('  jpeg %.0f files/s  %.2f ms/call  kernels per call %s' % (j['files_per_s'], j['ms_per_call'], j.get('kernel_ms_per_call') or j.get('kernel_ms')))
+    if j.get('get_meter_values'):
+        print('    get_meter_values(file names): %.0f files/s over %d files' % (j['get_meter_values']['files_per_s'], j['get_meter_values']['files']))
 c = d.get('cpu_baseline')
 if c:
     print('  cpu %.1f frames/s (1 core), %.0f (%d cores), parity mismatches %d' % (c['value'], c['all_cores']['value'], c['all_cores']['cores'], c['parity_mismatches_vs_gpu']))
