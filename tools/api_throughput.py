@@ -43,6 +43,11 @@ short = files
 files = files * 4
 got = run('GPU decode, chunks of 1024')
 assert got == ref * 4
+for batch in (2048, 4096):
+    os.environ['METERELF_BATCH'] = str(batch)
+    got = run('GPU decode, chunks of %d' % batch)
+    assert got == ref * 4
+os.environ['METERELF_BATCH'] = '1024'
 files = short
 
 # the decode + read call alone, file bytes already in memory
