@@ -1430,8 +1430,11 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
 // read_chunks: the reading path runs per chunk, right behind the chunk's decode on the chunk's stream (records into
 // c->d_results), instead of once over all frames afterwards -- its kernels then run beside the later chunks' Huffman
 // kernels, which leave most of the chip's throughput unused.
+// first_len > 0: the first `first_len` files form a chunk of their own (melf_jpeg_process_batch puts the files with very
+// few bits per block there: their Huffman kernel runs several times as long as a normal chunk's and, started first,
+// does so beside the other chunks' preparation and kernels instead of at the end of one of them).
 static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W, const int* rect,
-                                 std::vector<int32_t>& hstat, bool read_chunks)
+                                 std::vector<int32_t>& hstat, bool read_chunks, int first_len = 0)
 {
     // 512 files per chunk: the Huffman kernel's time hardly depends on the chunk size (critical path), so fewer, larger
     // chunks cost fewer launches; measured per 1024-file call: chunks of 128 / 256 / 512 files 6.1 / 3.4 / 2.8 ms
@@ -1461,8 +1464,10 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
     // every file's headers in one parallel pass; the chunks then only build tables and clean scans
     struct ParsedGuard { JpegParsed* p; ~ParsedGuard() { jpeg_parsed_free(p); } } parsed{jpeg_parse_files(data, sizes, n, H, W, hstat.data())};
     int k = 0;
-    for (int f0 = 0; f0 < n; f0 += chunk, ++k) {
-        const int m = n - f0 < chunk ? n - f0 : chunk, b = k % NJ;
+    for (int f0 = 0, m = 0; f0 < n; f0 += m, ++k) {
+        m = (k == 0 && first_len > 0) ? first_len : chunk;
+        if (m > n - f0) m = n - f0;
+        const int b = k % NJ;
         // the upload that last read this workspace's pinned stage buffer must be done before the host refills it
         if (k >= NJ) HIP_TRY(hipEventSynchronize(c->ev_jup[b]));
         if (int rc = jpeg_prepare_batch(ws[b], data + f0, sizes + f0, m, H, W, hstat.data() + f0, &err, parsed.p, f0)) return fail(rc, err);
@@ -1509,13 +1514,36 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     }
     static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
     const auto tc0 = std::chrono::steady_clock::now();
+    // Files with very few bits per block (a dark, flat frame: "DC difference 0, end of block" and nothing else) keep the
+    // Huffman kernel's wrongly-phased decoders in step with their garbage, so the truth crawls one segment per round and
+    // the image's workgroup runs ~3x as long as a normal one -- and with it the whole chunk's kernel.  They go FIRST, in a
+    // chunk of their own: its kernel then runs beside the other chunks' preparation and kernels.  Scheduling only: the
+    // records come back in the caller's order.
+    std::vector<int> perm;
+    std::vector<const uint8_t*> pdata;
+    std::vector<size_t> psizes;
+    int nsparse = 0;
+    if (!getenv("MELF_JPEG_NO_REORDER")) {
+        const double blocks = ((H + 7) / 8) * (double)((W + 7) / 8) * 1.5;
+        for (int i = 0; i < n; ++i) nsparse += (double)sizes[i] * 8.0 < 12.0 * blocks ? 1 : 0;
+        if (nsparse > 0 && nsparse < n) {
+            perm.resize(n); pdata.resize(n); psizes.resize(n);
+            int a = 0, b = nsparse;
+            for (int i = 0; i < n; ++i) perm[(double)sizes[i] * 8.0 < 12.0 * blocks ? a++ : b++] = i;
+            for (int i = 0; i < n; ++i) { pdata[i] = data[perm[i]]; psizes[i] = sizes[perm[i]]; }
+            data = pdata.data();
+            sizes = psizes.data();
+        } else {
+            nsparse = 0;
+        }
+    }
     std::vector<int32_t> hstat;
     // the reading path: ONE pass over all n frames behind the last chunk (the tuned match kernel in its full-batch layout);
     // MELF_JPEG_READ=chunk runs it per chunk on the chunk's stream instead (measured equal within noise)
     const char* rmode = getenv("MELF_JPEG_READ");
     const bool read_chunks = rmode && !strcmp(rmode, "chunk");
     if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
-    int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks);
+    int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks, nsparse);
     if (rc == MELF_SUCCESS && !read_chunks) {
         if (c->lanes > 1) rc = claim_all_lanes(c, c->stream);
         else rc = acquire_lane(c, c->stream, &c->active_lane);
@@ -1527,13 +1555,19 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     }
     // records and the decode status back, one synchronisation
     const auto tc1 = std::chrono::steady_clock::now();
-    HIP_TRY(hipMemcpyAsync(out_host, c->d_results, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
+    std::vector<melf_result> ordered;
+    melf_result* const recs = perm.empty() ? out_host : (ordered.resize(n), ordered.data());
+    HIP_TRY(hipMemcpyAsync(recs, c->d_results, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (trace)
-        fprintf(stderr, "[melf jpeg] pipelined call n=%d: %.2f ms enqueueing (host prepare + launches), %.2f ms waiting for the GPU\n", n,
-                std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+        fprintf(stderr, "[melf jpeg] pipelined call n=%d (%d sparse files first): %.2f ms enqueueing (host prepare + launches), %.2f ms waiting for the GPU\n", n,
+                nsparse, std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
-    for (int i = 0; i < n; ++i) status[i] = hstat[i] ? hstat[i] : (c->h_jstatus[i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
+    for (int i = 0; i < n; ++i) {
+        const int o = perm.empty() ? i : perm[i];
+        status[o] = hstat[i] ? hstat[i] : (c->h_jstatus[i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
+        if (!perm.empty()) out_host[o] = recs[i];
+    }
     return MELF_SUCCESS;
 }
 

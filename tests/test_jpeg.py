@@ -549,6 +549,37 @@ def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('nflat', [3, 90, 299])
+def test_flat_frames_are_scheduled_first_and_come_back_in_place(ctx, monkeypatch, nflat):
+    """Dark, flat frames (a few bits per block) hold the Huffman kernel for several times a normal frame's time; the
+    pipelined call decodes them in a first chunk of their own.  That is scheduling only: records and status in the
+    caller's order, equal to the one-piece call's, whatever the share of such files."""
+    from meterelf_amd import _hip
+    rng = np.random.default_rng(nflat)
+    good = [open(f, 'rb').read() for f in _files('sample-images1')]
+    (H, W, _ok, _why) = _hip.jpeg_probe(good[2])
+    good = [b for b in good if _hip.jpeg_probe(b)[:2] == (H, W)]
+    batch = [good[i] for i in rng.integers(0, len(good), 300)]
+    flat = [_encode(np.full((H, W, 3), int(v), np.uint8), quality=90) for v in (3, 9, 40)]
+    assert all(len(b) * 8 < 12 * (H // 8) * (W // 8) * 1.5 for b in flat) and not any(len(b) * 8 < 12 * (H // 8) * (W // 8) * 1.5 for b in good)
+    where = rng.choice(300, nflat, replace=False)
+    for (k, i) in enumerate(where):
+        batch[i] = flat[k % 3]
+    batch[7 if 7 not in where else 8] = good[0][:len(good[0]) // 3]  # a corrupt one among them
+    monkeypatch.setenv('MELF_JPEG_SERIAL', '1')
+    (ref, rstat) = ctx.jpeg_process_batch(batch, H, W)
+    monkeypatch.delenv('MELF_JPEG_SERIAL')
+    monkeypatch.setenv('MELF_JPEG_CHUNK', '128')
+    (got, gstat) = ctx.jpeg_process_batch(batch, H, W)
+    monkeypatch.setenv('MELF_JPEG_NO_REORDER', '1')
+    (got2, gstat2) = ctx.jpeg_process_batch(batch, H, W)
+    assert np.array_equal(gstat, rstat) and np.array_equal(gstat2, rstat)
+    ok = rstat == 0
+    assert ok.sum() == 299 and got[ok].tobytes() == ref[ok].tobytes() and got2[ok].tobytes() == ref[ok].tobytes()
+    assert (ref['status'][where] != _hip.FRAME_OK).all()  # a flat frame has no dials
+
+
+@pytest.mark.gpu
 def test_get_meter_values_keeps_its_context_between_calls(tmp_path):
     """Two calls with the same calibration share one GPU context (taken from and returned to the idle cache); an edited
     params.yml gets its own; a generator dropped half way returns a usable context; release_cached_contexts() empties
