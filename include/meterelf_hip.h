@@ -224,9 +224,9 @@ int melf_jpeg_process_batch(melf_ctx* ctx, const uint8_t* const* data, const siz
                             melf_result* out_host, int32_t* status);
 
 /* The same for n file names (the loop of get_meter_values, meterelf/_api.py:22-33): the library reads the files
- * (on threads), takes the frame size of the first file its decoder accepts as the batch's size (returned in
- * H_used / W_used) and processes every file of that size; the others come back with status 1 / 2 / 3 / 4 for the
- * caller to route (another call for another size, host decode for another format). */
+ * (on threads) and processes them frame size by frame size (a list may mix sizes; H_used / W_used return the size of
+ * the first file its decoder accepts); files it does not decode come back with status 1 / 2 / 4 for the caller to
+ * route (host decode for another format).  Status 3 is not used by this call. */
 int melf_jpeg_process_files(melf_ctx* ctx, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                             melf_result* out_host, int32_t* status);
 

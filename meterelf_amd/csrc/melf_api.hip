@@ -1651,30 +1651,44 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
     return MELF_SUCCESS;
 }
 
-// Stage 2: decode + reading path of the files stage 1 accepted (the context's GPU state: one call at a time).
+// Stage 2: decode + reading path of the files stage 1 accepted (the context's GPU state: one call at a time).  Files of
+// several frame sizes in one list (a camera that was turned at some point) are processed size by size, in the order in
+// which the sizes first appear; H_used / W_used report the first one.
 static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_used, melf_result* out_host, int32_t* status, const FilesRead& R)
 {
     if (n == 0) return MELF_SUCCESS;
-    // the batch shape: that of the first file the decoder takes
-    int H = 0, W = 0;
-    for (int i = 0; i < n && !H; ++i)
-        if (status[i] == MELF_JPEG_OK && R.oks[i]) { H = R.hs[i]; W = R.ws[i]; }
-    *H_used = H; *W_used = W;
-    std::vector<const uint8_t*> ptr;
-    std::vector<size_t> len;
-    std::vector<int> where;
+    *H_used = 0; *W_used = 0;
+    std::vector<char> todo(n, 0);
+    int left = 0;
     for (int i = 0; i < n; ++i) {
         if (status[i] != MELF_JPEG_OK) continue;
         if (!R.oks[i]) { status[i] = R.hs[i] > 0 ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_CORRUPT; continue; }
-        if (R.hs[i] != H || R.ws[i] != W) { status[i] = MELF_JPEG_SIZE_MISMATCH; continue; }
-        ptr.push_back(R.base + R.off[i]); len.push_back(R.off[(size_t)i + 1] - R.off[i]); where.push_back(i);
+        todo[i] = 1;
+        ++left;
     }
-    if (ptr.empty()) return MELF_SUCCESS;
-    const int m = (int)ptr.size();
-    std::vector<melf_result> res(m);
-    std::vector<int32_t> st(m);
-    if (int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data())) return rc;
-    for (int k = 0; k < m; ++k) { out_host[where[k]] = res[k]; status[where[k]] = st[k]; }
+    std::vector<const uint8_t*> ptr;
+    std::vector<size_t> len;
+    std::vector<int> where;
+    std::vector<melf_result> res;
+    std::vector<int32_t> st;
+    while (left > 0) {
+        int H = 0, W = 0;
+        ptr.clear(); len.clear(); where.clear();
+        for (int i = 0; i < n; ++i) {
+            if (!todo[i]) continue;
+            if (!H) { H = R.hs[i]; W = R.ws[i]; }
+            if (R.hs[i] != H || R.ws[i] != W) continue;
+            ptr.push_back(R.base + R.off[i]); len.push_back(R.off[(size_t)i + 1] - R.off[i]); where.push_back(i);
+            todo[i] = 0;
+        }
+        if (!*H_used) { *H_used = H; *W_used = W; }
+        const int m = (int)ptr.size();
+        left -= m;
+        res.resize(m);
+        st.resize(m);
+        if (int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data())) return rc;
+        for (int k = 0; k < m; ++k) { out_host[where[k]] = res[k]; status[where[k]] = st[k]; }
+    }
     return MELF_SUCCESS;
 }
 

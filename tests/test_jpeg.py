@@ -365,23 +365,33 @@ def test_process_files_in_two_halves(tmp_path):
         ok2 = status2 == _hip.JPEG_OK
         assert ok2.any() and got2[ok2].tobytes() == ref2[ok2].tobytes()
         ok = status == _hip.JPEG_OK
-        # the first file the decoder takes sets the call's frame size (the two 640 x 480 frames come first in
-        # sample-images1); the 480 x 640 ones come back as 'another size' for a call of their own
-        assert ok.sum() == 2 and (status == _hip.JPEG_SIZE_MISMATCH).sum() == len(files) - 3
+        # a list may mix frame sizes (the two 640 x 480 frames come first in sample-images1, 79 of 480 x 640 follow): the
+        # call processes them size by size and reports the first size
+        assert ok.sum() == len(files) - 1 and not (status == _hip.JPEG_SIZE_MISMATCH).any() and hw == (480, 640)
         assert got[ok].tobytes() == ref[ok].tobytes()
         assert status[-1] == _hip.JPEG_UNREADABLE
+        by_size = {}
+        for (i, f) in enumerate(files[:-1]):
+            by_size.setdefault(_hip.jpeg_probe(open(f, 'rb').read())[:2], []).append(i)
+        assert len(by_size) == 2
+        for ((h, w), idx) in by_size.items():  # each size's records: those of a call with that size's files alone
+            (alone, st_alone) = reader.ctx.jpeg_process_batch([open(files[i], 'rb').read() for i in idx], h, w)
+            assert (st_alone == 0).all() and alone.tobytes() == got[idx].tobytes()
         # the reader's pair: every size gets its call, like read_jpeg_paths_batch
         (r1, ok1) = reader.read_jpeg_paths_batch(files)
         reader.read_jpeg_paths_begin(files)
         (r2, ok2) = reader.read_jpeg_paths_end()
         assert np.array_equal(ok1, ok2) and r1[ok1].tobytes() == r2[ok2].tobytes() and ok1.sum() == len(files) - 1
-        # two lists in flight, the first with files of another size: its _end drains the second before it calls again
+        # two lists in flight; drain_jpeg_paths() (what get_meter_values does before it sends host-decoded frames through
+        # the context) collects them early and keeps the results for their _end calls
         (q1, qok1) = reader.read_jpeg_paths_batch(other)
         reader.read_jpeg_paths_begin(files)
         reader.read_jpeg_paths_begin(other)
         assert reader.jpeg_paths_in_flight() == 2
         (r3, ok3) = reader.read_jpeg_paths_end()
-        assert reader.jpeg_paths_in_flight() == 1 and reader.ctx.files_in_flight() == 0  # collected early, kept for its _end
+        assert reader.jpeg_paths_in_flight() == 1 and reader.ctx.files_in_flight() == 1
+        reader.drain_jpeg_paths()
+        assert reader.jpeg_paths_in_flight() == 1 and reader.ctx.files_in_flight() == 0
         (r4, ok4) = reader.read_jpeg_paths_end()
         assert reader.jpeg_paths_in_flight() == 0
         assert np.array_equal(ok1, ok3) and r1[ok1].tobytes() == r3[ok3].tobytes()
