@@ -20,7 +20,7 @@ from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional
 
 from . import _debug, _params
-from ._engine import MeterReader, make_blob, records_to_python, result_to_python
+from ._engine import MeterReader, make_blob, records_to_items, records_to_python, result_to_python
 from ._image import ImageFile
 from .exceptions import ImageProcessingError
 
@@ -157,10 +157,18 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                 following = begun[0] if begun else None
             else:
                 following = next(chunks, None)
+            items = None  # the chunk's result objects, when every file went through the GPU decoder
             if isinstance(raw, tuple):
-                converted = records_to_python(raw[0], raw[1], reader.dial_names, chunk)
+                if not _debug.DEBUG and all(raw[1]):
+                    items = records_to_items(raw[0], raw[1], reader.dial_names, chunk, MeterImageData)
+                else:
+                    converted = records_to_python(raw[0], raw[1], reader.dial_names, chunk)
             elif raw is not None:
                 converted = raw
+            if items is not None:
+                yield from items
+                chunk = following
+                continue
             on_host = [i for i in range(len(chunk)) if converted[i] is None]
             if on_host:
                 frames, where = [], []
