@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -280,8 +281,17 @@ struct melf_ctx {
     JpegWorkspace* jpeg_ring[NJ] = {};  // [0] is unused: slot 0 is `jpeg` itself
     hipStream_t jpeg_stream[NJ] = {};   // [0] unused: slot 0 decodes on the context's stream
     hipEvent_t ev_jup[NJ] = {}, ev_jdec[NJ] = {};
-    int32_t* h_jstatus = nullptr;
-    size_t jstatus_cap = 0;
+    // per CALL slot (two calls of the file-name API may overlap: the second one's preparation and uploads run while the
+    // first one's kernels do): the decoded frames, the records, the files' decode status in pinned memory, "call done"
+    static const int NJC = 2;
+    uint8_t* d_jframes[NJC] = {};
+    size_t jframes_cap[NJC] = {};
+    melf_result* d_jresults[NJC] = {};
+    size_t jresults_cap[NJC] = {};
+    int32_t* h_jstatus[NJC] = {};
+    size_t jstatus_cap[NJC] = {};
+    hipEvent_t ev_jcall[NJC] = {};
+    uint64_t jpeg_chunk_seq = 0;       // chunks decoded since the context was created: chunk q uses ring slot q % NJ
     // melf_jpeg_process_files: the files' bytes (grow-only: no per-file allocation, no zero fill, and after the first
     // call no fresh pages to fault in), and the call in flight of the begin / end pair
     // Up to NFJ begin / end calls in flight: each on its own thread, which READS its files at once (into the arena of its
@@ -625,7 +635,11 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
         if (c->ev_jup[b]) hipEventDestroy(c->ev_jup[b]);
         if (c->ev_jdec[b]) hipEventDestroy(c->ev_jdec[b]);
     }
-    if (c->h_jstatus) hipHostFree(c->h_jstatus);
+    for (int a = 0; a < melf_ctx::NJC; ++a) {
+        if (c->h_jstatus[a]) hipHostFree(c->h_jstatus[a]);
+        hipFree(c->d_jframes[a]); hipFree(c->d_jresults[a]);
+        if (c->ev_jcall[a]) hipEventDestroy(c->ev_jcall[a]);
+    }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1419,12 +1433,20 @@ extern "C" int melf_jpeg_decode_batch(melf_ctx* c, const uint8_t* const* data, c
     return MELF_SUCCESS;
 }
 
-// Decode of n files into c->d_stage_in in chunks, pipelined: while chunk k's kernels run (on one of two decode streams),
+// melf_jpeg_process_files_begin: the call slot of the thread's call, and what to do once everything of the call is
+// ENQUEUED (the next call in flight may then start its own preparation and enqueue behind it).  NULL: a plain call.
+static thread_local int tl_jpeg_slot = 0;
+static thread_local std::function<void()>* tl_jpeg_enqueued = nullptr;
+
+// Decode of n files into d_frames in chunks, pipelined: while chunk k's kernels run (on one of two decode streams),
 // the host parses chunk k + 1, builds its Huffman data, cleans its scan bytes into the other workspace's pinned stage
 // buffer, and the copy stream uploads it.  Serial, a 1024-file call spent more than half its time in host preparation,
 // the upload and the status read-back with the GPU idle.  The Huffman kernel is bound by its critical path (every
 // workgroup walks the same ~12 synchronisation rounds whatever the batch size: 0.8 ms for 256 files, 1.07 ms for 1024),
-// so consecutive chunks go round a ring of NJ workspaces and streams and their kernels overlap on the GPU.  Leaves the per-file status in c->h_jstatus (pinned) once `done` fires.
+// so consecutive chunks go round a ring of NJ workspaces and streams and their kernels overlap on the GPU.  Leaves the per-file
+// status in h_status (pinned) once the context's stream has passed the point this function leaves it at.
+// overlapped: another call's kernels may still be running (melf_jpeg_process_files_begin, two calls in flight): nothing
+// here waits for the context's stream; what protects a ring slot is its own pair of events, across calls as within one.
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
                             void* d_results, melf_result* out_host, hipStream_t st, const int* rect, int row_stride);
 // read_chunks: the reading path runs per chunk, right behind the chunk's decode on the chunk's stream (records into
@@ -1434,7 +1456,8 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
 // few bits per block there: their Huffman kernel runs several times as long as a normal chunk's and, started first,
 // does so beside the other chunks' preparation and kernels instead of at the end of one of them).
 static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W, const int* rect,
-                                 std::vector<int32_t>& hstat, bool read_chunks, int first_len = 0)
+                                 std::vector<int32_t>& hstat, bool read_chunks, int first_len, uint8_t* d_frames, melf_result* d_results,
+                                 int32_t* h_status, bool overlapped)
 {
     // 512 files per chunk: the Huffman kernel's time hardly depends on the chunk size (critical path), so fewer, larger
     // chunks cost fewer launches; measured per 1024-file call: chunks of 128 / 256 / 512 files 6.1 / 3.4 / 2.8 ms
@@ -1446,51 +1469,55 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
         if (!c->ev_jup[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jup[b], hipEventDisableTiming));
         if (!c->ev_jdec[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jdec[b], hipEventDisableTiming));
     }
-    if (c->jstatus_cap < (size_t)n) {
-        if (c->h_jstatus) HIP_TRY(hipHostFree(c->h_jstatus));
-        c->h_jstatus = nullptr; c->jstatus_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&c->h_jstatus, (size_t)n * sizeof(int32_t) + 64, hipHostMallocDefault));
-        c->jstatus_cap = (size_t)n;
-    }
     hstat.assign(n, 0);
     hipStream_t dstream[NJ];
     JpegWorkspace** ws[NJ];
     for (int b = 0; b < NJ; ++b) { dstream[b] = b ? c->jpeg_stream[b] : c->stream; ws[b] = b ? &c->jpeg_ring[b] : &c->jpeg; }
-    // the other streams start behind whatever the context's stream holds (the previous call's kernels read the frames)
-    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-    for (int b = 1; b < NJ; ++b) HIP_TRY(hipStreamWaitEvent(c->jpeg_stream[b], c->ev_fork, 0));
-    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_fork, 0));
+    if (!overlapped) {
+        // the other streams start behind whatever the context's stream holds (a caller's earlier work on it)
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        for (int b = 1; b < NJ; ++b) HIP_TRY(hipStreamWaitEvent(c->jpeg_stream[b], c->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_fork, 0));
+    }
     std::string err;
+    const uint64_t seq0 = c->jpeg_chunk_seq;
+    int k = 0;
+    // the ring position moves on past every chunk this call touched, also when it fails half way through one
+    struct SeqGuard { melf_ctx* c; uint64_t seq0; const int* k; bool done; ~SeqGuard() { c->jpeg_chunk_seq = seq0 + (uint64_t)*k + (done ? 0 : 1); } } seq_guard{c, seq0, &k, false};
     // every file's headers in one parallel pass; the chunks then only build tables and clean scans
     struct ParsedGuard { JpegParsed* p; ~ParsedGuard() { jpeg_parsed_free(p); } } parsed{jpeg_parse_files(data, sizes, n, H, W, hstat.data())};
-    int k = 0;
     for (int f0 = 0, m = 0; f0 < n; f0 += m, ++k) {
         m = (k == 0 && first_len > 0) ? first_len : chunk;
         if (m > n - f0) m = n - f0;
-        const int b = k % NJ;
+        const uint64_t seq = seq0 + (uint64_t)k;
+        const int b = (int)(seq % NJ);
         // the upload that last read this workspace's pinned stage buffer must be done before the host refills it
-        if (k >= NJ) HIP_TRY(hipEventSynchronize(c->ev_jup[b]));
+        if (seq >= (uint64_t)NJ) HIP_TRY(hipEventSynchronize(c->ev_jup[b]));
         if (int rc = jpeg_prepare_batch(ws[b], data + f0, sizes + f0, m, H, W, hstat.data() + f0, &err, parsed.p, f0)) return fail(rc, err);
         // ... and the kernels that last read its device buffers before the upload overwrites them
-        if (k >= NJ) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_jdec[b], 0));
+        if (seq >= (uint64_t)NJ) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_jdec[b], 0));
         if (int rc = jpeg_upload_batch(*ws[b], m, c->copy_stream, &err)) return fail(rc, err);
         HIP_TRY(hipEventRecord(c->ev_jup[b], c->copy_stream));
         HIP_TRY(hipStreamWaitEvent(dstream[b], c->ev_jup[b], 0));
         JpegTimers t{c, dstream[b], {}, {false, false, false}};
-        if (int rc = jpeg_decode_batch_kernels(*ws[b], m, H, W, c->d_stage_in + (size_t)f0 * H * W * 3, dstream[b], &err, jpeg_timer_hook, &t, rect))
+        if (int rc = jpeg_decode_batch_kernels(*ws[b], m, H, W, d_frames + (size_t)f0 * H * W * 3, dstream[b], &err, jpeg_timer_hook, &t, rect))
             return fail(rc, err);
-        HIP_TRY(hipMemcpyAsync(c->h_jstatus + f0, jpeg_device_status(*ws[b]), (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, dstream[b]));
+        HIP_TRY(hipMemcpyAsync(h_status + f0, jpeg_device_status(*ws[b]), (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, dstream[b]));
         if (read_chunks) {
             c->active_lane = k % melf_ctx::NLANES;
             if (int rc = claim_lane(c, c->active_lane, dstream[b])) return rc;
-            if (int rc = process_batch_on(c, c->d_stage_in + (size_t)f0 * H * W * 3, m, H, W, (size_t)H * W * 3, c->d_results + f0, nullptr,
+            if (int rc = process_batch_on(c, d_frames + (size_t)f0 * H * W * 3, m, H, W, (size_t)H * W * 3, d_results + f0, nullptr,
                                           dstream[b], nullptr, 0))
                 return rc;
         }
         HIP_TRY(hipEventRecord(c->ev_jdec[b], dstream[b]));
     }
-    // the context's stream continues when both decode streams are done
-    for (int b = 1; b < NJ && b < k; ++b) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_jdec[b], 0));
+    // the context's stream continues when this call's decode streams are done (a slot's latest record covers its earlier ones)
+    for (int q = k > NJ ? k - NJ : 0; q < k; ++q) {
+        const int b = (int)((seq0 + (uint64_t)q) % NJ);
+        if (b) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_jdec[b], 0));
+    }
+    seq_guard.done = true;
     return MELF_SUCCESS;
 }
 
@@ -1503,12 +1530,17 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
         return fail(MELF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)n * H * W * 3;
-    HIP_TRY(hipStreamSynchronize(c->stream));   // the previous call's kernels may still read d_stage_in / the stage buffers
-    if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
+    // overlapped: called on the thread of a melf_jpeg_process_files_begin call while the previous such call may still have
+    // kernels running (its buffers are another call slot's; the ring slots are guarded by their events)
+    const bool overlapped = tl_jpeg_enqueued != nullptr;
+    const int cs = overlapped ? tl_jpeg_slot % melf_ctx::NJC : 0;
     // the reading path only looks at the meter_rect crop: IDCT and colour conversion are limited to it
     const int rect[4] = {c->P.rect_x0, c->P.rect_y0, c->P.rect_x1, c->P.rect_y1};
     const bool serial = getenv("MELF_JPEG_SERIAL") != nullptr;   // A/B and tests: the one-piece path
+    if (!overlapped) HIP_TRY(hipStreamSynchronize(c->stream));   // a caller's earlier work on the context's stream
     if (serial || n <= 64) {
+        if (overlapped) HIP_TRY(hipDeviceSynchronize());   // the one-piece path shares its buffers with every call: alone on the GPU
+        if (int rc = grow(&c->d_stage_in, &c->stage_in_cap, bytes)) return rc;
         if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, c->d_stage_in, status, rect)) return rc;
         return melf_process_batch_dev(c, c->d_stage_in, n, H, W, (size_t)H * W * 3, nullptr, out_host, c->stream);
     }
@@ -1542,12 +1574,22 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     // MELF_JPEG_READ=chunk runs it per chunk on the chunk's stream instead (measured equal within noise)
     const char* rmode = getenv("MELF_JPEG_READ");
     const bool read_chunks = rmode && !strcmp(rmode, "chunk");
-    if (int rc = grow(&c->d_results, &c->results_cap, (size_t)n)) return rc;
-    int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks, nsparse);
+    if (int rc = grow(&c->d_jframes[cs], &c->jframes_cap[cs], bytes)) return rc;
+    if (int rc = grow(&c->d_jresults[cs], &c->jresults_cap[cs], (size_t)n)) return rc;
+    if (c->jstatus_cap[cs] < (size_t)n) {
+        if (c->h_jstatus[cs]) HIP_TRY(hipHostFree(c->h_jstatus[cs]));
+        c->h_jstatus[cs] = nullptr; c->jstatus_cap[cs] = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->h_jstatus[cs], (size_t)n * sizeof(int32_t) + 64, hipHostMallocDefault));
+        c->jstatus_cap[cs] = (size_t)n;
+    }
+    if (!c->ev_jcall[cs]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jcall[cs], hipEventDisableTiming));
+    int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks, nsparse, c->d_jframes[cs], c->d_jresults[cs], c->h_jstatus[cs],
+                                   overlapped);
     if (rc == MELF_SUCCESS && !read_chunks) {
         if (c->lanes > 1) rc = claim_all_lanes(c, c->stream);
         else rc = acquire_lane(c, c->stream, &c->active_lane);
-        if (rc == MELF_SUCCESS) rc = process_batch_on(c, c->d_stage_in, n, H, W, (size_t)H * W * 3, c->d_results, nullptr, c->stream, nullptr, 0);
+        if (rc == MELF_SUCCESS)
+            rc = process_batch_on(c, c->d_jframes[cs], n, H, W, (size_t)H * W * 3, c->d_jresults[cs], nullptr, c->stream, nullptr, 0);
     }
     if (rc != MELF_SUCCESS) {
         (void)hipDeviceSynchronize();   // nothing of the aborted pipeline may outlive the call
@@ -1557,15 +1599,19 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     const auto tc1 = std::chrono::steady_clock::now();
     std::vector<melf_result> ordered;
     melf_result* const recs = perm.empty() ? out_host : (ordered.resize(n), ordered.data());
-    HIP_TRY(hipMemcpyAsync(recs, c->d_results, (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(recs, c->d_jresults[cs], (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_jcall[cs], c->stream));
+    // everything of this call is enqueued: from here on it touches only its own slot's buffers, and the next call in flight
+    // may prepare and enqueue behind it
+    if (overlapped) (*tl_jpeg_enqueued)();
+    HIP_TRY(hipEventSynchronize(c->ev_jcall[cs]));
     if (trace)
         fprintf(stderr, "[melf jpeg] pipelined call n=%d (%d sparse files first): %.2f ms enqueueing (host prepare + launches), %.2f ms waiting for the GPU\n", n,
                 nsparse, std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
     for (int i = 0; i < n; ++i) {
         const int o = perm.empty() ? i : perm[i];
-        status[o] = hstat[i] ? hstat[i] : (c->h_jstatus[i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
+        status[o] = hstat[i] ? hstat[i] : (c->h_jstatus[cs][i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
         if (!perm.empty()) out_host[o] = recs[i];
     }
     return MELF_SUCCESS;
@@ -1654,7 +1700,8 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
 // Stage 2: decode + reading path of the files stage 1 accepted (the context's GPU state: one call at a time).  Files of
 // several frame sizes in one list (a camera that was turned at some point) are processed size by size, in the order in
 // which the sizes first appear; H_used / W_used report the first one.
-static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_used, melf_result* out_host, int32_t* status, const FilesRead& R)
+static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_used, melf_result* out_host, int32_t* status, const FilesRead& R,
+                             std::function<void()>* enqueued = nullptr, int call_slot = 0)
 {
     if (n == 0) return MELF_SUCCESS;
     *H_used = 0; *W_used = 0;
@@ -1686,7 +1733,12 @@ static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_use
         left -= m;
         res.resize(m);
         st.resize(m);
-        if (int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data())) return rc;
+        // the LAST group's call hands the context on as soon as it has enqueued everything (melf_jpeg_process_batch)
+        tl_jpeg_enqueued = left == 0 ? enqueued : nullptr;
+        tl_jpeg_slot = call_slot;
+        const int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data());
+        tl_jpeg_enqueued = nullptr;
+        if (rc) return rc;
         for (int k = 0; k < m; ++k) { out_host[where[k]] = res[k]; status[where[k]] = st[k]; }
     }
     return MELF_SUCCESS;
@@ -1736,20 +1788,29 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
                 std::unique_lock<std::mutex> lk(c->files_m);
                 c->files_cv.wait(lk, [&]() { return c->files_decode_turn == ticket; });
             }
+            // the turn goes on as soon as this call has ENQUEUED all its GPU work (the next call then prepares and enqueues
+            // while this one's kernels run), at the latest when the call is over
+            bool released = false;
+            std::function<void()> release = [&]() {
+                if (released) return;
+                released = true;
+                {
+                    std::lock_guard<std::mutex> lk(c->files_m);
+                    ++c->files_decode_turn;
+                }
+                c->files_cv.notify_all();
+            };
             if (rc == MELF_SUCCESS) {
                 try {
-                    rc = jpeg_files_decode(c, n, H_used, W_used, out_host, status, R);
+                    rc = jpeg_files_decode(c, n, H_used, W_used, out_host, status, R, getenv("MELF_FILES_NO_OVERLAP") ? nullptr : &release,
+                                           (int)(ticket % melf_ctx::NJC));
                 } catch (const std::exception& e) {
                     rc = fail(MELF_ERR_INVALID, std::string("out of host memory: ") + e.what());
                 }
             }
             job->rc = rc;
             if (rc) job->err = g_err;  // this thread's message, for the thread that calls _end
-            {
-                std::lock_guard<std::mutex> lk(c->files_m);
-                ++c->files_decode_turn;
-            }
-            c->files_cv.notify_all();
+            release();
         });
     } catch (const std::exception& e) {
         delete job;
