@@ -138,6 +138,29 @@ __device__ __forceinline__ uint32_t load_px3(const uint8_t* p, const uint8_t* bu
     return v >> (8u * back);
 }
 
+// The same for a lane's COLUMN of pixels, col + row_off for wave-uniform row offsets: the address arithmetic of
+// load_px3 (a 64-bit multiply-add, a 64-bit compare against the buffer's start, a select) cost ten issue slots per window
+// row and lane, a tenth of the kernel's vector instructions.  Here the direction is fixed per LANE: the dword starts one
+// byte early, except in the lane whose column begins at the buffer's first byte, which reads forward in every row (one
+// byte into its right-hand neighbour: inside the buffer, rows being at least two pixels wide -- melf_ctx_create refuses
+// a one-pixel-wide template).  Per row: one 64-bit add, the load, one shift.
+struct PxColumn {
+    const uint8_t* first;  // col - 1, or col in the lane at the buffer's start
+    uint32_t shift;        // 8, or 0 there
+};
+__device__ __forceinline__ PxColumn px_column(const uint8_t* col, const uint8_t* buffer_start)
+{
+    const bool at_start = col == buffer_start;
+    return PxColumn{at_start ? col : col - 1, at_start ? 0u : 8u};
+}
+__device__ __forceinline__ uint32_t load_px3_row(const PxColumn& c, size_t row_off)
+{
+    asm("" : "+s"(row_off));  // the offset stays a scalar product: otherwise the compiler folds it into one 64-bit vector multiply-add per row
+    uint32_t v;
+    __builtin_memcpy(&v, c.first + row_off, 4);
+    return v >> c.shift;
+}
+
 // packed 16-bit arithmetic on two values per register (v_pk_*_u16)
 typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
@@ -264,11 +287,14 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     const bool corevalid = lane < 25 && coreX >= 0 && coreX < P.tw && coreY >= 0 && coreY < P.th;
     const uint32_t corepx = load_px3(origin + (size_t)min(max(coreY, 0), P.th - 1) * rstride + (size_t)min(max(coreX, 0), P.tw - 1) * 3, src.base);
     uint32_t pxv[NR];
+    const PxColumn pcol = px_column(origin + (size_t)Xc * 3, src.base);
+    const int th1 = __builtin_amdgcn_readfirstlane(P.th - 1);
+    const int rs_u = __builtin_amdgcn_readfirstlane((int)rstride);  // uniform: the row offsets below are scalar products
     if (!FROM_HLS) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-            const int Y = min(max(wy0 + k, 0), P.th - 1);
-            pxv[k] = load_px3(origin + (size_t)Y * rstride + (size_t)Xc * 3, src.base);
+            const int Y = min(max(wy0 + k, 0), th1);
+            pxv[k] = load_px3_row(pcol, (size_t)((int64_t)Y * rs_u));
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -297,8 +323,8 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
             uint32_t pxe[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int Y = min(max(wy0 + yc + k, 0), P.th - 1);
-                pxe[k] = load_px3(origin + (size_t)Y * rstride + (size_t)Xc * 3, src.base);
+                const int Y = min(max(wy0 + yc + k, 0), th1);
+                pxe[k] = load_px3_row(pcol, (size_t)((int64_t)Y * rs_u));
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

@@ -64,7 +64,7 @@ static int check_params(const melf_params* p)
     if (!p) return fail(MELF_ERR_INVALID, "params is NULL");
     if (p->abi_version != MELF_ABI_VERSION) return fail(MELF_ERR_INVALID, "melf_params.abi_version mismatch");
     if (p->ndials < 1 || p->ndials > MELF_MAX_DIALS) return fail(MELF_ERR_INVALID, "ndials must be 1..8");
-    if (p->th < 1 || p->tw < 1) return fail(MELF_ERR_INVALID, "bad template size");
+    if (p->th < 1 || p->tw < 2) return fail(MELF_ERR_INVALID, "bad template size (at least 1 row of 2 pixels)");
     return MELF_SUCCESS;
 }
 
