@@ -206,6 +206,146 @@ def test_records_to_python_equals_per_record_conversion():
             assert got[i][1].filename == err.filename
 
 
+def test_records_to_items_equals_per_record_conversion():
+    """The fused conversion of an all-GPU chunk (records -> MeterImageData in one comprehension) gives what the
+    record-by-record path gives: same values, key order, float types, error classes and messages."""
+    from meterelf_amd import MeterImageData
+    names = ['0.0001', '0.001', '0.01', '0.1']
+    rng = np.random.default_rng(6)
+    n = 200
+    recs = np.zeros(n, _hip.RESULT_DTYPE)
+    recs['status'] = rng.choice([0, 0, 0, 0, 1, 2, 3], n)
+    recs['pos'] = rng.uniform(0, 10, (n, _hip.MAX_DIALS))
+    recs['value'] = rng.uniform(0, 1000, n)
+    recs['match_val'] = rng.uniform(0, 2e7, n).astype(np.float32)
+    recs['failed_dial'] = rng.integers(0, 4, n)
+    recs['unreadable_mask'] = rng.integers(1, 16, n)
+    files = ['f%d' % i for i in range(n)]
+    for ok in ([True] * n, (rng.integers(0, 6, n) > 0).tolist()):
+        got = _engine.records_to_items(recs, ok, names, files, MeterImageData)
+        for i in range(n):
+            if not ok[i]:
+                assert got[i] is None
+                continue
+            (vals, err) = _engine.result_to_python(recs[i], names, files[i])
+            item = got[i]
+            assert item.filename == files[i] and item.meter_values == vals and list(item.meter_values) == list(vals)
+            assert item.value == vals.get('value') and all(type(v) is float for v in item.meter_values.values())
+            assert (item.error is None) == (err is None)
+            if err is not None:
+                assert type(item.error) is type(err) and item.error.get_message() == err.get_message()
+    three = _engine.records_to_items(recs[:5], [True] * 5, names[:3], files[:5], MeterImageData)  # not four dials: no 'value'
+    assert all('value' not in it.meter_values for it in three if it.error is None)
+
+
+class _TwoInFlightReader:
+    """A CPU stand-in with the file-name surface of MeterReader: up to two lists in flight, drained before anything else
+    uses it (the contract get_meter_values relies on); readings come from the file NAME."""
+    log = []
+
+    def __init__(self, params, device=0, blob=None):
+        self.dial_names = params.dial_names
+        self.flight = []
+        self.collected = []
+        self.closed = False
+
+    def close(self):
+        assert not self.flight, 'closed with a list in flight'
+        self.closed = True
+        _TwoInFlightReader.log.append('close')
+
+    def _records(self, paths):
+        r = np.zeros(len(paths), _hip.RESULT_DTYPE)
+        ok = np.ones(len(paths), bool)
+        for (i, p) in enumerate(paths):
+            k = int(os.path.basename(p).split('.')[0][1:])
+            if k % 50 == 17:
+                ok[i] = False          # a file for the host branch
+            elif k % 7 == 3:
+                r[i]['status'] = _hip.FRAME_DIALS_NOT_FOUND
+                r[i]['match_val'] = k
+            else:
+                r[i]['pos'][:4] = [k % 10, (k // 10) % 10, (k // 100) % 10, (k // 1000) % 10]
+                r[i]['value'] = float(k)
+        return (r, ok)
+
+    def read_jpeg_paths_batch(self, paths):
+        assert not self.flight, 'one-piece call with a list in flight'
+        return self._records(paths)
+
+    def read_jpeg_paths_begin(self, paths):
+        assert len(self.flight) < 2, 'third list in flight'
+        self.flight.append(list(paths))
+        _TwoInFlightReader.log.append('begin %d' % len(paths))
+
+    def read_jpeg_paths_end(self):
+        paths = self.collected.pop(0) if self.collected else self.flight.pop(0)
+        _TwoInFlightReader.log.append('end')
+        return self._records(paths)
+
+    def jpeg_paths_in_flight(self):
+        return len(self.flight) + len(self.collected)
+
+    def drain_jpeg_paths(self):
+        self.collected += self.flight
+        self.flight = []
+        _TwoInFlightReader.log.append('drain')
+
+    def discard_jpeg_paths(self):
+        self.flight = []
+        self.collected = []
+        _TwoInFlightReader.log.append('discard')
+
+    def read_many(self, images, cropped=None):
+        assert not self.flight, 'host-decoded frames with a list in flight'
+        r = np.zeros(len(images), _hip.RESULT_DTYPE)
+        for (i, img) in enumerate(images):
+            r[i]['pos'][:4] = [1, 2, 3, 4]
+            r[i]['value'] = float(img[0, 0, 0]) + 0.5
+        return list(r)
+
+
+def test_get_meter_values_keeps_two_chunks_in_flight(tmp_path, monkeypatch):
+    """The loop of get_meter_values with a reader that takes two lists in flight: results in input order, the next chunks
+    begun before a chunk's records are touched, the reader drained before host-decoded frames go through it, nothing left
+    in flight when the consumer stops early or the list ends."""
+    from PIL import Image
+
+    from meterelf_amd import _api
+    monkeypatch.setattr(_api, 'MeterReader', _TwoInFlightReader)
+    monkeypatch.setenv('METERELF_BATCH', '100')
+    pfile = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
+    files = []
+    for k in range(1, 731):
+        f = str(tmp_path / ('f%d.png' % k))
+        if k % 50 == 17:  # the host branch really decodes these
+            Image.fromarray(np.full((4, 4, 3), k % 250, np.uint8)).save(f)
+        files.append(f)
+    _TwoInFlightReader.log = []
+    got = list(_api.get_meter_values(pfile, files))
+    assert [r.filename for r in got] == files
+    for (k, r) in zip(range(1, 731), got):
+        if k % 50 == 17:
+            assert r.error is None and r.value == (k % 250) + 0.5      # through read_many (the PNG's red channel + 0.5)
+        elif k % 7 == 3:
+            assert r.value is None and 'Dials not found' in r.error.get_message()
+        else:
+            assert r.error is None and r.value == float(k) and r.meter_values[list(r.meter_values)[0]] == float(k % 10)
+    log = _TwoInFlightReader.log
+    assert log.count('close') == 1 and log[-1] == 'close'
+    assert log.count('begin 100') == 6 and log.count('begin 30') == 1      # chunks 2..8 went through begin / end
+    assert log.count('drain') >= 6                                          # every chunk with a host-branch file
+    # two lists are begun right after the first chunk came back, before its records are used
+    assert log[:2] == ['begin 100', 'begin 100']
+    # a consumer that stops early leaves nothing in flight
+    _TwoInFlightReader.log = []
+    gen = _api.get_meter_values(pfile, files)
+    first = [next(gen) for _ in range(150)]
+    gen.close()
+    assert [r.filename for r in first] == files[:150]
+    assert 'discard' in _TwoInFlightReader.log and _TwoInFlightReader.log[-1] == 'close'
+
+
 def test_no_gpu_means_loud_failure():
     if _hip.device_count() > 0:
         pytest.skip('a GPU is visible')
