@@ -3,6 +3,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -97,7 +98,8 @@ private:
 // with the process anyway.
 inline WorkerPool& host_pool()
 {
-    static WorkerPool* pool = new WorkerPool((int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 2u) - 1u, 15u));
+    static WorkerPool* pool = new WorkerPool(getenv("MELF_HOST_THREADS") ? std::max(0, atoi(getenv("MELF_HOST_THREADS")) - 1)
+                                                                         : (int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 2u) - 1u, 15u));
     return *pool;
 }
 
@@ -106,7 +108,8 @@ inline WorkerPool& host_pool()
 // for the other (read stage 0.9 -> 1.5 ms, the decode stage's host part 0.8 -> 2.2 ms).
 inline WorkerPool& io_pool()
 {
-    static WorkerPool* pool = new WorkerPool((int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency() / 2, 2u) - 1u, 7u));
+    static WorkerPool* pool = new WorkerPool(getenv("MELF_IO_THREADS") ? std::max(0, atoi(getenv("MELF_IO_THREADS")) - 1)
+                                                                       : (int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency() / 2, 2u) - 1u, 7u));
     return *pool;
 }
 
