@@ -1605,10 +1605,15 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     // may prepare and enqueue behind it
     if (overlapped) (*tl_jpeg_enqueued)();
     HIP_TRY(hipEventSynchronize(c->ev_jcall[cs]));
-    if (trace)
-        fprintf(stderr, "[melf jpeg] pipelined call n=%d (%d sparse files first): %.2f ms enqueueing (host prepare + launches), %.2f ms waiting for the GPU\n", n,
-                nsparse, std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
+    if (trace) {
+        static const auto t_first = tc0;  // absolute times (ms since the first traced call) show how consecutive calls overlap
+        const auto tc2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[melf jpeg] pipelined call n=%d (%d sparse files first): %.2f ms enqueueing (host prepare + launches), %.2f ms waiting for the GPU"
+                        " [start %.2f, enqueued %.2f, done %.2f]\n", n,
+                nsparse, std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(tc2 - tc1).count(),
+                std::chrono::duration<double, std::milli>(tc0 - t_first).count(), std::chrono::duration<double, std::milli>(tc1 - t_first).count(),
+                std::chrono::duration<double, std::milli>(tc2 - t_first).count());
+    }
     for (int i = 0; i < n; ++i) {
         const int o = perm.empty() ? i : perm[i];
         status[o] = hstat[i] ? hstat[i] : (c->h_jstatus[cs][i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
