@@ -277,6 +277,23 @@ int melf_ctx_last_match(const melf_ctx* ctx, melf_match_info* out);
  * context (host logic; kernel = MELF_MATCH_KERNEL_MFMA when the shape belongs to the tuned kernel's class, else the
  * kernel that takes it).  reserved[0] = padded template rows, reserved[1] = L-plane rows per frame group. */
 int melf_match_layout_query(int th, int tw, int rows, int cols, int n, melf_match_info* out);
+/* The GENERAL matrix-core kernel's plan for a shape and batch size, without a GPU (host logic; tests pin its invariants for
+ * every batch size).  out->kernel = the kernel DEFAULT dispatch launches for this shape and n (the plan returned is the
+ * general kernel's either way: MELF_MATCH=gen forces it).  For the general kernel -- here, in melf_match_layout_query and
+ * in melf_ctx_last_match -- rows_per_wave = rows a tile computes, tiles = tiles (partials) per frame, waves = tasks per
+ * group x groups, reserved[0] = Toeplitz blocks per template row, [1] = L-plane rows per frame group, [2] = column blocks
+ * per tile, [3] = K slices per tile, [4] = remainder ("V form") map columns, [5] = image blocks per V-form row.
+ * tasks (optional, cap entries): one entry per wave of a frame group, *ntasks = how many there are.
+ * A wave computes map rows y0 .. y0 + rows - 1 (rows_computed >= rows are accumulated) of column blocks xb0 .. xb0 + nxb - 1
+ * (32 map columns each) over the slice [k_lo, k_hi) of the tile's K range (Toeplitz block x template row); rows == 0: a
+ * V-form tile = ONE map column (remainder column index xb0) x the 32 map rows from y0, K range = (image row - y0, image
+ * block).  Slices of a tile add up through partial tiles: part_off .. + nslices x 4 x rows_computed x nxb KiB (V form:
+ * nslices x 4) of the group's part_stride KiB. */
+typedef struct {
+    int32_t y0, rows, rows_computed, xb0, nxb, tile, slice, nslices, k_lo, k_hi, part_off, part_stride;
+} melf_gen_task;
+int melf_match_gen_plan_query(int th, int tw, int rows, int cols, int n, melf_match_info* out, melf_gen_task* tasks, int cap,
+                              int32_t* ntasks);
 
 int melf_ctx_set_profiling(melf_ctx* ctx, int on);  /* 0 off, 1 every kernel, 2 only the match kernel (two event records per batch instead of eight) */
 int melf_ctx_timings(melf_ctx* ctx, double ms[MELF_K_COUNT], int64_t launches[MELF_K_COUNT]);

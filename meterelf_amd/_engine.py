@@ -19,8 +19,9 @@ def load_template(params: Params) -> np.ndarray:
     """cv2.imread(dials_file, IMREAD_GRAYSCALE) (reference: meterelf/_image.py:72-81).
 
     A grey file is taken as it is.  For a colour file OpenCV 3.4 lets the file format's own library make the grey image:
-    libpng for PNG (png_set_rgb_to_gray with 0.299 / 0.587: 15-bit coefficients 9798 / 19235 / 3735, palettes expanded to
-    RGB first), libjpeg for JPEG (the decoder is asked for JCS_GRAYSCALE: the Y plane itself); every other format is
+    libpng for PNG (png_set_rgb_to_gray with 0.299 / 0.587: libpng 1.6 truncates them to the 15-bit coefficients 9797 / 19234 and
+    gives blue the rest, 3737, and does NOT round the sum -- checked against libpng itself, tests/test_host_logic.py; palettes
+    expanded to RGB first), libjpeg for JPEG (the decoder is asked for JCS_GRAYSCALE: the Y plane itself); every other format is
     decoded to BGR and goes through cvtColor's 14-bit weights (R 4899, G 9617, B 1868).  Pillow's convert('L') is none of
     these (other weights, truncation)."""
     from PIL import Image
@@ -38,7 +39,7 @@ def load_template(params: Params) -> np.ndarray:
                 rgb = np.asarray(im.convert('RGB'), dtype=np.int64)
                 (r, g, b) = (rgb[:, :, 0], rgb[:, :, 1], rgb[:, :, 2])
                 if fmt == 'PNG':
-                    grey = (r * 9798 + g * 19235 + b * 3735 + 16384) >> 15
+                    grey = (r * 9797 + g * 19234 + b * 3737) >> 15
                 else:
                     grey = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14
                 template = np.ascontiguousarray(grey.astype(np.uint8))

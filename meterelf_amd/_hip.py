@@ -76,7 +76,7 @@ EXPORTS = [
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_sync', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
-    'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
+    'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_match_gen_plan_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
     'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end',
 ]
@@ -124,6 +124,8 @@ def lib():
     L.melf_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.melf_ctx_last_match.argtypes = [vp, C.POINTER(MelfMatchInfo)]
     L.melf_match_layout_query.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MelfMatchInfo)]
+    L.melf_match_gen_plan_query.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MelfMatchInfo), vp, C.c_int,
+                                            C.POINTER(C.c_int32)]
     L.melf_ctx_set_frames_resident.argtypes = [vp, C.c_int]
     L.melf_ctx_timings.argtypes = [vp, vp, vp]
     i32p = C.POINTER(C.c_int32)
@@ -213,12 +215,33 @@ def build_dial_masks(cparams):
     return out
 
 
-def _match_info_dict(mi):
+GEN_TASK_DTYPE = np.dtype([(k, '<i4') for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'tile', 'slice', 'nslices', 'k_lo', 'k_hi',
+                                                  'part_off', 'part_stride')])
+
+
+def _match_info_dict(mi, gen_plan=False):
     d = {k: getattr(mi, k) for (k, _t) in MelfMatchInfo._fields_ if k != 'reserved'}
     d['kernel'] = MATCH_KERNEL_NAMES[mi.kernel]
-    d['layout'] = ('rb%d%s' % (mi.rows_per_wave, '+pairs' if mi.pair_waves else '')) if mi.kernel == 1 else None
-    d['th_pad'], d['rows_pad'] = mi.reserved[0], mi.reserved[1]
+    d['layout'] = ('rb%d%s' % (mi.rows_per_wave, '+pairs' if mi.pair_waves else '')) if mi.kernel == 1 and not gen_plan else None
+    if mi.kernel == 2 or gen_plan:   # the general kernel's plan: tile shape, slices, remainder columns
+        (d['nd'], d['rows_pad'], d['blocks_per_tile'], d['slices'], d['v_columns'], d['v_blocks']) = tuple(mi.reserved)
+        d['layout'] = 'r%dx%d/%d%s' % (mi.rows_per_wave, d['blocks_per_tile'], d['slices'], '+v%d' % d['v_columns'] if d['v_columns'] else '')
+    else:
+        d['th_pad'], d['rows_pad'] = mi.reserved[0], mi.reserved[1]
     return d
+
+
+def match_gen_plan_query(th, tw, rows, cols, n):
+    """The general matrix-core kernel's plan for this shape and batch size (host logic, no GPU needed): (info dict -- 'kernel' is what
+    DEFAULT dispatch launches for the shape --, structured array of one frame group's wave tasks)."""
+    mi = MelfMatchInfo()
+    nt = C.c_int32(0)
+    check(lib().melf_match_gen_plan_query(th, tw, rows, cols, n, C.byref(mi), None, 0, C.byref(nt)))
+    tasks = np.zeros(nt.value, GEN_TASK_DTYPE)
+    check(lib().melf_match_gen_plan_query(th, tw, rows, cols, n, C.byref(mi), _ptr(tasks), nt.value, C.byref(nt)))
+    d = _match_info_dict(mi, gen_plan=True)
+    d['default_kernel'] = d.pop('kernel')
+    return d, tasks
 
 
 def match_layout_query(th, tw, rows, cols, n):

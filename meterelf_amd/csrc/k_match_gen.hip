@@ -434,6 +434,8 @@ GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes)
     std::vector<Tile> tiles;
     const int Rc = best_rc;
     p.rc = Rc;
+    p.nxb_tile = best_nxb;
+    p.nslices = best_ns;
     for (int y0 = 0; y0 < p.rh; y0 += Rc) {
         const int R = std::min(Rc, p.rh - y0);
         for (int xb = 0; xb < nxb_h; xb += best_nxb) {

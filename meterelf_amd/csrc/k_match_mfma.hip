@@ -571,7 +571,7 @@ static double mm_wave_cycles(int R, int units, int nxb, int th_pad)
 
 MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
 {
-    MfmaPlan p;
+    MfmaPlan p = {};
     p.rh = rows - th + 1;
     p.rw = cols - tw + 1;
     p.nxb = p.rw > 32 ? 2 : 1;
@@ -581,7 +581,9 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
     // launch's time is (rounds of waves over the 1024 SIMDs) x (its longest wave); among equals the fewest pairs.
     const int simds = 1024;
     int force_rb = 0, force_np = -1;
-    if (const char* e = getenv("MELF_MATCH_LAYOUT")) sscanf(e, "%d,%d", &force_rb, &force_np);  // experiments / tests: "rb,np"
+    if (const char* e = getenv("MELF_MATCH_LAYOUT")) {  // experiments / tests: "rb,np"; anything outside the family is ignored
+        if (sscanf(e, "%d,%d", &force_rb, &force_np) < 1 || force_rb < 2 || force_rb > 5) { force_rb = 0; force_np = -1; }
+    }
     double best = 0;
     p.rb = 0;
     for (int rb = 2; rb <= 5; ++rb) {
@@ -703,6 +705,9 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
         MM_CASE(1, 2) MM_CASE(1, 3) MM_CASE(1, 4) MM_CASE(1, 5)
         MM_CASE(2, 2) MM_CASE(2, 3) MM_CASE(2, 4) MM_CASE(2, 5)
 #endif
+        default:   // a plan outside the instantiated family must never pass silently: the records would come from stale partials
+            fprintf(stderr, "[melf] k_match_mfma: no instantiation for %d column blocks x %d rows per wave\n", p.nxb, p.rb);
+            abort();
     }
 #undef MM_CASE
 }

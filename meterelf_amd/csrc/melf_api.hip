@@ -377,11 +377,17 @@ static int claim_all_lanes(melf_ctx* c, hipStream_t st)
     return MELF_SUCCESS;
 }
 
+// Work buffers only ever grow.  A buffer that is replaced may still be read by kernels in flight -- another caller stream's
+// batch on the other lane, or the previous melf_jpeg_process_files_begin call's kernels -- so the whole device is drained
+// first (explicitly: hipFree happens to synchronise, but nothing promises it).  Growth is rare (first use of a size).
 template <class T>
 static int grow(T** ptr, size_t* cap, size_t need)
 {
     if (need <= *cap) return MELF_SUCCESS;
-    if (*ptr) HIP_TRY(hipFree(*ptr));
+    if (*ptr) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(*ptr));
+    }
     *ptr = nullptr;
     *cap = 0;
     HIP_TRY(hipMalloc((void**)ptr, need * sizeof(T)));
@@ -691,13 +697,64 @@ extern "C" int melf_ctx_set_frames_resident(melf_ctx* c, int on)
     return MELF_SUCCESS;
 }
 
+// the general kernel's plan in melf_match_info terms (melf_ctx_last_match, melf_match_layout_query, melf_match_gen_plan_query)
+static void fill_gen_info(melf_match_info* info, const GenPlan& pl)
+{
+    info->tiles = pl.ntiles; info->waves = pl.ntasks * pl.groups; info->rows_per_wave = pl.rc;
+    info->reserved[0] = pl.nd; info->reserved[1] = pl.rows_pad; info->reserved[2] = pl.nxb_tile; info->reserved[3] = pl.nslices;
+    info->reserved[4] = pl.vcols; info->reserved[5] = pl.ndv;
+}
+
+// Which kernel default dispatch picks for a shape and batch size (no context: assumes the tuned kernel's template tables
+// exist whenever the shape is in its class, which is what melf_ctx_create arranges).
+static int default_match_kind(int th, int tw, int rows, int cols, int n)
+{
+    const bool fast_ok = mfma_match_ok(th, tw, rows, cols);
+    const bool gen_ok = gen_match_ok(th, tw, rows, cols);
+    if (fast_ok) {
+        // measured on MI355X, map 132 x 63 (tools/gpu_check_gen.sh): tuned / general kernel 175 / 246 us at 1024 frames,
+        // 128 / 161 at 512, 72 / 87 at 256, 62 / 33 at 64; map 17 x 33 at 1024 frames: 67 / 42 us
+        const int rh = rows - th + 1, rw = cols - tw + 1, groups = (n + 31) / 32;
+        const bool few_frames = groups <= 4;                               // the tuned kernel cannot slice its K loop
+        const bool small_map = (long)((rh + 4) / 5) * groups * 2 <= 512;   // ... nor fill the chip with a small map
+        const bool odd_cols = rw > 32 && rw % 32 >= 1 && rw % 32 <= 4;     // a whole column block for <= 4 columns
+        if (!gen_ok || !(few_frames || small_map || odd_cols)) return MK_FAST;
+    }
+    return gen_ok ? MK_GEN : MK_DOT4;
+}
+
+extern "C" int melf_match_gen_plan_query(int th, int tw, int rows, int cols, int n, melf_match_info* out, melf_gen_task* tasks,
+                                         int cap, int32_t* ntasks)
+{
+    if (!out || n < 1 || cap < 0 || (cap > 0 && !tasks)) return fail(MELF_ERR_INVALID, "bad argument");
+    memset(out, 0, sizeof(*out));
+    out->n = n; out->rows = rows; out->cols = cols; out->groups = (n + 31) / 32;
+    if (rows < th || cols < tw || th < 1 || tw < 1) return fail(MELF_ERR_INVALID, "image smaller than the template");
+    if (!gen_match_ok(th, tw, rows, cols)) return fail(MELF_ERR_TOO_LARGE, "shape outside the general matrix-core kernel's limits");
+    const GenPlan pl = gen_plan(th, tw, rows, cols, n);
+    out->kernel = default_match_kind(th, tw, rows, cols, n);
+    fill_gen_info(out, pl);
+    if (ntasks) *ntasks = pl.ntasks;
+    for (int i = 0; i < pl.ntasks && i < cap; ++i) {
+        const GenTask& t = pl.tasks[i];
+        melf_gen_task& o = tasks[i];
+        o.y0 = t.y0; o.rows = t.R; o.rows_computed = t.Rc; o.xb0 = t.xb0; o.nxb = t.nxb; o.tile = t.tile;
+        o.slice = t.slice; o.nslices = t.nslices; o.k_lo = t.k_lo; o.k_hi = t.k_hi; o.part_off = t.part_off; o.part_stride = t.part_stride;
+    }
+    return MELF_SUCCESS;
+}
+
 extern "C" int melf_match_layout_query(int th, int tw, int rows, int cols, int n, melf_match_info* out)
 {
     if (!out || n < 1) return fail(MELF_ERR_INVALID, "bad argument");
     memset(out, 0, sizeof(*out));
     out->n = n; out->rows = rows; out->cols = cols; out->groups = (n + 31) / 32;
     if (rows < th || cols < tw || th < 1 || tw < 1) return fail(MELF_ERR_INVALID, "image smaller than the template");
-    if (!mfma_match_ok(th, tw, rows, cols)) { out->kernel = gen_match_ok(th, tw, rows, cols) ? MK_GEN : MK_DOT4; return MELF_SUCCESS; }
+    if (!mfma_match_ok(th, tw, rows, cols)) {
+        out->kernel = gen_match_ok(th, tw, rows, cols) ? MK_GEN : MK_DOT4;
+        if (out->kernel == MK_GEN) fill_gen_info(out, gen_plan(th, tw, rows, cols, n));
+        return MELF_SUCCESS;
+    }
     const MfmaPlan pl = mfma_plan(th, tw, rows, cols, n);
     out->kernel = MK_FAST;
     out->rows_per_wave = pl.rb; out->full_waves = pl.na; out->pair_waves = 2 * pl.np;
@@ -717,6 +774,8 @@ extern "C" int melf_ctx_last_match(const melf_ctx* c, melf_match_info* out)
 extern "C" int melf_ctx_set_profiling(melf_ctx* c, int on)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    // a _begin call's thread appends to the event list while it runs: no profiling calls in between (header: "no other call")
+    if (!c->files_jobs.empty()) return fail(MELF_ERR_INVALID, "melf_ctx_set_profiling while a melf_jpeg_process_files_begin call is in flight");
     c->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
     return MELF_SUCCESS;
 }
@@ -724,6 +783,7 @@ extern "C" int melf_ctx_set_profiling(melf_ctx* c, int on)
 extern "C" int melf_ctx_timings(melf_ctx* c, double ms[MELF_K_COUNT], int64_t launches[MELF_K_COUNT])
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
+    if (!c->files_jobs.empty()) return fail(MELF_ERR_INVALID, "melf_ctx_timings while a melf_jpeg_process_files_begin call is in flight");
     HIP_TRY(hipSetDevice(c->device));
     for (auto& e : c->events) {
         HIP_TRY(hipEventSynchronize(e.stop));
@@ -760,16 +820,9 @@ static int pick_match_kind(const melf_ctx* c, int rows, int cols, int n)
     const bool gen_ok = gen_match_ok(th, tw, rows, cols);
     if (c->force_kind == MK_FAST && fast_ok) return MK_FAST;
     if (c->force_kind == MK_GEN && gen_ok) return MK_GEN;
-    if (fast_ok) {
-        // measured on MI355X, map 132 x 63 (tools/gpu_check_gen.sh): tuned / general kernel 175 / 246 us at 1024 frames,
-        // 128 / 161 at 512, 72 / 87 at 256, 62 / 33 at 64; map 17 x 33 at 1024 frames: 67 / 42 us
-        const int rh = rows - th + 1, rw = cols - tw + 1, groups = (n + 31) / 32;
-        const bool few_frames = groups <= 4;                               // the tuned kernel cannot slice its K loop
-        const bool small_map = (long)((rh + 4) / 5) * groups * 2 <= 512;   // ... nor fill the chip with a small map
-        const bool odd_cols = rw > 32 && rw % 32 >= 1 && rw % 32 <= 4;     // a whole column block for <= 4 columns
-        if (!gen_ok || !(few_frames || small_map || odd_cols)) return MK_FAST;
-    }
-    return gen_ok ? MK_GEN : MK_DOT4;
+    const int kind = default_match_kind(th, tw, rows, cols, n);
+    if (kind == MK_FAST && !fast_ok) return gen_ok ? MK_GEN : MK_DOT4;   // no Toeplitz tables for this template
+    return kind;
 }
 
 static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry** out)
@@ -893,7 +946,7 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
         GenDev dev = ge->dev;
         dev.part = ge->part[bl];
         dev.counters = ge->counters[bl];
-        info.tiles = pl.ntiles; info.waves = pl.ntasks * pl.groups; info.rows_per_wave = pl.rc;
+        fill_gen_info(&info, pl);
         launch_gen_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls, ev.start, ev.stop);
     } else {
         *nparts = match_parts(c->mg, ms.rows, ms.cols);
@@ -1435,7 +1488,16 @@ extern "C" int melf_jpeg_decode_batch(melf_ctx* c, const uint8_t* const* data, c
 
 // melf_jpeg_process_files_begin: the call slot of the thread's call, and what to do once everything of the call is
 // ENQUEUED (the next call in flight may then start its own preparation and enqueue behind it).  NULL: a plain call.
+// tl_jpeg_files_thread: the call runs on the thread of a melf_jpeg_process_files_begin call, i.e. the PREVIOUS such call of
+// the context may still have kernels running and its host thread may still be in its tail (waiting for its "call done"
+// event, reading its slot's pinned status, filling the caller's records).  Such a call therefore uses the call slot of its
+// own ticket -- for EVERY frame-size group of its file list, not only for the one that carries the hand-over hook (round 3
+// took slot 0 for the other groups and could overwrite the previous call's status buffer under its reader) -- and never
+// assumes the GPU is its own.
+// INVARIANT: once a call has run (*tl_jpeg_enqueued)() it touches nothing of the context but its own call slot
+// (d_jframes / d_jresults / h_jstatus / ev_jcall [slot]); everything else belongs to the next call from that moment on.
 static thread_local int tl_jpeg_slot = 0;
+static thread_local bool tl_jpeg_files_thread = false;
 static thread_local std::function<void()>* tl_jpeg_enqueued = nullptr;
 
 // Decode of n files into d_frames in chunks, pipelined: while chunk k's kernels run (on one of two decode streams),
@@ -1532,7 +1594,7 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     const size_t bytes = (size_t)n * H * W * 3;
     // overlapped: called on the thread of a melf_jpeg_process_files_begin call while the previous such call may still have
     // kernels running (its buffers are another call slot's; the ring slots are guarded by their events)
-    const bool overlapped = tl_jpeg_enqueued != nullptr;
+    const bool overlapped = tl_jpeg_files_thread;
     const int cs = overlapped ? tl_jpeg_slot % melf_ctx::NJC : 0;
     // the reading path only looks at the meter_rect crop: IDCT and colour conversion are limited to it
     const int rect[4] = {c->P.rect_x0, c->P.rect_y0, c->P.rect_x1, c->P.rect_y1};
@@ -1603,7 +1665,7 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     HIP_TRY(hipEventRecord(c->ev_jcall[cs], c->stream));
     // everything of this call is enqueued: from here on it touches only its own slot's buffers, and the next call in flight
     // may prepare and enqueue behind it
-    if (overlapped) (*tl_jpeg_enqueued)();
+    if (tl_jpeg_enqueued) (*tl_jpeg_enqueued)();
     HIP_TRY(hipEventSynchronize(c->ev_jcall[cs]));
     if (trace) {
         static const auto t_first = tc0;  // absolute times (ms since the first traced call) show how consecutive calls overlap
@@ -1706,7 +1768,7 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
 // several frame sizes in one list (a camera that was turned at some point) are processed size by size, in the order in
 // which the sizes first appear; H_used / W_used report the first one.
 static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_used, melf_result* out_host, int32_t* status, const FilesRead& R,
-                             std::function<void()>* enqueued = nullptr, int call_slot = 0)
+                             std::function<void()>* enqueued = nullptr, int call_slot = 0, bool files_thread = false)
 {
     if (n == 0) return MELF_SUCCESS;
     *H_used = 0; *W_used = 0;
@@ -1741,8 +1803,10 @@ static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_use
         // the LAST group's call hands the context on as soon as it has enqueued everything (melf_jpeg_process_batch)
         tl_jpeg_enqueued = left == 0 ? enqueued : nullptr;
         tl_jpeg_slot = call_slot;
+        tl_jpeg_files_thread = files_thread;
         const int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data());
         tl_jpeg_enqueued = nullptr;
+        tl_jpeg_files_thread = false;
         if (rc) return rc;
         for (int k = 0; k < m; ++k) { out_host[where[k]] = res[k]; status[where[k]] = st[k]; }
     }
@@ -1808,7 +1872,7 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
             if (rc == MELF_SUCCESS) {
                 try {
                     rc = jpeg_files_decode(c, n, H_used, W_used, out_host, status, R, getenv("MELF_FILES_NO_OVERLAP") ? nullptr : &release,
-                                           (int)(ticket % melf_ctx::NJC));
+                                           (int)(ticket % melf_ctx::NJC), true);
                 } catch (const std::exception& e) {
                     rc = fail(MELF_ERR_INVALID, std::string("out of host memory: ") + e.what());
                 }

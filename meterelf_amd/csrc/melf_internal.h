@@ -75,6 +75,7 @@ struct GenTask {           // one wave's job
 };
 struct GenPlan {
     int rh, rw, rwp, nd, nkb, rows_pad, groups, ntiles, ntasks, rc;
+    int nxb_tile, nslices;   // column blocks per H-form tile, K slices per H-form tile (the planner's choice)
     int vcols, vx0, vkb0, ndv, ndelta, part_stride;
     size_t lg_bytes, r_bytes, ws_bytes, part_bytes, atab_bytes, atabv_bytes;
     std::vector<GenTask> tasks;

@@ -65,3 +65,59 @@ def hip_runtime():
     paths = sorted({line.split()[-1] for line in open('/proc/self/maps') if 'libamdhip64' in line})
     ours = [p for p in paths if '/torch/' not in p] or paths
     return C.CDLL(ours[0])
+
+
+def libpng_rgb_to_gray(path):
+    """The grey image libpng makes of a colour / palette PNG when asked the way OpenCV 3.4's PNG reader asks
+    (modules/imgcodecs/src/grfmt_png.cpp: png_set_palette_to_rgb for palettes, png_set_strip_alpha, then
+    png_set_rgb_to_gray(png, 1, 0.299, 0.587)), through ctypes on the system's libpng16.  None when there is no libpng16 to
+    load (the formula assertion beside it still stands).  Test infrastructure: the expected vector comes from the library
+    the reference's dependency links, not from a restated formula."""
+    import ctypes as C
+    try:
+        png = C.CDLL('libpng16.so.16')
+    except OSError:
+        return None
+    libc = C.CDLL(None)
+    vp = C.c_void_p
+    libc.fopen.restype = vp
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [vp]
+    png.png_get_libpng_ver.restype = C.c_char_p
+    png.png_get_libpng_ver.argtypes = [vp]
+    png.png_create_read_struct.restype = vp
+    png.png_create_read_struct.argtypes = [C.c_char_p, vp, vp, vp]
+    png.png_create_info_struct.restype = vp
+    png.png_create_info_struct.argtypes = [vp]
+    for (name, args) in (('png_init_io', [vp, vp]), ('png_read_info', [vp, vp]), ('png_read_update_info', [vp, vp]),
+                         ('png_set_palette_to_rgb', [vp]), ('png_set_strip_alpha', [vp]), ('png_read_image', [vp, vp]),
+                         ('png_set_rgb_to_gray', [vp, C.c_int, C.c_double, C.c_double])):
+        getattr(png, name).restype = None
+        getattr(png, name).argtypes = args
+    for (name, rt) in (('png_get_image_width', C.c_uint32), ('png_get_image_height', C.c_uint32), ('png_get_color_type', C.c_ubyte),
+                       ('png_get_rowbytes', C.c_size_t)):
+        getattr(png, name).restype = rt
+        getattr(png, name).argtypes = [vp, vp]
+    fp = libc.fopen(path.encode(), b'rb')
+    assert fp, path
+    try:
+        p = png.png_create_read_struct(png.png_get_libpng_ver(None), None, None, None)
+        info = png.png_create_info_struct(p)
+        assert p and info
+        png.png_init_io(p, fp)
+        png.png_read_info(p, info)
+        (w, h, ct) = (png.png_get_image_width(p, info), png.png_get_image_height(p, info), png.png_get_color_type(p, info))
+        if ct == 3:
+            png.png_set_palette_to_rgb(p)
+        if ct & 4:
+            png.png_set_strip_alpha(p)
+        if ct & 2 or ct == 3:
+            png.png_set_rgb_to_gray(p, 1, 0.299, 0.587)
+        png.png_read_update_info(p, info)
+        assert png.png_get_rowbytes(p, info) == w
+        out = np.zeros((h, w), np.uint8)
+        rows = (vp * h)(*[out.ctypes.data + i * w for i in range(h)])
+        png.png_read_image(p, rows)
+    finally:
+        libc.fclose(fp)
+    return out

@@ -922,9 +922,13 @@ def _records_equal(a, b):
 
 @pytest.mark.parametrize('sd,seed', [('sample-images1', 2024), ('sample-images2', 2025)])
 def test_full_size_batch_properties(env, sd, seed):
-    """Configs 3 and 4: 1024 frames in one call.  (1) Batch-composition invariance: the records equal those of the same
-    frames in ragged pieces (one piece exercises the small-batch kernels).  (2) Permutation equivariance.  (3) A frame
-    repeated in the batch gives the same record everywhere.  (4) The oracle on 48 of the 1024."""
+    """Configs 3 and 4: 1024 frames in one call -- host-fed (melf_process_batch: 128-frame chunks through the general kernel)
+    AND resident in HBM (ONE melf_process_batch_dev launch of 1024 frames: the tuned kernel's headline layout for config 3,
+    the general kernel's 32-group plan for config 4 -- the launches bench.py times).  (0) Both give the same records.
+    (1) Batch-composition invariance: the records equal those of the same frames in ragged pieces (one piece exercises the
+    small-batch kernels).  (2) Permutation equivariance.  (3) A frame repeated in the batch gives the same record everywhere.
+    (4) The oracle on 48 of the 1024."""
+    import ctypes as C
     from oracle import pyoracle as po
     e = env[sd]
     reader = e['reader']
@@ -935,6 +939,19 @@ def test_full_size_batch_properties(env, sd, seed):
     frames = base[pick]  # every base frame at least once, the rest repeats in random places
     whole = reader.read_frames(frames)
     assert len(whole) == 1024
+    # (0) the same 1024 frames resident in HBM, one call, default dispatch
+    hip = hip_runtime()
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(frames.nbytes)) == 0
+    try:
+        assert hip.hipMemcpy(dptr, frames.ctypes.data_as(C.c_void_p), C.c_size_t(frames.nbytes), 1) == 0
+        resident = reader.ctx.process_batch_dev(dptr.value, 1024, frames.shape[1], frames.shape[2])
+        info = reader.ctx.last_match()
+    finally:
+        hip.hipFree(dptr)
+    want = {'sample-images1': ('mfma', 'rb4+pairs', 1024), 'sample-images2': ('gen', 'r2x1/3+v1', 1024)}[sd]
+    assert (info['kernel'], info['layout'], info['n']) == want, info
+    assert _records_equal(resident, whole), 'one resident 1024-frame launch vs the host-fed 128-frame chunks'
     # (1) pieces: 1000 + 24, and 33 + 479 + 512
     for cuts in ((0, 1000, 1024), (0, 33, 512, 1024)):
         parts = np.concatenate([reader.read_frames(frames[a:b]) for (a, b) in zip(cuts, cuts[1:])])

@@ -443,14 +443,22 @@ def test_colour_template_grey_conversion_follows_the_file_format(tmp_path):
             yaml.safe_dump(data2, fp)
         return _engine.load_template(_params.load(str(d / 'params.yml')))
 
+    from tests.helpers import libpng_rgb_to_gray
     png = load('png', lambda f: Image.fromarray(rgb, 'RGB').save(f, 'PNG'))
-    assert np.array_equal(png, ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8))
+    assert np.array_equal(png, ((r * 9797 + g * 19234 + b * 3737) >> 15).astype(np.uint8))
+    # ... which is what libpng itself produces for the call OpenCV 3.4 makes (png_set_rgb_to_gray(png, 1, 0.299, 0.587))
+    ref = libpng_rgb_to_gray(str(tmp_path / 'png' / 'png.img'))
+    if ref is not None:
+        assert np.array_equal(png, ref)
     bmp = load('bmp', lambda f: Image.fromarray(rgb, 'RGB').save(f, 'BMP'))
     assert np.array_equal(bmp, ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8))
     assert (png != bmp).any()      # the two formulas are not the same function
     pal = Image.fromarray(rgb, 'RGB').quantize(64)
     prgb = np.asarray(pal.convert('RGB'), dtype=np.int64)
     ppng = load('pal', lambda f: pal.save(f, 'PNG'))
-    assert np.array_equal(ppng, ((prgb[..., 0] * 9798 + prgb[..., 1] * 19235 + prgb[..., 2] * 3735 + 16384) >> 15).astype(np.uint8))
+    assert np.array_equal(ppng, ((prgb[..., 0] * 9797 + prgb[..., 1] * 19234 + prgb[..., 2] * 3737) >> 15).astype(np.uint8))
+    ref = libpng_rgb_to_gray(str(tmp_path / 'pal' / 'pal.img'))
+    if ref is not None:
+        assert np.array_equal(ppng, ref)
     grey = rng.integers(0, 256, size=(th, tw), dtype=np.uint8)
     assert np.array_equal(load('grey', lambda f: Image.fromarray(grey, 'L').save(f, 'PNG')), grey)

@@ -401,6 +401,63 @@ def test_process_files_in_two_halves(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_calls_in_flight_mixed_sizes_keep_their_own_status(tmp_path):
+    """Two _begin calls in flight, the second one's list mixing frame sizes (its first size group is NOT the group that hands
+    the context on), the first one's list holding a file whose entropy-coded data are damaged (header fine: only the GPU
+    decoder can notice, through the call slot's pinned status buffer).  Round 3 ran the second call's first group in call
+    slot 0 -- the first call's slot -- and could overwrite that status buffer while the first call's thread was still
+    reading it: the damaged file then came back "decoded" with a zero-filled record.  Every call must report
+    exactly what the same list reports alone."""
+    from meterelf_amd import MeterReader, _hip, _params
+    reader = MeterReader(_params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml')))
+    try:
+        by_size = {}
+        for f in _files('sample-images1'):
+            by_size.setdefault(_hip.jpeg_probe(open(f, 'rb').read())[:2], []).append(f)
+        (portrait, landscape) = (by_size[(640, 480)], by_size[(480, 640)])
+        assert len(portrait) == 79 and len(landscape) == 2
+        # a damaged scan the GPU decoder reports: all-ones bits (FF 00 = a stuffed FF byte) are no Huffman code of these tables
+        good = open(portrait[5], 'rb').read()
+        sos = good.index(b'\xff\xda')
+        bad = None
+        for (k, span) in enumerate((400, 2000, 6000)):
+            cand = bytearray(good)
+            at = sos + 14 + 3000
+            cand[at:at + span] = b'\xff\x00' * (span // 2)
+            path = tmp_path / ('damaged%d.jpg' % k)
+            path.write_bytes(bytes(cand))
+            (_r, st, _hw) = reader.ctx.jpeg_process_files([str(path)] + portrait[:70])
+            if st[0] == _hip.JPEG_CORRUPT and (st[1:] == 0).all():
+                bad = str(path)
+                break
+        assert bad is not None, 'no damaged candidate was reported corrupt by the decoder'
+        rng = np.random.default_rng(77)
+        list_a = [portrait[i] for i in rng.integers(0, 79, 300)]
+        list_a[137] = bad
+        # second list: 70 landscape names first (a size group of its own, more than the 64 files of the one-piece path), then
+        # portrait ones (the last group: the one that hands the context on)
+        list_b = [landscape[i % 2] for i in range(70)] + [portrait[i] for i in rng.integers(0, 79, 200)]
+        (ref_a, st_a, hw_a) = reader.ctx.jpeg_process_files(list_a)
+        (ref_b, st_b, hw_b) = reader.ctx.jpeg_process_files(list_b)
+        assert st_a[137] == _hip.JPEG_CORRUPT and (np.delete(st_a, 137) == 0).all() and (st_b == 0).all()
+        for rep in range(12):
+            reader.ctx.jpeg_process_files_begin(list_a)
+            reader.ctx.jpeg_process_files_begin(list_b)
+            (got_a, gst_a, ghw_a) = reader.ctx.jpeg_process_files_end()
+            reader.ctx.jpeg_process_files_begin(list_a)          # a third call: its slot is the first call's again
+            (got_b, gst_b, ghw_b) = reader.ctx.jpeg_process_files_end()
+            (got_c, gst_c, ghw_c) = reader.ctx.jpeg_process_files_end()
+            for (got, gst, ref, st, tag) in ((got_a, gst_a, ref_a, st_a, 'first'), (got_b, gst_b, ref_b, st_b, 'second'),
+                                             (got_c, gst_c, ref_a, st_a, 'third')):
+                assert np.array_equal(gst, st), (rep, tag, np.flatnonzero(gst != st)[:5])
+                ok = st == 0
+                assert got[ok].tobytes() == ref[ok].tobytes(), (rep, tag)
+            assert (ghw_a, ghw_b) == (hw_a, hw_b)
+    finally:
+        reader.close()
+
+
+@pytest.mark.gpu
 def test_get_meter_values_overlapped_chunks_and_early_close(tmp_path, monkeypatch):
     """Small chunks, so that the library works on chunk k + 1 while chunk k is consumed: same results as one big chunk,
     with a file for the host branch in the middle (no overlap across that chunk); a generator dropped half way

@@ -28,6 +28,11 @@ REJECTED = ('20180814021309-01-e01.jpg', '20180814021310-00-e02.jpg')
 EXPECTED_LAYOUT = {320: 'rb2', 512: 'rb2+pairs', 700: 'rb3', 800: 'rb3+pairs', 900: 'rb4', 1024: 'rb4+pairs',
                    1056: 'rb4+pairs', 1100: 'rb5', 2048: 'rb4+pairs'}
 
+# sample-images2 shape (BASELINE config 4: crop 135 x 220, map 17 x 33): default dispatch is the GENERAL matrix-core kernel
+# at every batch size (small map, 33 = 32 + 1 columns); batch size -> its plan 'r<tile rows>x<column blocks>/<K slices>+v<remainder
+# columns>'.  1024 is what bench.py's config-4 block launches (32 groups x 32 tasks = 1024 waves).
+EXPECTED_GEN_LAYOUT = {320: 'r2x1/7+v1', 512: 'r2x1/6+v1', 1024: 'r2x1/3+v1', 2048: 'r6x1/4+v1'}
+
 
 # ------------------------------------------------------------------ CPU: the planner ----
 def test_planner_invariants_every_batch_size():
@@ -52,6 +57,102 @@ def test_planner_invariants_every_batch_size():
             assert d['waves'] >= 880, (n, d)   # and it uses (nearly) every SIMD
     for (n, want) in EXPECTED_LAYOUT.items():
         assert _hip.match_layout_query(th, tw, rows, cols, n)['layout'] == want, n
+
+
+def _check_gen_plan(th, tw, rows, cols, n):
+    """Invariants of the general matrix-core kernel's plan (gen_plan, k_match_gen.hip) for one shape and batch size."""
+    from meterelf_amd import _hip
+    (d, tasks) = _hip.match_gen_plan_query(th, tw, rows, cols, n)
+    (rh, rw) = (rows - th + 1, cols - tw + 1)
+    assert d['groups'] == (n + 31) // 32 and d['waves'] == len(tasks) * d['groups']
+    assert d['rows_per_wave'] in (2, 4, 6, 8) and d['blocks_per_tile'] in (1, 2) and 1 <= d['slices'] <= 16
+    (nd, ndv, vcols) = (d['nd'], d['v_blocks'], d['v_columns'])
+    assert nd == (tw + 62) // 32 and 0 <= vcols <= 4
+    vx0 = 32 * (rw // 32) if vcols else rw
+    cover = np.zeros((rh, rw), np.int32)
+    tiles = {}
+    for t in tasks:
+        tiles.setdefault(int(t['tile']), []).append(t)
+    assert sorted(tiles) == list(range(d['tiles'])), 'tile ids are the slots of the (max, argmax) partials: dense'
+    assert d['tiles'] < 32768                       # GenTask::tile is 16 bits wide
+    part_ranges = []
+    for (ti, ts) in tiles.items():
+        t0 = ts[0]
+        ns = int(t0['nslices'])
+        assert len(ts) == ns and sorted(int(t['slice']) for t in ts) == list(range(ns)), ti
+        for t in ts:    # every slice of a tile describes the same tile
+            assert tuple(int(t[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'part_off')) == \
+                   tuple(int(t0[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'part_off')), ti
+        (y0, R, Rc, xb0, nxb) = (int(t0[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb'))
+        assert 0 <= y0 < rh and y0 < 32768
+        if R:      # H form: R map rows x nxb column blocks
+            assert 1 <= R <= Rc == d['rows_per_wave'] and 1 <= nxb <= d['blocks_per_tile'] and y0 + R <= rh
+            (c0, c1) = (32 * xb0, min(32 * (xb0 + nxb), vx0))
+            assert c0 < c1
+            cover[y0:y0 + R, c0:c1] += 1
+            (klen, nq) = (nd * th, Rc * nxb * 4)
+        else:      # V form: one remainder column x 32 map rows
+            assert 0 <= xb0 < vcols and y0 % 32 == 0
+            nrow = min(32, rh - y0)
+            cover[y0:y0 + nrow, vx0 + xb0] += 1
+            (klen, nq) = ((nrow + th - 1) * ndv, 4)
+        # the slices partition the tile's K range, none of them empty
+        spans = sorted((int(t['k_lo']), int(t['k_hi'])) for t in ts)
+        assert spans[0][0] == 0 and spans[-1][1] == klen, (ti, spans, klen)
+        for ((a0, a1), (b0, b1)) in zip(spans, spans[1:]):
+            assert a1 == b0, (ti, spans)
+        assert all(a < b for (a, b) in spans), (ti, spans)
+        if ns > 1:
+            part_ranges.append((int(t0['part_off']), int(t0['part_off']) + ns * nq))
+        assert all(int(t['part_stride']) == int(t0['part_stride']) for t in ts)
+    assert (cover == 1).all(), 'every map position computed exactly once'
+    # partial-tile storage of the sliced tiles: disjoint ranges inside the group's stride, 32-bit byte offsets
+    part_ranges.sort()
+    stride = int(tasks[0]['part_stride'])
+    for ((a0, a1), (b0, b1)) in zip(part_ranges, part_ranges[1:]):
+        assert a1 <= b0, part_ranges
+    if part_ranges:
+        assert part_ranges[-1][1] <= stride and stride * 1024 < 2 ** 32
+    # the last image row any wave requests lies inside the zero-padded L plane of the group
+    assert d['rows_pad'] >= rows
+    return d
+
+
+def test_gen_planner_invariants_every_batch_size():
+    """Host logic, no GPU (the reference has ONE code path for every batch size, meterelf/_utils.py:91-97; here
+    gen_plan picks tile rows / column blocks / K slices from the number of frame groups): for every batch size 1..4300 and the
+    crops of BASELINE configs 3 and 4, every map position is covered exactly once, the K slices of every tile partition its K
+    range, partial-tile ranges are disjoint, and the 16-bit task fields hold."""
+    from meterelf_amd import _hip
+    seen = {}
+    for (rows, cols) in ((250, 250), (135, 220)):
+        last = None
+        for n in range(1, 4301):
+            if last is not None and (n + 31) // 32 == last[0]:
+                # the plan depends on n only through the number of 32-frame groups: same groups, same plan
+                (d, _t) = _hip.match_gen_plan_query(119, 188, rows, cols, n)
+                assert (d['layout'], d['tiles'], d['waves']) == last[1], n
+                continue
+            d = _check_gen_plan(119, 188, rows, cols, n)
+            last = ((n + 31) // 32, (d['layout'], d['tiles'], d['waves']))
+            seen.setdefault((rows, cols), set()).add(d['layout'])
+    # what BENCH config 4 launches (1024 frames of the 135 x 220 crop, 32 groups): 2-row tiles in 3 K slices + the 33rd map
+    # column in V form, 1024 waves -- tests/test_match_layouts.py::test_general_kernel_layouts_full_path runs exactly this
+    (d, _t) = _hip.match_gen_plan_query(119, 188, 135, 220, 1024)
+    assert (d['default_kernel'], d['layout'], d['tiles'], d['waves']) == ('gen', EXPECTED_GEN_LAYOUT[1024], 10, 1024), d
+    for (n, want) in EXPECTED_GEN_LAYOUT.items():
+        (d, _t) = _hip.match_gen_plan_query(119, 188, 135, 220, n)
+        assert (d['default_kernel'], d['layout']) == ('gen', want), (n, d)
+    assert len(seen[(135, 220)]) >= 4 and len(seen[(250, 250)]) >= 4    # the sweep does exercise different plans
+
+
+@pytest.mark.parametrize('th,tw,rows,cols', [(9, 11, 9, 11), (9, 11, 40, 75), (40, 64, 250, 250), (119, 256, 300, 468), (60, 100, 135, 231),
+                                             (119, 188, 130, 1000), (31, 33, 62, 97)], ids=lambda v: str(v))
+def test_gen_planner_invariants_other_shapes(th, tw, rows, cols):
+    """The same invariants for other templates and maps: 1 x 1 map, 1-4 remainder columns, several V-form row blocks, two
+    column blocks per tile, templates up to 256 columns."""
+    for n in (1, 32, 33, 100, 512, 1024, 3000):
+        _check_gen_plan(th, tw, rows, cols, n)
 
 
 def test_planner_other_shapes():
@@ -308,3 +409,171 @@ def test_other_template_heights_in_every_layout(tmp_path, monkeypatch, th, tw, r
             assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mvd.tobytes(), mxd.tobytes(), myd.tobytes())
     finally:
         r.close()
+
+
+# ------------------------------------------------------------------ GPU: BASELINE configs 4 and 5 at the sizes bench.py launches ----
+@pytest.fixture(scope='module')
+def lay2():
+    """sample-images2 readers (BASELINE config 4: crop 135 x 220, map 17 x 33): default dispatch (the general matrix-core
+    kernel at every batch size) and the VALU kernel forced; 256 distinct synthesised frames + two special ones."""
+    from meterelf_amd import MeterReader, _hip, _params
+    from oracle import pyoracle as po
+    from tests.test_gpu_parity import _good, synth_frames
+    if _hip.device_count() < 1:
+        pytest.fail('GPU tests need an MI355X: no HIP device visible (no CPU fallback exists)')
+    pfile = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
+    params = _params.load(pfile)
+    files = sorted(glob.glob(os.path.join(GOLDEN, 'sample-images2', '*.jpg')))
+    readers = {}
+    saved = os.environ.pop('MELF_MATCH', None)
+    try:
+        readers['default'] = MeterReader(params)
+        os.environ['MELF_MATCH'] = 'dot4'     # read when the context is created
+        readers['dot4'] = MeterReader(params)
+    finally:
+        os.environ.pop('MELF_MATCH', None)
+        if saved is not None:
+            os.environ['MELF_MATCH'] = saved
+    base = synth_frames(_good(files), 256, 2025, shift=6, sigma=3.0)
+    special = np.empty((2,) + base.shape[1:], np.uint8)
+    special[0] = 97
+    special[1] = np.random.default_rng(5).integers(0, 256, size=base.shape[1:], dtype=np.uint8)
+    out = dict(readers=readers, base=base, special=special, oparams=po.Params(pfile), params=params, files=files)
+    yield out
+    for r in readers.values():
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', sorted(EXPECTED_GEN_LAYOUT), ids=lambda n: 'n%d_%s' % (n, EXPECTED_GEN_LAYOUT[n]))
+def test_general_kernel_layouts_full_path(lay2, n):
+    """BASELINE config 4's launch shapes (1024 = what bench.py's config-4 block times): n HBM-resident sample-images2 frames in
+    ONE melf_process_batch_dev call at default dispatch -- the general matrix-core kernel in the plan gen_plan picks for that
+    many frame groups (asserted) -- records byte-identical, for ALL frames, to the VALU kernel's on the same device buffer; the
+    oracle on 64 sampled frames plus the constant and the below-threshold ones."""
+    from oracle import pyoracle as po
+    from tests.test_gpu_parity import _compare_records
+    hip = hip_runtime()
+    (frames, where) = _batch(lay2, n, 4000 + n)
+    (H, W) = frames.shape[1:3]
+    buf = _DevBuf(hip, frames.nbytes)
+    try:
+        buf.upload(frames)
+        got = {}
+        for (kind, reader) in lay2['readers'].items():
+            for rep in range(2):    # twice: the arrival counters of the sliced tiles must be back at zero for the next launch
+                got[kind] = reader.ctx.process_batch_dev(buf.p.value, n, H, W)
+                info = reader.ctx.last_match()
+                assert info['n'] == n and info['groups'] == (n + 31) // 32
+                if kind == 'default':
+                    assert (info['kernel'], info['layout']) == ('gen', EXPECTED_GEN_LAYOUT[n]), info
+                    if n == 1024:
+                        assert (info['tiles'], info['waves']) == (10, 1024), info     # BENCH_r03 config4.match_layout
+                    if rep == 0:
+                        first = got[kind]
+                    else:
+                        assert first.tobytes() == got[kind].tobytes(), 'second launch of the same plan'
+                else:
+                    assert info['kernel'] == kind, info
+    finally:
+        buf.free()
+    assert got['default'].tobytes() == got['dot4'].tobytes(), 'general matrix-core kernel vs VALU kernel'
+    rng = np.random.default_rng(n)
+    sample = np.unique(np.concatenate([rng.choice(n, 64, replace=False), where]))
+    _compare_records(got['default'][sample], po.process_frames(frames[sample], lay2['oparams']), tag='config 4, n=%d' % n)
+    st = got['default']['status']
+    assert (st[where] == 1).all()
+    assert float(got['default']['match_val'][where[0]]) == 0.0
+    assert (int(got['default']['match_x'][where[0]]), int(got['default']['match_y'][where[0]])) == (0, 0)
+    assert (st == 0).sum() > n * 0.8
+
+
+@pytest.mark.gpu
+def test_general_kernel_whole_map_config4(lay2):
+    """melf_match_ccoeff(want_map=True) on 1024 crops of 135 x 220 at default dispatch (2-row tiles in 3 K slices + the V-form
+    column): the whole float32 map of every image bit-equal to the VALU kernel's, and to the oracle's on four of them."""
+    from meterelf_amd._engine import load_template
+    from oracle import pyoracle as po
+    n = 1024
+    (frames, where) = _batch(lay2, n, 5000)
+    p = lay2['params']
+    ((x0, y0), (x1, y1)) = p.meter_rect.top_left, p.meter_rect.bottom_right
+    imgs = np.ascontiguousarray(frames[:, y0:y1, x0:x1, 1])
+    assert imgs.shape[1:] == (135, 220)
+    ctx = lay2['readers']['default'].ctx
+    (mv, mx, my, rmap) = ctx.match_ccoeff(imgs, want_map=True)
+    info = ctx.last_match()
+    assert (info['kernel'], info['layout'], info['waves']) == ('gen', EXPECTED_GEN_LAYOUT[n], 1024), info
+    (mvd, mxd, myd, rmapd) = lay2['readers']['dot4'].ctx.match_ccoeff(imgs, want_map=True)
+    assert lay2['readers']['dot4'].ctx.last_match()['kernel'] == 'dot4'
+    assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32))
+    assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mvd.tobytes(), mxd.tobytes(), myd.tobytes())
+    tpl = load_template(p)
+    for i in (0, int(where[0]), n // 2, n - 1):
+        (ev, ex, ey, emap) = po.match_ccoeff(imgs[i], tpl, want_map=True)
+        assert np.array_equal(rmap[i], emap), i
+        assert (float(mv[i]), int(mx[i]), int(my[i])) == (ev, ex, ey), i
+
+
+@pytest.mark.gpu
+def test_config5_resident_full_size(lay):
+    """BASELINE config 5, one GPU's share, as bench.py's config5_block launches it: 512 frames of 1920 x 1080 resident in HBM
+    (6 220 800-byte frame stride, 3.2 GB), the six-dial params of bench.config5_params_dir, ONE melf_process_batch_dev call
+    (tuned kernel, 'rb2+pairs').  The oracle on 32 sampled frames (six positions; the reference cannot combine != 4 dials,
+    meterelf/_reading.py:166), and what cannot depend on the batch: the same frames in ragged pieces and in permuted order."""
+    import shutil
+    from bench import config5_params_dir
+    from meterelf_amd import MeterReader, _params
+    from oracle import pyoracle as po
+    from tests.test_gpu_parity import POS_TOL
+    hip = hip_runtime()
+    (n, H, W) = (512, 1080, 1920)
+    d = config5_params_dir()
+    reader = None
+    try:
+        pfile = os.path.join(d, 'params.yml')
+        params = _params.load(pfile)
+        op = po.Params(pfile)
+        op.load_template()
+        reader = MeterReader(params)
+        assert len(params.dial_names) == 6
+        rng = np.random.default_rng(1080)
+        (src, where) = _batch(lay, n, 6000)             # 640 x 480 config-3 frames: their meter crops become the 1080p meters
+        bg = rng.integers(0, 256, size=(4, H, W, 3), dtype=np.uint8)
+        frames = np.empty((n, H, W, 3), np.uint8)
+        for i in range(n):
+            frames[i] = bg[i % 4]
+        frames[:, 420:670, 1210:1460] = src[:, 160:410, 50:300]
+        buf = _DevBuf(hip, frames.nbytes)
+        try:
+            buf.upload(frames)
+            whole = reader.ctx.process_batch_dev(buf.p.value, n, H, W)
+            info = reader.ctx.last_match()
+            assert (info['kernel'], info['layout'], info['n']) == ('mfma', 'rb2+pairs', n), info
+            # ragged pieces of the same device buffer: 200 (general kernel) + 33 + 279 (tuned kernel's small layouts)
+            fs = H * W * 3
+            cuts = (0, 200, 233, 512)
+            parts = np.concatenate([reader.ctx.process_batch_dev(buf.p.value + a * fs, b - a, H, W) for (a, b) in zip(cuts, cuts[1:])])
+            assert parts.tobytes() == whole.tobytes(), 'pieces'
+            sample = np.unique(np.concatenate([rng.choice(n, 32, replace=False), where]))
+            ores = po.process_frames(frames[sample], op)
+            perm = rng.permutation(n)
+            frames = frames[perm]
+            buf.upload(frames)
+            assert reader.ctx.process_batch_dev(buf.p.value, n, H, W).tobytes() == whole[perm].tobytes(), 'permutation'
+        finally:
+            buf.free()
+    finally:
+        if reader is not None:
+            reader.close()
+        shutil.rmtree(d, ignore_errors=True)      # the oracle reads the template when it is first used: only now
+    for (k, i) in enumerate(sample):
+        (r, o) = (whole[i], ores[k])
+        assert int(r['status']) == o.status, i
+        assert (int(r['match_x']), int(r['match_y']), float(r['match_val'])) == (o.match_x, o.match_y, o.match_val), i
+        if o.status == 0:
+            assert np.allclose(r['pos'][:6], list(o.pos)[:6], rtol=0, atol=POS_TOL), i
+            assert np.allclose(r['angle'][:6], list(o.angle)[:6], rtol=0, atol=POS_TOL), i
+        elif o.status == 3:
+            assert int(r['unreadable_mask']) == o.unreadable_mask, i
+    assert (whole['status'][where] == 1).all() and (whole['status'] == 0).sum() > n * 0.8
