@@ -280,17 +280,17 @@ int melf_match_layout_query(int th, int tw, int rows, int cols, int n, melf_matc
 /* The GENERAL matrix-core kernel's plan for a shape and batch size, without a GPU (host logic; tests pin its invariants for
  * every batch size).  out->kernel = the kernel DEFAULT dispatch launches for this shape and n (the plan returned is the
  * general kernel's either way: MELF_MATCH=gen forces it).  For the general kernel -- here, in melf_match_layout_query and
- * in melf_ctx_last_match -- rows_per_wave = rows a tile computes, tiles = tiles (partials) per frame, waves = tasks per
- * group x groups, reserved[0] = Toeplitz blocks per template row, [1] = L-plane rows per frame group, [2] = column blocks
- * per tile, [3] = K slices per tile, [4] = remainder ("V form") map columns, [5] = image blocks per V-form row.
- * tasks (optional, cap entries): one entry per wave of a frame group, *ntasks = how many there are.
+ * in melf_ctx_last_match -- rows_per_wave = rows a tile computes, tiles = tiles (= workgroups, = partials) per frame group,
+ * waves = waves of the launch, reserved[0] = Toeplitz blocks per template row, [1] = L-plane rows per frame group,
+ * [2] = column blocks per tile, [3] = K slices per tile = waves per workgroup, [4] = remainder ("V form") map columns,
+ * [5] = image blocks per V-form row.
+ * tasks (optional, cap entries): one entry per wave of a frame group's workgroups, *ntasks = how many there are.
  * A wave computes map rows y0 .. y0 + rows - 1 (rows_computed >= rows are accumulated) of column blocks xb0 .. xb0 + nxb - 1
  * (32 map columns each) over the slice [k_lo, k_hi) of the tile's K range (Toeplitz block x template row); rows == 0: a
  * V-form tile = ONE map column (remainder column index xb0) x the 32 map rows from y0, K range = (image row - y0, image
- * block).  Slices of a tile add up through partial tiles: part_off .. + nslices x 4 x rows_computed x nxb KiB (V form:
- * nslices x 4) of the group's part_stride KiB. */
+ * block).  The nslices waves of a tile are one workgroup and add their accumulators up in its LDS (lds_bytes). */
 typedef struct {
-    int32_t y0, rows, rows_computed, xb0, nxb, tile, slice, nslices, k_lo, k_hi, part_off, part_stride;
+    int32_t y0, rows, rows_computed, xb0, nxb, tile, slice, nslices, k_lo, k_hi, lds_bytes, reserved;
 } melf_gen_task;
 int melf_match_gen_plan_query(int th, int tw, int rows, int cols, int n, melf_match_info* out, melf_gen_task* tasks, int cap,
                               int32_t* ntasks);

@@ -216,7 +216,7 @@ def build_dial_masks(cparams):
 
 
 GEN_TASK_DTYPE = np.dtype([(k, '<i4') for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'tile', 'slice', 'nslices', 'k_lo', 'k_hi',
-                                                  'part_off', 'part_stride')])
+                                                  'lds_bytes', 'reserved')])
 
 
 def _match_info_dict(mi, gen_plan=False):

@@ -233,14 +233,12 @@ struct melf_ctx {
     long tsum = 0;
     bool use_mfma = true;                // MELF_MATCH=dot4 forces the VALU kernel
     int force_kind = -1;                 // MELF_MATCH=fast / gen: force the tuned / the general matrix-core kernel where it can run
-    // plans of the general matrix-core kernel, one per (crop shape, frame groups) seen; partial tiles and arrival
-    // counters per pipeline lane (two batches may be in flight)
+    // plans of the general matrix-core kernel, one per (crop shape, frame groups) seen (read-only once built: both pipeline
+    // lanes launch from the same entry)
     struct GenEntry {
         int rows, cols, groups;
         GenPlan plan;
         GenDev dev;
-        void* part[4] = {nullptr, nullptr, nullptr, nullptr};       // per pipeline lane (NLANES)
-        int* counters[4] = {nullptr, nullptr, nullptr, nullptr};
     };
     std::vector<GenEntry*> gen_cache;
     // pipeline lanes: sets of work buffers that can be in flight at once (one per caller stream, up to NLANES), so that
@@ -613,8 +611,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     for (auto& e : c->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     hipFree(c->d_atab);
     for (auto* ge : c->gen_cache) {
-        hipFree(ge->dev.atab); hipFree(ge->dev.atabv); hipFree(ge->dev.tasks);
-        for (int l = 0; l < melf_ctx::NLANES; ++l) { hipFree(ge->part[l]); hipFree(ge->counters[l]); }
+        hipFree(ge->dev.atab); hipFree(ge->dev.atabv); hipFree(ge->dev.tiles);
         delete ge;
     }
     for (int l = 0; l < melf_ctx::NLANES; ++l) {
@@ -735,11 +732,15 @@ extern "C" int melf_match_gen_plan_query(int th, int tw, int rows, int cols, int
     out->kernel = default_match_kind(th, tw, rows, cols, n);
     fill_gen_info(out, pl);
     if (ntasks) *ntasks = pl.ntasks;
+    // one entry per WAVE: wave w of tile ti's workgroup, with the slice of the tile's K range the kernel gives it
     for (int i = 0; i < pl.ntasks && i < cap; ++i) {
-        const GenTask& t = pl.tasks[i];
+        const int ti = i / pl.nslices, w = i - ti * pl.nslices;
+        const GenTile& t = pl.tiles[ti];
         melf_gen_task& o = tasks[i];
-        o.y0 = t.y0; o.rows = t.R; o.rows_computed = t.Rc; o.xb0 = t.xb0; o.nxb = t.nxb; o.tile = t.tile;
-        o.slice = t.slice; o.nslices = t.nslices; o.k_lo = t.k_lo; o.k_hi = t.k_hi; o.part_off = t.part_off; o.part_stride = t.part_stride;
+        o.y0 = t.y0; o.rows = t.R; o.rows_computed = t.Rc; o.xb0 = t.xb0; o.nxb = t.nxb; o.tile = ti;
+        o.slice = w; o.nslices = pl.nslices;
+        o.k_lo = (int32_t)((long)w * t.klen / pl.nslices); o.k_hi = (int32_t)((long)(w + 1) * t.klen / pl.nslices);
+        o.lds_bytes = (int32_t)pl.lds_bytes; o.reserved = 0;
     }
     return MELF_SUCCESS;
 }
@@ -833,8 +834,7 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
     if (c->gen_cache.size() >= 16) {  // a caller cycling through many shapes: drop the oldest plan
         HIP_TRY(hipDeviceSynchronize());
         auto* old = c->gen_cache.front();
-        hipFree(old->dev.atab); hipFree(old->dev.atabv); hipFree(old->dev.tasks);
-        for (int l = 0; l < melf_ctx::NLANES; ++l) { hipFree(old->part[l]); hipFree(old->counters[l]); }
+        hipFree(old->dev.atab); hipFree(old->dev.atabv); hipFree(old->dev.tiles);
         delete old;
         c->gen_cache.erase(c->gen_cache.begin());
     }
@@ -845,8 +845,8 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
     ge->plan = gen_plan(c->P.th, c->P.tw, rows, cols, n);
     const GenPlan& p = ge->plan;
     if (getenv("MELF_GEN_TRACE"))
-        fprintf(stderr, "[melf gen] crop %dx%d n=%d: map %dx%d nd=%d tile rows %d, %d tiles (%d V columns), %d waves per group x %d groups, partials %zu KiB\n",
-                rows, cols, n, p.rh, p.rw, p.nd, p.rc, p.ntiles, p.vcols, p.ntasks, p.groups, p.part_bytes / 1024);
+        fprintf(stderr, "[melf gen] crop %dx%d n=%d: map %dx%d nd=%d tiles of %d rows x %d blocks, %d tiles (%d V columns) x %d groups = %d workgroups of %d waves, %zu B of LDS each\n",
+                rows, cols, n, p.rh, p.rw, p.nd, p.rc, p.nxb_tile, p.ntiles, p.vcols, p.groups, p.ntiles * p.groups, p.nslices, p.lds_bytes);
     auto upload = [&]() -> int {
         std::vector<int8_t> atab(p.atab_bytes);
         gen_build_atab(c->h_templ.data(), c->P.th, c->P.tw, p, atab.data());
@@ -858,12 +858,12 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
             HIP_TRY(hipMalloc((void**)&ge->dev.atabv, atabv.size()));
             HIP_TRY(hipMemcpy(ge->dev.atabv, atabv.data(), atabv.size(), hipMemcpyHostToDevice));
         }
-        HIP_TRY(hipMalloc((void**)&ge->dev.tasks, p.tasks.size() * sizeof(GenTask)));
-        HIP_TRY(hipMemcpy(ge->dev.tasks, p.tasks.data(), p.tasks.size() * sizeof(GenTask), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&ge->dev.tiles, p.tiles.size() * sizeof(GenTile)));
+        HIP_TRY(hipMemcpy(ge->dev.tiles, p.tiles.data(), p.tiles.size() * sizeof(GenTile), hipMemcpyHostToDevice));
         return MELF_SUCCESS;
     };
     if (int rc = upload()) {
-        hipFree(ge->dev.atab); hipFree(ge->dev.atabv); hipFree(ge->dev.tasks);
+        hipFree(ge->dev.atab); hipFree(ge->dev.atabv); hipFree(ge->dev.tiles);
         delete ge;
         return rc;
     }
@@ -931,21 +931,13 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
         if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
         if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.ntiles)) return rc;
-        if (!ge->counters[bl]) {
-            const size_t cb = (size_t)pl.groups * pl.ntiles * sizeof(int);
-            HIP_TRY(hipMalloc((void**)&ge->counters[bl], cb));
-            HIP_TRY(hipMemsetAsync(ge->counters[bl], 0, cb, ls));
-            if (pl.part_bytes) HIP_TRY(hipMalloc(&ge->part[bl], pl.part_bytes));
-        }
         *parts = c->d_lpart[bl];
         {
             KernelTimer t(c, MELF_K_LPLANE, ls);
             launch_match_prep(ms, from_bgr, m, pl.groups, pl.rows_pad, pl.nkb, pl.rwp, pl.rh, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl],
                               c->d_wsum[bl], ls);
         }
-        GenDev dev = ge->dev;
-        dev.part = ge->part[bl];
-        dev.counters = ge->counters[bl];
+        const GenDev& dev = ge->dev;
         fill_gen_info(&info, pl);
         launch_gen_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls, ev.start, ev.stop);
     } else {

@@ -62,30 +62,25 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
                        hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- K2, general form (k_match_gen.hip): any template up to 256 columns, any map size ----
-struct GenTask {           // one wave's job
+struct GenTile {           // one workgroup's tile of the correlation map (per frame group)
     int16_t y0;            // first map row of the tile (V form: first of its 32 map rows)
     int8_t R, Rc;          // map rows of the tile, rows computed (R rounded up to 2/4/6/8); R == 0: V-form tile
     int8_t nxb;            // column blocks (1 or 2)
     int8_t pad0;
     int16_t xb0;           // first column block (V form: index of the remainder column)
-    int16_t tile;          // tile index inside the frame group = slot of its (max, argmax) partial
-    int16_t slice, nslices;
-    int32_t k_lo, k_hi;    // this wave's range of the tile's linearised K space
-    int32_t part_off, part_stride;  // partial-tile storage (units of 1 KiB), per-group stride
+    int32_t klen;          // length of the tile's linearised K range; wave w of ns takes [w klen / ns, (w + 1) klen / ns)
 };
 struct GenPlan {
     int rh, rw, rwp, nd, nkb, rows_pad, groups, ntiles, ntasks, rc;
-    int nxb_tile, nslices;   // column blocks per H-form tile, K slices per H-form tile (the planner's choice)
-    int vcols, vx0, vkb0, ndv, ndelta, part_stride;
-    size_t lg_bytes, r_bytes, ws_bytes, part_bytes, atab_bytes, atabv_bytes;
-    std::vector<GenTask> tasks;
+    int nxb_tile, nslices;   // column blocks per H-form tile, K slices = waves per workgroup (the planner's choice)
+    int vcols, vx0, vkb0, ndv, ndelta;
+    size_t lg_bytes, r_bytes, ws_bytes, atab_bytes, atabv_bytes, lds_bytes;
+    std::vector<GenTile> tiles;
 };
 struct GenDev {            // device copies that belong to one plan
     int8_t* atab = nullptr;
     int8_t* atabv = nullptr;
-    GenTask* tasks = nullptr;
-    void* part = nullptr;
-    int* counters = nullptr;
+    GenTile* tiles = nullptr;
 };
 bool gen_match_ok(int th, int tw, int rows, int cols);
 GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes);

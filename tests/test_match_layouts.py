@@ -30,8 +30,8 @@ EXPECTED_LAYOUT = {320: 'rb2', 512: 'rb2+pairs', 700: 'rb3', 800: 'rb3+pairs', 9
 
 # sample-images2 shape (BASELINE config 4: crop 135 x 220, map 17 x 33): default dispatch is the GENERAL matrix-core kernel
 # at every batch size (small map, 33 = 32 + 1 columns); batch size -> its plan 'r<tile rows>x<column blocks>/<K slices>+v<remainder
-# columns>'.  1024 is what bench.py's config-4 block launches (32 groups x 32 tasks = 1024 waves).
-EXPECTED_GEN_LAYOUT = {320: 'r2x1/7+v1', 512: 'r2x1/6+v1', 1024: 'r2x1/3+v1', 2048: 'r6x1/4+v1'}
+# columns>' (K slices = waves of the tile's workgroup).  1024 is what bench.py's config-4 block launches.
+EXPECTED_GEN_LAYOUT = {320: 'r2x1/7+v1', 512: 'r2x1/7+v1', 1024: 'r4x1/8+v1', 2048: 'r4x1/4+v1'}
 
 
 # ------------------------------------------------------------------ CPU: the planner ----
@@ -65,7 +65,10 @@ def _check_gen_plan(th, tw, rows, cols, n):
     (d, tasks) = _hip.match_gen_plan_query(th, tw, rows, cols, n)
     (rh, rw) = (rows - th + 1, cols - tw + 1)
     assert d['groups'] == (n + 31) // 32 and d['waves'] == len(tasks) * d['groups']
-    assert d['rows_per_wave'] in (2, 4, 6, 8) and d['blocks_per_tile'] in (1, 2) and 1 <= d['slices'] <= 16
+    assert d['rows_per_wave'] in (2, 4, 6, 8) and d['blocks_per_tile'] in (1, 2)
+    # the slices of a tile are the waves of ONE workgroup: at most 8 (small tile shapes, two waves per SIMD) or 4
+    assert 1 <= d['slices'] <= (8 if d['rows_per_wave'] * d['blocks_per_tile'] <= 4 else 4)
+    assert (d['rows_per_wave'], d['blocks_per_tile']) != (8, 2)      # that shape spills: not offered
     (nd, ndv, vcols) = (d['nd'], d['v_blocks'], d['v_columns'])
     assert nd == (tw + 62) // 32 and 0 <= vcols <= 4
     vx0 = 32 * (rw // 32) if vcols else rw
@@ -75,14 +78,14 @@ def _check_gen_plan(th, tw, rows, cols, n):
         tiles.setdefault(int(t['tile']), []).append(t)
     assert sorted(tiles) == list(range(d['tiles'])), 'tile ids are the slots of the (max, argmax) partials: dense'
     assert d['tiles'] < 32768                       # GenTask::tile is 16 bits wide
-    part_ranges = []
     for (ti, ts) in tiles.items():
         t0 = ts[0]
         ns = int(t0['nslices'])
         assert len(ts) == ns and sorted(int(t['slice']) for t in ts) == list(range(ns)), ti
+        assert ns == d['slices']                      # one workgroup size per launch
         for t in ts:    # every slice of a tile describes the same tile
-            assert tuple(int(t[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'part_off')) == \
-                   tuple(int(t0[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'part_off')), ti
+            assert tuple(int(t[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'lds_bytes')) == \
+                   tuple(int(t0[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb', 'lds_bytes')), ti
         (y0, R, Rc, xb0, nxb) = (int(t0[k]) for k in ('y0', 'rows', 'rows_computed', 'xb0', 'nxb'))
         assert 0 <= y0 < rh and y0 < 32768
         if R:      # H form: R map rows x nxb column blocks
@@ -102,17 +105,10 @@ def _check_gen_plan(th, tw, rows, cols, n):
         for ((a0, a1), (b0, b1)) in zip(spans, spans[1:]):
             assert a1 == b0, (ti, spans)
         assert all(a < b for (a, b) in spans), (ti, spans)
-        if ns > 1:
-            part_ranges.append((int(t0['part_off']), int(t0['part_off']) + ns * nq))
-        assert all(int(t['part_stride']) == int(t0['part_stride']) for t in ts)
+        # the slices add up in the workgroup's LDS: room for the tile's accumulators (nq KiB) + the waves' maxima, within a CU's 160 KiB
+        lds = int(t0['lds_bytes'])
+        assert (lds == 0) if ns == 1 else (nq * 1024 + ns * 32 * 8 <= lds <= 160 * 1024), (ti, ns, nq, lds)
     assert (cover == 1).all(), 'every map position computed exactly once'
-    # partial-tile storage of the sliced tiles: disjoint ranges inside the group's stride, 32-bit byte offsets
-    part_ranges.sort()
-    stride = int(tasks[0]['part_stride'])
-    for ((a0, a1), (b0, b1)) in zip(part_ranges, part_ranges[1:]):
-        assert a1 <= b0, part_ranges
-    if part_ranges:
-        assert part_ranges[-1][1] <= stride and stride * 1024 < 2 ** 32
     # the last image row any wave requests lies inside the zero-padded L plane of the group
     assert d['rows_pad'] >= rows
     return d
@@ -122,7 +118,7 @@ def test_gen_planner_invariants_every_batch_size():
     """Host logic, no GPU (the reference has ONE code path for every batch size, meterelf/_utils.py:91-97; here
     gen_plan picks tile rows / column blocks / K slices from the number of frame groups): for every batch size 1..4300 and the
     crops of BASELINE configs 3 and 4, every map position is covered exactly once, the K slices of every tile partition its K
-    range, partial-tile ranges are disjoint, and the 16-bit task fields hold."""
+    range, the workgroup's LDS holds the tile, and the 16-bit tile fields hold."""
     from meterelf_amd import _hip
     seen = {}
     for (rows, cols) in ((250, 250), (135, 220)):
@@ -136,10 +132,9 @@ def test_gen_planner_invariants_every_batch_size():
             d = _check_gen_plan(119, 188, rows, cols, n)
             last = ((n + 31) // 32, (d['layout'], d['tiles'], d['waves']))
             seen.setdefault((rows, cols), set()).add(d['layout'])
-    # what BENCH config 4 launches (1024 frames of the 135 x 220 crop, 32 groups): 2-row tiles in 3 K slices + the 33rd map
-    # column in V form, 1024 waves -- tests/test_match_layouts.py::test_general_kernel_layouts_full_path runs exactly this
+    # what BENCH config 4 launches (1024 frames of the 135 x 220 crop, 32 groups): test_general_kernel_layouts_full_path runs exactly this
     (d, _t) = _hip.match_gen_plan_query(119, 188, 135, 220, 1024)
-    assert (d['default_kernel'], d['layout'], d['tiles'], d['waves']) == ('gen', EXPECTED_GEN_LAYOUT[1024], 10, 1024), d
+    assert (d['default_kernel'], d['layout']) == ('gen', EXPECTED_GEN_LAYOUT[1024]), d
     for (n, want) in EXPECTED_GEN_LAYOUT.items():
         (d, _t) = _hip.match_gen_plan_query(119, 188, 135, 220, n)
         assert (d['default_kernel'], d['layout']) == ('gen', want), (n, d)
@@ -467,8 +462,6 @@ def test_general_kernel_layouts_full_path(lay2, n):
                 assert info['n'] == n and info['groups'] == (n + 31) // 32
                 if kind == 'default':
                     assert (info['kernel'], info['layout']) == ('gen', EXPECTED_GEN_LAYOUT[n]), info
-                    if n == 1024:
-                        assert (info['tiles'], info['waves']) == (10, 1024), info     # BENCH_r03 config4.match_layout
                     if rep == 0:
                         first = got[kind]
                     else:
@@ -490,8 +483,8 @@ def test_general_kernel_layouts_full_path(lay2, n):
 
 @pytest.mark.gpu
 def test_general_kernel_whole_map_config4(lay2):
-    """melf_match_ccoeff(want_map=True) on 1024 crops of 135 x 220 at default dispatch (2-row tiles in 3 K slices + the V-form
-    column): the whole float32 map of every image bit-equal to the VALU kernel's, and to the oracle's on four of them."""
+    """melf_match_ccoeff(want_map=True) on 1024 crops of 135 x 220 at default dispatch (the plan of bench.py's config-4 launch,
+    V-form column included): the whole float32 map of every image bit-equal to the VALU kernel's, and to the oracle's on four."""
     from meterelf_amd._engine import load_template
     from oracle import pyoracle as po
     n = 1024
@@ -503,7 +496,7 @@ def test_general_kernel_whole_map_config4(lay2):
     ctx = lay2['readers']['default'].ctx
     (mv, mx, my, rmap) = ctx.match_ccoeff(imgs, want_map=True)
     info = ctx.last_match()
-    assert (info['kernel'], info['layout'], info['waves']) == ('gen', EXPECTED_GEN_LAYOUT[n], 1024), info
+    assert (info['kernel'], info['layout']) == ('gen', EXPECTED_GEN_LAYOUT[n]), info
     (mvd, mxd, myd, rmapd) = lay2['readers']['dot4'].ctx.match_ccoeff(imgs, want_map=True)
     assert lay2['readers']['dot4'].ctx.last_match()['kernel'] == 'dot4'
     assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32))

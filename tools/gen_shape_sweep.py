@@ -27,11 +27,17 @@ NB = 4
 frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), NB * n, 2025, dev)
 (H, W) = base.shape[1:3]
 stream = torch.cuda.current_stream().cuda_stream
+# reference records: the VALU kernel (an independent formulation) on batch 0
+os.environ['MELF_MATCH'] = 'dot4'
+ctx = _hip.Context(blob, 0)
+ref = ctx.process_batch_dev(frames.data_ptr(), n, H, W, want_host=True, stream=stream).tobytes()
+ctx.close()
 os.environ['MELF_MATCH'] = 'gen'
-ref = None
 nxs = (1, 2) if len(sys.argv) > 3 and sys.argv[3] == 'nx2' else (1,)
-shapes = ['default'] + ['%d,%d,%d' % (rc, nx, ns) for rc in (2, 4, 6, 8) for nx in nxs for ns in (1, 2, 3, 4, 5, 6, 8, 10, 12)]
-for rep in range(1 if len(nxs) > 1 else 2):
+# slices = waves of the tile's workgroup: up to 8 for the small tile shapes (two waves per SIMD), 4 otherwise; 8 x 2 is not built
+shapes = ['default'] + ['%d,%d,%d' % (rc, nx, ns) for rc in (2, 4, 6, 8) for nx in nxs for ns in range(1, 9)
+                        if ns <= (8 if rc * nx <= 4 else 4) and (rc, nx) != (8, 2)]
+for rep in range(int(os.environ.get('SWEEP_PASSES', '1'))):
     for sh in shapes:
         if sh == 'default':
             os.environ.pop('MELF_GEN_SHAPE', None)
@@ -42,8 +48,6 @@ for rep in range(1 if len(nxs) > 1 else 2):
             ctx.process_batch_dev(frames.data_ptr() + (i % NB) * n * H * W * 3, n, H, W, want_host=False, stream=stream)
         torch.cuda.synchronize()
         recs = ctx.process_batch_dev(frames.data_ptr(), n, H, W, want_host=True, stream=stream)
-        if ref is None:
-            ref = recs.tobytes()
         ok = recs.tobytes() == ref
         ctx.set_profiling(2)
         ctx.timings()
@@ -52,5 +56,6 @@ for rep in range(1 if len(nxs) > 1 else 2):
         torch.cuda.synchronize()
         (ms, cnt) = ctx.timings()['k_match']
         info = ctx.last_match()
-        print('pass %d %-10s k_match %.4f ms  waves %5d tiles %d  records %s' % (rep, sh, ms / cnt, info['waves'], info['tiles'], 'same' if ok else 'DIFFER'), flush=True)
+        print('pass %d %-10s k_match %.4f ms  %-12s waves %5d tiles %d  records %s' % (rep, sh, ms / cnt, info['layout'], info['waves'], info['tiles'],
+                                                                                  'same as the VALU kernel\'s' if ok else 'DIFFER'), flush=True)
         ctx.close()
