@@ -184,6 +184,26 @@ __device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) * __builtin_bit_cast(u16x2v, b)));
 }
 
+// A frame's record, written by one wave: lanes 0 .. MELF_MAX_DIALS - 1 store pos[lane] / angle[lane] (zero beyond the
+// context's dials), lane 0 the scalars.  Every byte of the record is written (no padding in melf_result).
+__device__ __forceinline__ void write_record(melf_result* __restrict__ out, int lane, int status, int mx, int my, float mv, int failed_dial,
+                                             uint32_t unreadable, double value, double pos_lane, double angle_lane)
+{
+    if (lane < MELF_MAX_DIALS) {
+        out->pos[lane] = pos_lane;
+        out->angle[lane] = angle_lane;
+    }
+    if (lane == 0) {
+        out->status = status;
+        out->match_x = mx; out->match_y = my;
+        out->failed_dial = failed_dial;
+        out->unreadable_mask = unreadable;
+        out->match_val = mv;
+        out->value = value;
+    }
+}
+static_assert(sizeof(melf_result) == 24 + 16 * MELF_MAX_DIALS + 8, "melf_result has padding: write_record must fill it");
+
 #ifdef MELF_DIALS_STAMP
 // Diagnostic build only: shader-clock stamps at the phase boundaries of each wave (tools/dials_clock.py).
 __device__ uint64_t g_dials_stamps[8 * 8192];
@@ -198,7 +218,8 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_dials_stamps(ui
 
 // Register budget: 128 of the SIMD's 512 ("amdgpu-num-vgpr" is doubled by the backend for gfx90a+'s unified file): four waves
 // per SIMD, i.e. all 4 096 waves of a 1024-frame batch resident at once.  (Round 2 held it at 104 so that a wave fitted beside
-// a register-capped match wave of the other caller stream; that variant is gone, and at 128 nothing spills.)
+// a register-capped match wave of the other caller stream; that variant is gone, and at 128 nothing spills and -- since round 4,
+// tests/test_host_logic.py reads the code object's notes -- the kernel has no private segment at all.)
 #ifndef MELF_DIALS_VGPRS
 #define MELF_DIALS_VGPRS 64
 #endif
@@ -254,13 +275,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         mx = mi % rw;
         my = mi / rw;
         if ((double)mv < P.match_threshold) {
-            if (threadIdx.x == 0) {
-                melf_result r = {};
-                r.status = MELF_FRAME_DIALS_NOT_FOUND;
-                r.match_x = mx; r.match_y = my; r.match_val = mv;
-                r.failed_dial = -1;
-                results[f] = r;
-            }
+            if (d == 0) write_record(results + f, lane, MELF_FRAME_DIALS_NOT_FOUND, mx, my, mv, -1, 0u, 0.0, 0.0, 0.0);
             return;
         }
     }
@@ -630,30 +645,25 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     if (lane == 0) { s_status[d] = status; s_pos[d] = pos; s_angle[d] = angle; }
     __syncthreads();
 
-    // ---- error aggregation + digit combine (_reading.py:98-111) ----
-    if (threadIdx.x == 0) {
-        melf_result r = {};
-        r.match_x = mx; r.match_y = my; r.match_val = mv;
-        r.failed_dial = -1;
-        r.status = MELF_FRAME_OK;
-        for (int k = 0; k < P.ndials; ++k) {
-            r.pos[k] = s_pos[k];
-            r.angle[k] = s_angle[k];
-            if (s_status[k] == 2) r.unreadable_mask |= 1u << k;
-        }
+    // ---- error aggregation + digit combine (_reading.py:98-111): wave 0, the record written field by field from LDS (a local
+    // melf_result indexed by name_order lived in scratch: 168 bytes of private segment per lane of every wave, round 3) ----
+    if (d == 0) {
+        int st = MELF_FRAME_OK, failed = -1;
+        uint32_t unread = 0;
+        double value = 0.0;
         for (int k = 0; k < P.ndials; ++k)
-            if (s_status[k] == 1) { r.status = MELF_FRAME_NEEDLE_CONTOURS_NOT_FOUND; r.failed_dial = k; break; }
-        if (r.status == MELF_FRAME_NEEDLE_CONTOURS_NOT_FOUND) {
-            // the reference raises at this dial: later dials are never looked at
-            uint32_t keep = (1u << r.failed_dial) - 1u;
-            r.unreadable_mask &= keep;
-        } else if (r.unreadable_mask) {
-            r.status = MELF_FRAME_ANGLE_UNDETERMINED;
+            if (s_status[k] == 2) unread |= 1u << k;
+        for (int k = 0; k < P.ndials; ++k)
+            if (s_status[k] == 1) { st = MELF_FRAME_NEEDLE_CONTOURS_NOT_FOUND; failed = k; break; }
+        if (st == MELF_FRAME_NEEDLE_CONTOURS_NOT_FOUND) {
+            unread &= (1u << failed) - 1u;   // the reference raises at this dial: later dials are never looked at
+        } else if (unread) {
+            st = MELF_FRAME_ANGLE_UNDETERMINED;
         } else if (P.ndials == 4) {
-            r.value = value_by_positions(r.pos[P.name_order[0]], r.pos[P.name_order[1]], r.pos[P.name_order[2]],
-                                         r.pos[P.name_order[3]]);
+            value = value_by_positions(s_pos[P.name_order[0]], s_pos[P.name_order[1]], s_pos[P.name_order[2]], s_pos[P.name_order[3]]);
         }
-        results[f] = r;
+        const bool has = lane < P.ndials;
+        write_record(results + f, lane, st, mx, my, mv, failed, unread, value, has ? s_pos[has ? lane : 0] : 0.0, has ? s_angle[has ? lane : 0] : 0.0);
     }
 }
 

@@ -601,12 +601,12 @@ bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W)
 }
 
 // launch configuration (MELF_FUSED_CONFIG=0..3 for experiments):
-//   0: 512 threads, 3 workgroups/CU (6 waves/SIMD, <= 80 VGPRs), no prefetch   [default of the bit-table variants]
+//   0: 512 threads, 3 workgroups/CU (6 waves/SIMD, <= 80 VGPRs), no prefetch   [default of the bit-table variants until round 4]
 //   4: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), register prefetch [default of the interval-table
 //      variants: with the launches rotating over buffers beyond the Infinity Cache it is 3-10 % faster than 2 x 512
 //      threads x 4 waves/SIMD, which was the fastest while the working set sat in the cache]
 //   1: 512 threads, 2 workgroups/CU (4 waves/SIMD), register prefetch
-//   2: 1024 threads, 1-2 workgroups/CU (4 waves/SIMD), register prefetch
+//   2: 1024 threads, 1-2 workgroups/CU (4 waves/SIMD), register prefetch   [default of the bit-table / generic variants]
 //   3: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), no prefetch
 static int g_fused_config = -1;  // -1: per-variant default
 static thread_local hipEvent_t g_fused_ev_start = nullptr, g_fused_ev_stop = nullptr;
@@ -665,12 +665,16 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
         }
     } else {
         switch (g_fused_config) {
+            case 0: if constexpr (V != 4) { launch_lut_t<V, 512, 0, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
             case 1: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 3: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             default:
+                // round 4, rotating buffers (tools/run_stage.py fused, MELF_FUSED_VARIANT=bits / generic): 1024 threads with the
+                // register prefetch 0.0705 / 0.093 ms per B = 256 launch against 0.100 / 0.110 for the old default (512 threads x 6
+                // waves per SIMD at <= 80 VGPRs, which spilled 14-44 registers into scratch); nothing spills at 128
                 if constexpr (V == 4) launch_lut_t<V, 512, 0, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);  // the tie path needs > 80 VGPRs
-                else launch_lut_t<V, 512, 0, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
+                else launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
                 break;
         }
     }

@@ -53,11 +53,11 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 
-// RFRAG: R in the tuned match kernel's EPILOGUE order instead ([row][k (4)][lane (64)][q (8)], rwp = 64): lane (n, hh) of a
-// match wave finds the row-window sums of its 32 accumulator elements j = 8 k + q = 16 xb + e, i.e. of map columns
-// x = 32 xb + (e & 3) + 8 (e >> 2) + 4 hh, in four lane-contiguous 16-byte pieces -- it adds them up over the template
-// rows itself (match_wave), so neither k_colsum nor the window-sum array exist on that path.
-template <bool FROM_BGR, bool RFRAG>
+// R is written in the match waves' EPILOGUE order: [row][piece (rwp / 16)][lane (64)][q (8)] u16, piece = 2 xb + half: lane (n, hh)
+// of a match wave finds the row-window sums of its accumulator elements e = 8 half + q of column block xb, i.e. of map columns
+// x = 32 xb + (e & 3) + 8 (e >> 2) + 4 hh, in one lane-contiguous 16-byte piece.  The match waves add them up over the template
+// rows themselves (k_match_mfma since round 3, k_match_gen since round 4): no column-sum kernel, no window-sum array.
+template <bool FROM_BGR>
 __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw, int rwp,
                                                      int8_t* __restrict__ Lg, uint16_t* __restrict__ R)
 {
@@ -157,67 +157,21 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
         uint16_t* ro = R + (((size_t)grp * src.rows + y) * rwp) * 32;
         const int bias = tw * 128;
         const int pmax = nkb * 32 - 1;
-        if (RFRAG) {
-            const int k = t >> 6, ln = t & 63, nn = ln & 31, hh = ln >> 5;
+        const int ln = t & 63, nn = ln & 31, hh = ln >> 5;
+        for (int kk = t >> 6; kk < rwp / 16; kk += 4) {   // 1 KiB pieces, four per pass of the workgroup
+            const int xb = kk >> 1, e0 = 8 * (kk & 1);
             uint32_t o[4];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int j = 8 * k + q, xb = j >> 4, e = j & 15;
+                const int e = e0 + q;
                 const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 const int hi = (int)pre_dyn[nn * pstride + min(x + tw - 1, pmax)], lo = x > 0 ? (int)pre_dyn[nn * pstride + min(x - 1, pmax)] : 0;
                 const uint32_t v = (uint32_t)(hi - lo + bias) & 0xffffu;
                 if (q & 1) o[q >> 1] |= v << 16; else o[q >> 1] = v;
             }
             u32x4m ov = {o[0], o[1], o[2], o[3]};
-            *(u32x4m*)(ro + (size_t)t * 8) = ov;
-        } else
-        for (int e = t; e < rwp * 32; e += 256) {
-            const int x = e >> 5, nn = e & 31;
-            const int hi = (int)pre_dyn[nn * pstride + min(x + tw - 1, pmax)], lo = x > 0 ? (int)pre_dyn[nn * pstride + min(x - 1, pmax)] : 0;
-            ro[e] = (uint16_t)(hi - lo + bias);
+            *(u32x4m*)(ro + ((size_t)kk * 64 + ln) * 8) = ov;
         }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// k_colsum: ws[g][y][x][n] = sum_{i < th} R[g][y + i][x][n]  (u32), exact.
-// One workgroup per 128 (x, n) columns of a group and per chunk of output rows, Q threads per column: the tile of R is
-// fetched with coalesced, deeply pipelined loads into LDS (thread q of a column takes rows q, q + Q, ...), then thread
-// q slides down its own Q-th of the column's output rows (its first window summed from LDS).  With one thread per
-// column the launch is 1024 waves of latency-bound work -- one per SIMD; Q = 4 gives the loads four times the
-// requests in flight and cuts the serial slide to a quarter.
-// grid = (rwp * 32 / 128, groups, row chunks), block = 128 * Q.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_colsum(const uint16_t* __restrict__ R, int rows, int th, int rh, int rowlen /* rwp * 32 */,
-                                                 int ychunk, uint32_t* __restrict__ ws)
-{
-    extern __shared__ uint16_t col[];  // [rows of the chunk][128]
-    const int t = threadIdx.x & 127, q = threadIdx.x >> 7, nq = blockDim.x >> 7;
-    const int grp = blockIdx.y, c0 = blockIdx.x * 128;
-    const int y0 = blockIdx.z * ychunk, y1 = min(rh, y0 + ychunk);
-    const int nin = y1 - y0 + th - 1;
-    const uint16_t* r = R + ((size_t)grp * rows + y0) * rowlen + c0 + t;
-    // sixteen independent loads in flight per thread (a loop of single loads waits for each one)
-    int y = q;
-    for (; y + 15 * nq < nin; y += 16 * nq) {
-        uint16_t v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = r[(size_t)(y + k * nq) * rowlen];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) col[(y + k * nq) * 128 + t] = v[k];
-    }
-    for (; y < nin; y += nq) col[y * 128 + t] = r[(size_t)y * rowlen];
-    __syncthreads();
-    const int nout = y1 - y0, per = (nout + nq - 1) / nq;
-    const int a = q * per, b = min(nout, a + per);
-    if (a >= b) return;
-    uint32_t* o = ws + ((size_t)grp * rh + y0) * rowlen + c0 + t;
-    uint32_t s = 0;
-    for (int yy = a; yy < a + th - 1; ++yy) s += col[yy * 128 + t];
-    for (int yo = a; yo < b; ++yo) {
-        s += col[(yo + th - 1) * 128 + t];
-        o[(size_t)yo * rowlen] = s;
-        s -= col[yo * 128 + t];
     }
 }
 
@@ -261,7 +215,7 @@ __device__ inline bool better_m(float v, int i, float bv, int bi)
 // One wave's whole job.  MFIRST / MLAST: which 32-column blocks (bit xb) the first / last of the R
 // rows computes -- the balanced layout gives two neighbouring waves one column block each of a
 // shared row, so that every wave carries 8 or 9 half-row units instead of 10.
-// Window sums: `ws` points at the row-window sums R in epilogue order (k_prep_lplane<.., RFRAG>) and the wave adds them
+// Window sums: `ws` points at the row-window sums R in epilogue order (k_prep_lplane) and the wave adds them
 // up itself -- one 4 KiB row per template row, requested a step ahead like every other operand, the 64
 // additions spread over the step's MFMA sub-blocks (the vector ALU is idle there) -- into the window sums of its first
 // map row; the following rows slide (minus the row that leaves, plus the row that enters) in the epilogue.
@@ -610,7 +564,6 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
     p.rows_pad = rows_cov + p.th_pad + MM_PD + 1;   // last row touched: y0 + (th_pad - 1) + R + PD - 1 (prefetched, unused)
     p.lg_bytes = (size_t)p.groups * p.rows_pad * p.nkb * 1024;
     p.r_bytes = (size_t)p.groups * rows * 64 * 32 * sizeof(uint16_t);
-    p.ws_bytes = (size_t)p.groups * p.rh * 64 * 32 * sizeof(uint32_t);
     return p;
 }
 
@@ -634,45 +587,28 @@ void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab)
                 }
 }
 
-void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int rh, int th, int tw,
-                       int8_t* d_lg, uint16_t* d_r, uint32_t* d_ws, hipStream_t stream, bool rfrag)
+void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int tw, int8_t* d_lg,
+                       uint16_t* d_r, hipStream_t stream)
 {
     dim3 grid(rows_pad, groups), block(256);
     const size_t pre_bytes = (size_t)32 * (nkb * 32 + 8) * sizeof(int16_t);
-    // row chunks of the column-sum pass: at most 96 KiB of LDS per workgroup
-    const int max_in = 96 * 1024 / 256;
-    int ychunk = rh + th - 1 <= max_in ? rh : std::max(1, max_in - (th - 1));
-    static const int want_chunks = getenv("MELF_COLSUM_CHUNKS") ? atoi(getenv("MELF_COLSUM_CHUNKS")) : 1;  // experiments
-    if (want_chunks > 1) ychunk = std::min(ychunk, (rh + want_chunks - 1) / want_chunks);
-    const int nchunks = (rh + ychunk - 1) / ychunk;
-    const size_t col_bytes = (size_t)(std::min(rh, ychunk) + th - 1) * 128 * sizeof(uint16_t);
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr_set[64] = {false};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {  // once per device: dynamic LDS beyond the 64 KiB default
-        (void)hipFuncSetAttribute((const void*)k_colsum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_prep_lplane<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_prep_lplane<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_prep_lplane<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_prep_lplane<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_prep_lplane<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_set[dev] = true;
     }
-    if (rfrag) {   // the tuned match kernel adds the row-window sums up itself: no column-sum pass, no window-sum array
-        if (from_bgr) hipLaunchKernelGGL((k_prep_lplane<true, true>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
-        else hipLaunchKernelGGL((k_prep_lplane<false, true>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
-        return;
-    }
-    if (from_bgr) hipLaunchKernelGGL((k_prep_lplane<true, false>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
-    else hipLaunchKernelGGL((k_prep_lplane<false, false>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
-    static const int colsum_q = getenv("MELF_COLSUM_Q") ? std::min(8, std::max(1, atoi(getenv("MELF_COLSUM_Q")))) : 4;  // threads per column
-    hipLaunchKernelGGL(k_colsum, dim3(rwp * 32 / 128, groups, nchunks), dim3(128 * colsum_q), col_bytes, stream, d_r, src.rows, th, rh,
-                       rwp * 32, ychunk, d_ws);
+    if (from_bgr) hipLaunchKernelGGL((k_prep_lplane<true>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+    else hipLaunchKernelGGL((k_prep_lplane<false>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
 }
 
 void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
-                      uint16_t* d_r, uint32_t* d_ws, hipStream_t stream, bool rfrag)
+                      uint16_t* d_r, hipStream_t stream)
 {
-    launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, p.rh, th, tw, d_lg, d_r, d_ws, stream, rfrag);
+    (void)th;
+    launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, tw, d_lg, d_r, stream);
 }
 
 template <int NXB, int RB>

@@ -251,7 +251,6 @@ struct melf_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[NLANES] = {};
     int8_t* d_lg[NLANES] = {}; size_t lg_cap[NLANES] = {};
     uint16_t* d_rsum[NLANES] = {}; size_t rsum_cap[NLANES] = {};
-    uint32_t* d_wsum[NLANES] = {}; size_t wsum_cap[NLANES] = {};
     MatchPartial* d_lpart[NLANES] = {}; size_t lpart_cap[NLANES] = {};
     uint32_t* d_fused_tables = nullptr;  // K1b lookup tables (built on the GPU at creation)
     int fused_ambiguous = 0;             // hue-table entries whose answer depends on float32 rounding of the triple
@@ -615,7 +614,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
         delete ge;
     }
     for (int l = 0; l < melf_ctx::NLANES; ++l) {
-        hipFree(c->d_lg[l]); hipFree(c->d_rsum[l]); hipFree(c->d_wsum[l]); hipFree(c->d_lpart[l]);
+        hipFree(c->d_lg[l]); hipFree(c->d_rsum[l]); hipFree(c->d_lpart[l]);
         if (c->lane_stream[l]) hipStreamDestroy(c->lane_stream[l]);
         if (c->ev_join[l]) hipEventDestroy(c->ev_join[l]);
     }
@@ -909,17 +908,18 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
     if (kind == MK_FAST) {
         const MfmaPlan pl = mfma_plan(P.th, P.tw, ms.rows, ms.cols, m);
         *nparts = pl.nparts;
-        // the tuned kernel adds up its window sums itself from R (no k_colsum launch, no window-sum array)
+        // the match waves add up their window sums themselves from R (no column-sum launch, no window-sum array)
         if (int rc = grow(&c->d_lg[bl], &c->lg_cap[bl], pl.lg_bytes)) return rc;
         if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.nparts)) return rc;
         *parts = c->d_lpart[bl];
         {
             KernelTimer t(c, MELF_K_LPLANE, ls);
-            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], nullptr, ls, true);
+            launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], ls);
         }
         info.rows_per_wave = pl.rb; info.full_waves = pl.na; info.pair_waves = 2 * pl.np;
         info.waves = pl.nparts * pl.groups; info.tiles = pl.nparts;
+        info.reserved[0] = pl.th_pad; info.reserved[1] = pl.rows_pad;
         launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], (const uint32_t*)c->d_rsum[bl], d_map, *parts, ls,
                           ev.start, ev.stop);
     } else if (kind == MK_GEN) {
@@ -929,17 +929,15 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
         *nparts = pl.ntiles;
         if (int rc = grow(&c->d_lg[bl], &c->lg_cap[bl], pl.lg_bytes)) return rc;
         if (int rc = grow(&c->d_rsum[bl], &c->rsum_cap[bl], pl.r_bytes / sizeof(uint16_t))) return rc;
-        if (int rc = grow(&c->d_wsum[bl], &c->wsum_cap[bl], pl.ws_bytes / sizeof(uint32_t))) return rc;
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * pl.ntiles)) return rc;
         *parts = c->d_lpart[bl];
         {
             KernelTimer t(c, MELF_K_LPLANE, ls);
-            launch_match_prep(ms, from_bgr, m, pl.groups, pl.rows_pad, pl.nkb, pl.rwp, pl.rh, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl],
-                              c->d_wsum[bl], ls);
+            launch_match_prep(ms, from_bgr, m, pl.groups, pl.rows_pad, pl.nkb, pl.rwp, P.tw, c->d_lg[bl], c->d_rsum[bl], ls);
         }
         const GenDev& dev = ge->dev;
         fill_gen_info(&info, pl);
-        launch_gen_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_wsum[bl], d_map, *parts, ls, ev.start, ev.stop);
+        launch_gen_match(m, pl, ms.rows, P.th, P.tw, c->tsum, c->mg.tmean, dev, c->d_lg[bl], c->d_rsum[bl], d_map, *parts, ls, ev.start, ev.stop);
     } else {
         *nparts = match_parts(c->mg, ms.rows, ms.cols);
         if (int rc = grow(&c->d_lpart[bl], &c->lpart_cap[bl], (size_t)m * *nparts)) return rc;

@@ -48,15 +48,15 @@ int match_parts(const MatchGeom& g, int rows, int cols);
 struct MfmaPlan {
     int rh, rw, nxb, nkb, th_pad, nparts, rows_pad, groups;
     int rb, na, np;   // layout: na waves of rb full map rows + np pairs of (rb + 1)-row waves sharing their middle row
-    size_t lg_bytes, r_bytes, ws_bytes;
+    size_t lg_bytes, r_bytes;
 };
 bool mfma_match_ok(int th, int tw, int rows, int cols);
 MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes);
 size_t mfma_atab_bytes(int th);
 void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab);
 void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
-                      uint16_t* d_r, uint32_t* d_ws, hipStream_t stream, bool rfrag);
-// launch_mfma_match: d_ws = the row-window sums R in epilogue order (prep with rfrag = true); the waves add them up
+                      uint16_t* d_r, hipStream_t stream);
+// launch_mfma_match: d_ws = the row-window sums R in epilogue order (k_prep_lplane); the waves add them up
 void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, double tmean, const int8_t* d_atab,
                        const int8_t* d_lg, const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials,
                        hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
@@ -73,8 +73,9 @@ struct GenTile {           // one workgroup's tile of the correlation map (per f
 struct GenPlan {
     int rh, rw, rwp, nd, nkb, rows_pad, groups, ntiles, ntasks, rc;
     int nxb_tile, nslices;   // column blocks per H-form tile, K slices = waves per workgroup (the planner's choice)
+    int nxb_h;               // column blocks the H form covers
     int vcols, vx0, vkb0, ndv, ndelta;
-    size_t lg_bytes, r_bytes, ws_bytes, atab_bytes, atabv_bytes, lds_bytes;
+    size_t lg_bytes, r_bytes, atab_bytes, atabv_bytes, lds_bytes;
     std::vector<GenTile> tiles;
 };
 struct GenDev {            // device copies that belong to one plan
@@ -86,12 +87,12 @@ bool gen_match_ok(int th, int tw, int rows, int cols);
 GenPlan gen_plan(int th, int tw, int rows, int cols, int nframes);
 void gen_build_atab(const uint8_t* templ, int th, int tw, const GenPlan& p, int8_t* atab);
 void gen_build_atabv(const uint8_t* templ, int th, int tw, const GenPlan& p, int8_t* atabv);
-void launch_gen_match(int n, const GenPlan& p, int th, int tw, long tsum, double tmean, const GenDev& dev, const int8_t* d_lg,
-                      const uint32_t* d_ws, float* d_result_map, MatchPartial* d_partials, hipStream_t stream,
+void launch_gen_match(int n, const GenPlan& p, int rows, int th, int tw, long tsum, double tmean, const GenDev& dev, const int8_t* d_lg,
+                      const uint16_t* d_r, float* d_result_map, MatchPartial* d_partials, hipStream_t stream,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// prep for either matrix-core kernel: Lg (fragment order), row-window sums, window sums
-void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int rh, int th, int tw,
-                       int8_t* d_lg, uint16_t* d_r, uint32_t* d_ws, hipStream_t stream, bool rfrag = false);
+// prep for either matrix-core kernel: Lg (fragment order) and the row-window sums R in the match waves' epilogue order
+void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int tw, int8_t* d_lg,
+                       uint16_t* d_r, hipStream_t stream);
 
 // ---- K3: per-dial reading ---------------------------------------------------
 struct DialGeom {

@@ -949,7 +949,7 @@ def test_full_size_batch_properties(env, sd, seed):
         info = reader.ctx.last_match()
     finally:
         hip.hipFree(dptr)
-    want = {'sample-images1': ('mfma', 'rb4+pairs', 1024), 'sample-images2': ('gen', 'r4x1/8+v1', 1024)}[sd]
+    want = {'sample-images1': ('mfma', 'rb4+pairs', 1024), 'sample-images2': ('gen', 'r4x1/4+v1', 1024)}[sd]
     assert (info['kernel'], info['layout'], info['n']) == want, info
     assert _records_equal(resident, whole), 'one resident 1024-frame launch vs the host-fed 128-frame chunks'
     # (1) pieces: 1000 + 24, and 33 + 479 + 512

@@ -462,3 +462,35 @@ def test_colour_template_grey_conversion_follows_the_file_format(tmp_path):
         assert np.array_equal(ppng, ref)
     grey = rng.integers(0, 256, size=(th, tw), dtype=np.uint8)
     assert np.array_equal(load('grey', lambda f: Image.fromarray(grey, 'L').save(f, 'PNG')), grey)
+
+
+def test_no_scratch_in_the_hot_path_kernels():
+    """Code-object metadata of the built library (tools/kernel_meta.py reads the amdhsa notes; no GPU): no kernel that
+    default dispatch launches on the reading path, the fused-mask stage or the JPEG stage has a private segment
+    (private_segment_fixed_size == 0: no spilled vector registers in scratch, no dynamically indexed local array) -- a kernel
+    that spills still computes the right thing, so only a check of the build notices (round 3's k_dials carried 168 bytes per
+    lane, k_match_gen<8> 592)."""
+    import re
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import kernel_meta
+    meta = kernel_meta.kernel_metadata()
+    assert len(meta) > 40, 'no kernel metadata found in libmeterelf_hip.so'
+    hot = []
+    for (name, d) in meta.items():
+        fused = re.search(r'k_fused_mask_lutILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
+        if fused:
+            # the launch shapes launch_lut_v picks by default: interval tables <6..8, 1024, 1, 8>, bit tables / generic <0..3, 1024, 1, 4>,
+            # ties <4, 512, 0, 4> (the other instantiations are MELF_FUSED_CONFIG experiments)
+            (v, t, pf, wps) = (int(x) for x in fused.groups())
+            if not ((v >= 6 and (t, pf, wps) == (1024, 1, 8)) or (v <= 3 and (t, pf, wps) == (1024, 1, 4)) or (v == 4 and (t, pf, wps) == (512, 0, 4))):
+                continue
+        elif not any(k in name for k in ('k_prep_lplane', 'k_match_mfma', 'k_match_gen', 'k_dials', 'k_jpeg_huff', 'k_jpeg_idct',
+                                         'k_jpeg_color', 'k_bgr2hls', 'k_fused_mask')):
+            continue
+        hot.append(name)
+        assert d.get('private_segment_fixed_size', 0) == 0, (name, d)
+        assert d.get('wavefront_size', 64) == 64
+    kinds = {k: sum(1 for n in hot if k in n) for k in ('k_prep_lplane', 'k_match_mfma', 'k_match_gen', 'k_dials', 'k_fused_mask_lut', 'k_jpeg_huff')}
+    assert kinds['k_prep_lplane'] == 2 and kinds['k_match_mfma'] == 8 and kinds['k_match_gen'] == 7 and kinds['k_dials'] == 12, kinds
+    assert kinds['k_fused_mask_lut'] >= 8 and kinds['k_jpeg_huff'] >= 4, kinds
+    assert not any('k_colsum' in n for n in meta)       # the window sums are added up by the match waves since round 4

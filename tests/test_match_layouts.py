@@ -31,7 +31,7 @@ EXPECTED_LAYOUT = {320: 'rb2', 512: 'rb2+pairs', 700: 'rb3', 800: 'rb3+pairs', 9
 # sample-images2 shape (BASELINE config 4: crop 135 x 220, map 17 x 33): default dispatch is the GENERAL matrix-core kernel
 # at every batch size (small map, 33 = 32 + 1 columns); batch size -> its plan 'r<tile rows>x<column blocks>/<K slices>+v<remainder
 # columns>' (K slices = waves of the tile's workgroup).  1024 is what bench.py's config-4 block launches.
-EXPECTED_GEN_LAYOUT = {320: 'r2x1/7+v1', 512: 'r2x1/7+v1', 1024: 'r4x1/8+v1', 2048: 'r4x1/4+v1'}
+EXPECTED_GEN_LAYOUT = {320: 'r2x1/4+v1', 512: 'r2x1/4+v1', 1024: 'r4x1/4+v1', 2048: 'r6x1/4+v1'}
 
 
 # ------------------------------------------------------------------ CPU: the planner ----
