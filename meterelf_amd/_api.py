@@ -8,6 +8,12 @@ loop, files go to the GPU in chunks (METERELF_BATCH, default 1024) and the libra
 works on the next two chunks while the current chunk's results are consumed, so up to three chunks
 are read ahead of the consumer.
 
+Several GPUs in one process (round 4): the chunks are dealt round-robin over METERELF_DEVICES (a comma list of
+device indices; default "all" = every visible device; "0,0" = two contexts on one GPU), one MeterReader and one
+begin / end pipeline per device, each on its own thread; the results are yielded in input order.  Frames are
+independent (meterelf/_api.py:22-33), so there is no collective: the process holds the calibration blob and every
+device gets its own context from it.  With one device nothing changes (no threads).
+
 cv2.imread of the reference (meterelf/_image.py:49): baseline JPEG files are read (on threads, inside the
 library) and decoded on the GPU (METERELF_DECODE=gpu, the default; bit-identical to libjpeg's defaults); any other file, and
 everything when METERELF_DECODE=host, is decoded on the host by Pillow on a small thread pool
@@ -15,11 +21,12 @@ everything when METERELF_DECODE=host, is decoded on the host by Pillow on a smal
 """
 import hashlib
 import os
+import queue
 import threading
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional
 
-from . import _debug, _params
+from . import _debug, _hip, _params
 from ._engine import MeterReader, make_blob, records_to_items, records_to_python, result_to_python
 from ._image import ImageFile
 from .exceptions import ImageProcessingError
@@ -36,30 +43,43 @@ class MeterImageData(NamedTuple):
 # Creating a context (device tables, streams) and growing its workspaces on the first chunk cost ~30 ms per call -- more
 # than the 1024 files of a chunk take to read.  The reference keeps its per-Params state in module-level caches too
 # (meterelf/_image.py:69-81, meterelf/_dial_data.py:11-19, keyed by id(params)); here the key is the calibration itself
-# (digest of the blob = params + template + masks, plus the dial names), so a params.yml edited between two calls gets a
-# new context.  An idle context keeps its device workspaces (about 3 GB after 1024-file chunks of 640 x 480 frames);
-# METERELF_CTX_CACHE=0 turns the cache off, release_cached_contexts() empties it.
+# (digest of the blob = params + template + masks, plus the dial names), the device, and the environment switches the
+# library reads when it creates a context (MELF_MATCH, MELF_JPEG_*, ...: a changed switch gets a new context instead of a
+# stale one), so a params.yml edited between two calls gets a new context.  An idle context keeps its device workspaces
+# (about 3 GB after 1024-file chunks of 640 x 480 frames, of the GPU's 288 GB); at most METERELF_CTX_CACHE_MAX are kept
+# (default: two per device used), METERELF_CTX_CACHE=0 turns the cache off, release_cached_contexts() empties it.  A
+# fork()ed child forgets the parent's contexts without touching HIP (it must create its own).
 _idle_readers: Dict[bytes, MeterReader] = {}
 _idle_lock = threading.Lock()
 _IDLE_MAX = 2
+_devices_used = 1
+_ENV_IN_KEY = ('MELF_MATCH', 'MELF_MATCH_LAYOUT', 'MELF_GEN_SHAPE', 'MELF_LANES', 'MELF_FORCE_GENERIC_MASK', 'MELF_FUSED_VARIANT',
+               'MELF_FUSED_CONFIG', 'MELF_JPEG_CHUNK', 'MELF_JPEG_SERIAL', 'MELF_JPEG_READ', 'MELF_JPEG_NO_REORDER', 'MELF_FILES_NO_OVERLAP',
+               'MELF_IO_THREADS', 'MELF_LIB_PATH')
 
 
-def _acquire_reader(params) -> MeterReader:
+def _reader_key(params, blob, device: int) -> bytes:
+    env = ';'.join('%s=%s' % (k, os.environ[k]) for k in _ENV_IN_KEY if k in os.environ)
+    return hashlib.sha1(blob.tobytes() + repr(list(params.dial_names)).encode() + b'|dev%d|' % device + env.encode()).digest()
+
+
+def _acquire_reader(params, device: int = 0) -> MeterReader:
     blob = make_blob(params)
-    key = hashlib.sha1(blob.tobytes() + repr(list(params.dial_names)).encode()).digest()
+    key = _reader_key(params, blob, device)
     with _idle_lock:
         reader = _idle_readers.pop(key, None)
     if reader is None:
-        reader = MeterReader(params, blob=blob)
+        reader = MeterReader(params, device=device, blob=blob)
     reader._cache_key = key
     return reader
 
 
 def _release_reader(reader: MeterReader) -> None:
     key = getattr(reader, '_cache_key', None)
+    limit = int(os.getenv('METERELF_CTX_CACHE_MAX', str(max(_IDLE_MAX, 2 * _devices_used))))
     if key is not None and os.getenv('METERELF_CTX_CACHE', '1') != '0' and type(reader) is MeterReader:
         with _idle_lock:
-            if key not in _idle_readers and len(_idle_readers) < _IDLE_MAX:
+            if key not in _idle_readers and len(_idle_readers) < limit:
                 _idle_readers[key] = reader
                 return
     reader.close()
@@ -74,9 +94,28 @@ def release_cached_contexts() -> None:
         r.close()
 
 
+def _forget_contexts_in_child() -> None:
+    # after fork() the parent's HIP state is not usable in the child: drop the handles WITHOUT calling into the library
+    for r in list(_idle_readers.values()):
+        for ctx in [getattr(r, 'ctx', None)] + list(getattr(r, '_crop_ctx', {}).values()):
+            if ctx is not None:
+                ctx._h = None
+    _idle_readers.clear()
+
+
 import atexit  # noqa: E402
 
 atexit.register(release_cached_contexts)   # before the interpreter tears the library binding down
+if hasattr(os, 'register_at_fork'):
+    os.register_at_fork(after_in_child=_forget_contexts_in_child)
+
+
+def _device_list() -> List[int]:
+    """METERELF_DEVICES: comma list of device indices (an index may repeat: that many contexts on that GPU), or "all"."""
+    spec = os.getenv('METERELF_DEVICES', 'all').strip()
+    if spec in ('', 'all'):
+        return list(range(max(1, _hip.device_count())))
+    return [int(x) for x in spec.split(',') if x.strip() != ''] or [0]
 
 
 def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
@@ -93,12 +132,8 @@ def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
 _REAL_READER = MeterReader   # tests substitute MeterReader with a CPU stand-in: such readers are never cached
 
 
-def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[MeterImageData]:
-    params = _params.load(params_file)
-    gpu_decode = os.getenv('METERELF_DECODE', 'gpu') != 'host'
-    batch = max(1, int(os.getenv('METERELF_BATCH', '1024' if gpu_decode else '64')))
-    if _debug.DEBUG:
-        batch = 1  # DEBUG re-raises at the failing file, before any later file is touched
+def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode: bool, batch: int) -> Iterator[List[MeterImageData]]:
+    """One device's pipeline: chunk lists in, one list of MeterImageData per chunk out, in order."""
     reader: Optional[MeterReader] = None
     nthreads = max(1, int(os.getenv('METERELF_DECODE_THREADS', str(min(8, os.cpu_count() or 1)))))
     pool = ThreadPoolExecutor(max_workers=nthreads) if (nthreads > 1 and batch > 1) else None
@@ -123,7 +158,6 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         return [None if rec is None else result_to_python(rec, reader.dial_names, f) for (rec, f) in zip(recs, chunk)]
 
     try:
-        chunks = _chunks(filenames, batch)
         begun: List[List[str]] = []  # chunks handed to the library, oldest first
 
         def _begin_more() -> None:
@@ -137,7 +171,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
         chunk = next(chunks, None)
         while chunk is not None:
             if reader is None:
-                reader = _acquire_reader(params) if MeterReader is _REAL_READER else MeterReader(params)
+                reader = _acquire_reader(params, device) if MeterReader is _REAL_READER else MeterReader(params, device=device)
             assert len(reader.dial_names) == 4  # meterelf/_reading.py:166
             pipelined = gpu_decode and batch > 1 and hasattr(reader, 'read_jpeg_paths_begin')
             errors: Dict[int, ImageProcessingError] = {}
@@ -166,7 +200,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
             elif raw is not None:
                 converted = raw
             if items is not None:
-                yield from items
+                yield items
                 chunk = following
                 continue
             on_host = [i for i in range(len(chunk)) if converted[i] is None]
@@ -186,6 +220,7 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                     reader.drain_jpeg_paths()  # host-decoded frames go through the context: nothing may be in flight on it
                 records = reader.read_many(frames) if frames else []
                 by_index.update(zip(where, records))
+            out: List[MeterImageData] = []
             for (i, filename) in enumerate(chunk):
                 done = converted[i]
                 if done is not None:
@@ -197,7 +232,8 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                         (meter_values, error) = result_to_python(by_index[i], reader.dial_names, filename)
                 if error is not None and _debug.DEBUG and i not in errors:
                     raise error
-                yield MeterImageData(filename, meter_values.get('value'), error, meter_values)
+                out.append(MeterImageData(filename, meter_values.get('value'), error, meter_values))
+            yield out
             chunk = following
         clean = True
     except GeneratorExit:
@@ -216,3 +252,92 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
                 _release_reader(reader)   # idle and in a known state: the next call with this calibration takes it over
             else:
                 reader.close()
+
+
+def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[MeterImageData]:
+    global _devices_used
+    params = _params.load(params_file)
+    gpu_decode = os.getenv('METERELF_DECODE', 'gpu') != 'host'
+    batch = max(1, int(os.getenv('METERELF_BATCH', '1024' if gpu_decode else '64')))
+    devices = _device_list()
+    if _debug.DEBUG:
+        batch = 1  # DEBUG re-raises at the failing file, before any later file is touched
+        devices = devices[:1]
+    chunks = _chunks(filenames, batch)
+    if len(devices) == 1:
+        for items in _process_chunks(params, chunks, devices[0], gpu_decode, batch):
+            yield from items
+        return
+    _devices_used = max(_devices_used, len(set(devices)))
+    yield from _fan_out(params, chunks, devices, gpu_decode, batch)
+
+
+_STOP = object()
+
+
+def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode: bool, batch: int) -> Iterator[MeterImageData]:
+    """Chunk k goes to worker k mod D (one per entry of `devices`: its own thread, MeterReader and begin / end pipeline); the
+    workers' chunk results come back through per-worker queues and are yielded in input order.  Every worker may hold
+    AHEAD chunks (the two its library works on, the one being converted, one waiting), so the consumer is at most
+    D x AHEAD chunks behind the file list.  A worker's exception is re-raised here, at the position of its chunk."""
+    AHEAD = 4
+    nw = len(devices)
+    inq = [queue.Queue() for _ in range(nw)]
+    outq = [queue.Queue() for _ in range(nw)]
+
+    def work(w: int) -> None:
+        def feed() -> Iterator[List[str]]:
+            while True:
+                item = inq[w].get()
+                if item is _STOP:
+                    return
+                yield item
+        gen = _process_chunks(params, feed(), devices[w], gpu_decode, batch)
+        try:
+            for items in gen:
+                outq[w].put(items)
+        except BaseException as e:     # handed to the consumer thread
+            outq[w].put(e)
+        finally:
+            gen.close()
+            outq[w].put(_STOP)
+
+    threads = [threading.Thread(target=work, args=(w,), name='meterelf-dev%d-%d' % (devices[w], w), daemon=True) for w in range(nw)]
+    for t in threads:
+        t.start()
+    dealt = 0        # chunks handed out
+    taken = 0        # chunks yielded
+    exhausted = False
+    try:
+        while True:
+            while not exhausted and dealt - taken < nw * AHEAD:
+                chunk = next(chunks, None)
+                if chunk is None:
+                    exhausted = True
+                    for q in inq:
+                        q.put(_STOP)
+                    break
+                inq[dealt % nw].put(chunk)
+                dealt += 1
+            if taken == dealt:
+                break
+            items = outq[taken % nw].get()
+            if isinstance(items, BaseException):
+                raise items
+            if items is _STOP:      # a worker ended early without an exception: cannot happen
+                raise RuntimeError('meterelf_amd: a device worker stopped before its chunks were done')
+            taken += 1
+            yield from items
+    finally:
+        if not exhausted:
+            for q in inq:        # a consumer that stopped early (or an error): chunks not yet started are dropped
+                try:
+                    while True:
+                        q.get_nowait()
+                except queue.Empty:
+                    pass
+                q.put(_STOP)
+        # a consumer that stopped early: the workers finish the chunk they are in (their pipelines are collected by
+        # _process_chunks' own clean-up) and end; nothing of theirs is yielded any more
+        for t in threads:
+            t.join()

@@ -558,6 +558,7 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
         return fail(MELF_ERR_NO_DEVICE, "no HIP device: libmeterelf_hip has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(MELF_ERR_INVALID, "bad device index");
     HIP_TRY(hipSetDevice(device));
+    pool_set_devices(ndev);   // the host pools share the cores out over the visible devices
     std::vector<uint8_t> host;
     if (blob_on_device) {
         if (!blob || blob_bytes < sizeof(BlobHeader)) return fail(MELF_ERR_INVALID, "blob too small");
@@ -1128,6 +1129,7 @@ extern "C" int melf_process_batch(melf_ctx* c, const uint8_t* frames_host, int n
     if (!frames_host || !out_host || n < 0 || H <= 0 || W <= 0) return fail(MELF_ERR_INVALID, "bad argument");
     if (frame_stride < (size_t)H * W * 3) return fail(MELF_ERR_INVALID, "frame_stride smaller than a frame");
     HIP_TRY(hipSetDevice(c->device));
+    pool_use_device(c->device);
     const melf_params& P = c->P;
     const int x0 = P.rect_x0 < W ? P.rect_x0 : W, x1 = P.rect_x1 < W ? P.rect_x1 : W;
     const int y0 = P.rect_y0 < H ? P.rect_y0 : H, y1 = P.rect_y1 < H ? P.rect_y1 : H;
@@ -1462,6 +1464,7 @@ extern "C" int melf_jpeg_decode_batch(melf_ctx* c, const uint8_t* const* data, c
     if (!data || !sizes || !out || !status || n < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || n > 32768)
         return fail(MELF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    pool_use_device(c->device);
     const size_t bytes = (size_t)n * H * W * 3;
     uint8_t* d = (uint8_t*)out;
     if (!out_on_device) {
@@ -1581,6 +1584,7 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     if (!data || !sizes || !out_host || !status || n < 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535 || n > 32768)
         return fail(MELF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    pool_use_device(c->device);
     const size_t bytes = (size_t)n * H * W * 3;
     // overlapped: called on the thread of a melf_jpeg_process_files_begin call while the previous such call may still have
     // kernels running (its buffers are another call slot's; the ring slots are guarded by their events)
@@ -1688,6 +1692,7 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
 {
     if (n == 0) return MELF_SUCCESS;
     if (!paths || !out_host || !status || !H_used || !W_used || n < 0 || n > 32768) return fail(MELF_ERR_INVALID, "bad argument");
+    pool_use_device(c->device);
     // Two passes on the host pool: open + size, then -- the offsets known -- read into ONE grow-only arena (no per-file
     // allocation, no zero fill, no fresh pages to fault in after the first call: with sixteen threads faulting pages
     // of the same address space the per-file buffers cost more than the reads).

@@ -93,14 +93,41 @@ private:
     bool stop_ = false;
 };
 
-// One pool per process, created on first use and deliberately never destroyed: a destructor that joins the workers
-// would hang exit() in a forked child (the threads exist in the parent only), and at process exit the threads go away
-// with the process anyway.
+// One pool PER DEVICE (round 4: get_meter_values drives every GPU of a node from one process, one host thread per device;
+// with one pool per process the devices' parallel loops would queue behind each other), created on first use and
+// deliberately never destroyed: a destructor that joins the workers would hang exit() in a forked child (the threads exist
+// in the parent only), and at process exit the threads go away with the process anyway.  The entry points set the calling
+// thread's device (pool_use_device) before their first parallel loop; the host's cores are shared out over the visible
+// devices (pool_set_devices, called by melf_ctx_create).
+inline thread_local int tl_pool_device = 0;
+inline std::atomic<int> g_pool_devices{1};
+inline void pool_use_device(int device) { tl_pool_device = device >= 0 ? device & 63 : 0; }
+inline void pool_set_devices(int ndev)
+{
+    int cur = g_pool_devices.load();
+    while (ndev > cur && !g_pool_devices.compare_exchange_weak(cur, ndev)) {}
+}
+inline WorkerPool& pool_of(WorkerPool** pools, std::mutex& m, const char* env, unsigned divisor, unsigned lo, unsigned hi)
+{
+    std::lock_guard<std::mutex> lk(m);
+    WorkerPool*& p = pools[tl_pool_device];
+    if (!p) {
+        int n;
+        if (getenv(env)) {
+            n = std::max(0, atoi(getenv(env)) - 1);
+        } else {
+            const unsigned share = std::max<unsigned>(std::thread::hardware_concurrency(), 2u) / (divisor * (unsigned)std::max(1, g_pool_devices.load()));
+            n = (int)std::min<unsigned>(std::max<unsigned>(share, lo + 1u) - 1u, hi);
+        }
+        p = new WorkerPool(n);
+    }
+    return *p;
+}
 inline WorkerPool& host_pool()
 {
-    static WorkerPool* pool = new WorkerPool(getenv("MELF_HOST_THREADS") ? std::max(0, atoi(getenv("MELF_HOST_THREADS")) - 1)
-                                                                         : (int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 2u) - 1u, 15u));
-    return *pool;
+    static WorkerPool* pools[64] = {};
+    static std::mutex m;
+    return pool_of(pools, m, "MELF_HOST_THREADS", 1, 3, 15);   // the device's share of the cores, 4 .. 16 threads with the caller
 }
 
 // A second, smaller pool for the file reads of melf_jpeg_process_files: with two calls in flight the next chunk's
@@ -108,9 +135,9 @@ inline WorkerPool& host_pool()
 // for the other (read stage 0.9 -> 1.5 ms, the decode stage's host part 0.8 -> 2.2 ms).
 inline WorkerPool& io_pool()
 {
-    static WorkerPool* pool = new WorkerPool(getenv("MELF_IO_THREADS") ? std::max(0, atoi(getenv("MELF_IO_THREADS")) - 1)
-                                                                       : (int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency() / 2, 2u) - 1u, 7u));
-    return *pool;
+    static WorkerPool* pools[64] = {};
+    static std::mutex m;
+    return pool_of(pools, m, "MELF_IO_THREADS", 2, 1, 7);
 }
 
 }  // namespace melf

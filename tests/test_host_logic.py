@@ -346,6 +346,119 @@ def test_get_meter_values_keeps_two_chunks_in_flight(tmp_path, monkeypatch):
     assert 'discard' in _TwoInFlightReader.log and _TwoInFlightReader.log[-1] == 'close'
 
 
+class _PerDeviceReader(_TwoInFlightReader):
+    """The same stand-in, remembering which device it was made for and what it was given."""
+    made = []
+
+    def __init__(self, params, device=0, blob=None):
+        super().__init__(params, device, blob)
+        self.device = device
+        self.seen = []
+        _PerDeviceReader.made.append(self)
+
+    def read_jpeg_paths_batch(self, paths):
+        self.seen.append(list(paths))
+        return super().read_jpeg_paths_batch(paths)
+
+    def read_jpeg_paths_begin(self, paths):
+        self.seen.append(list(paths))
+        return super().read_jpeg_paths_begin(paths)
+
+
+@pytest.mark.parametrize('devices', ['0,1', '0,1,2', '0,1,2,3,4,5,6,7', '0,0'])
+def test_get_meter_values_over_several_devices(tmp_path, monkeypatch, devices):
+    """The reference API over all GPUs of a node in one process (meterelf/_api.py:16-33: one list in, results in input order):
+    chunks dealt round-robin over METERELF_DEVICES, one reader and one thread per entry; results in input order; a host-branch
+    file in the middle of a chunk; a consumer that stops early leaves no worker running and nothing in flight; a worker's
+    exception surfaces in the consumer."""
+    import threading
+
+    from PIL import Image
+
+    from meterelf_amd import _api
+    monkeypatch.setattr(_api, 'MeterReader', _PerDeviceReader)
+    monkeypatch.setenv('METERELF_BATCH', '50')
+    monkeypatch.setenv('METERELF_DEVICES', devices)
+    dev = [int(x) for x in devices.split(',')]
+    pfile = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
+    files = []
+    for k in range(1, 1238):
+        f = str(tmp_path / ('f%d.png' % k))
+        if k % 50 == 17:
+            Image.fromarray(np.full((4, 4, 3), k % 250, np.uint8)).save(f)
+        files.append(f)
+    _PerDeviceReader.made = []
+    def workers():
+        return [t.name for t in threading.enumerate() if t.name.startswith('meterelf-dev')]
+    got = list(_api.get_meter_values(pfile, files))
+    assert not workers(), 'device workers still running'
+    assert [r.filename for r in got] == files
+    for (k, r) in zip(range(1, 1238), got):
+        if k % 50 == 17:
+            assert r.error is None and r.value == (k % 250) + 0.5
+        elif k % 7 == 3:
+            assert r.value is None and 'Dials not found' in r.error.get_message()
+        else:
+            assert r.error is None and r.value == float(k)
+    readers = _PerDeviceReader.made
+    assert [r.device for r in sorted(readers, key=lambda r: files.index(r.seen[0][0]))] == dev   # one reader per entry, on its device
+    assert all(r.closed and not r.flight and not r.collected for r in readers)
+    chunks = [files[i:i + 50] for i in range(0, len(files), 50)]
+    for (w, r) in enumerate(sorted(readers, key=lambda r: files.index(r.seen[0][0]))):
+        assert r.seen == chunks[w::len(dev)], w            # worker w got chunks w, w + D, ... in order
+    # a consumer that stops early
+    _PerDeviceReader.made = []
+    gen = _api.get_meter_values(pfile, files)
+    first = [next(gen) for _ in range(120)]
+    gen.close()
+    assert [r.filename for r in first] == files[:120]
+    assert not workers()
+    assert all(r.closed and not r.flight and not r.collected for r in _PerDeviceReader.made)
+    # a worker that fails: the exception reaches the consumer at that chunk's position, the other workers are collected
+    class _Boom(_PerDeviceReader):
+        def _records(self, paths):
+            if any(os.path.basename(p) == 'f333.png' for p in paths):
+                raise RuntimeError('device lost')
+            return super()._records(paths)
+    monkeypatch.setattr(_api, 'MeterReader', _Boom)
+    _PerDeviceReader.made = []
+    seen = []
+    with pytest.raises(RuntimeError, match='device lost'):
+        for r in _api.get_meter_values(pfile, files):
+            seen.append(r.filename)
+    assert seen == files[:300]          # everything before the failing chunk (files 301..350) was delivered, in order
+    assert not workers()
+
+
+def test_context_cache_key_and_fork_hook(monkeypatch):
+    """The cache of idle GPU contexts: the key carries the device and the environment switches the library reads at context
+    creation (a changed MELF_MATCH must not get a stale context back); a forked child forgets the parent's contexts without
+    calling into the library."""
+    from meterelf_amd import _api
+    p = _params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml'))
+    blob = _engine.make_blob(p)
+    k0 = _api._reader_key(p, blob, 0)
+    assert k0 == _api._reader_key(p, blob, 0) and k0 != _api._reader_key(p, blob, 1)
+    monkeypatch.setenv('MELF_MATCH', 'dot4')
+    assert _api._reader_key(p, blob, 0) != k0
+    monkeypatch.delenv('MELF_MATCH')
+    assert _api._reader_key(p, blob, 0) == k0
+
+    class _Ctx:
+        _h = 123
+
+    class _R:
+        ctx = _Ctx()
+        _crop_ctx = {(1, 1): _Ctx()}
+    r = _R()
+    monkeypatch.setitem(_api._idle_readers, b'x', r)
+    _api._forget_contexts_in_child()
+    assert not _api._idle_readers and r.ctx._h is None and r._crop_ctx[(1, 1)]._h is None
+    assert _api._device_list() == list(range(max(1, _hip.device_count())))
+    monkeypatch.setenv('METERELF_DEVICES', '2, 0,0')
+    assert _api._device_list() == [2, 0, 0]
+
+
 def test_no_gpu_means_loud_failure():
     if _hip.device_count() > 0:
         pytest.skip('a GPU is visible')

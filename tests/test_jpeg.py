@@ -458,6 +458,45 @@ def test_two_calls_in_flight_mixed_sizes_keep_their_own_status(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])
+def test_get_meter_values_over_two_contexts_on_one_gpu(sd, tmp_path, monkeypatch):
+    """The reference API fanned out over several devices in one process (METERELF_DEVICES; here "0,0": two contexts, two host
+    threads, two begin / end pipelines on the one GPU of the box): exactly the single-device results, in input order -- with
+    files of two frame sizes, the two 'Dials not found' frames, a file for the host branch and an unreadable one among them."""
+    from PIL import Image
+
+    from meterelf_amd import _api, get_meter_values, release_cached_contexts
+    pfile = os.path.join(GOLDEN, sd, 'params.yml')
+    base = _files(sd)
+    rng = np.random.default_rng(12)
+    names = [base[i] for i in rng.integers(0, len(base), 2600)]
+    png = str(tmp_path / 'frame.png')
+    Image.open(base[5]).save(png)              # not a JPEG: decoded on the host, read through the same context
+    names[700] = png
+    names[1500] = str(tmp_path / 'missing.jpg')
+    monkeypatch.setenv('METERELF_BATCH', '256')
+
+    def run(devices):
+        monkeypatch.setenv('METERELF_DEVICES', devices)
+        return [(r.filename, r.value, None if r.error is None else (type(r.error).__name__, r.error.get_message()), r.meter_values)
+                for r in get_meter_values(pfile, names)]
+    try:
+        ref = run('0')
+        assert [r[0] for r in ref] == names and ref[1500][2][0] == 'ImageLoadingError' and ref[700][1] == ref[names.index(base[5])][1]
+        assert run('0,0') == ref
+        assert run('0,0,0') == ref
+        # a consumer that stops early: both workers end, their contexts go back to the cache idle
+        gen = get_meter_values(pfile, names)
+        first = [next(gen) for _ in range(300)]
+        gen.close()
+        assert [(r.filename, r.value) for r in first] == [(r[0], r[1]) for r in ref[:300]]
+        assert run('0,0') == ref
+        assert 1 <= len(_api._idle_readers) <= 6
+    finally:
+        release_cached_contexts()
+
+
+@pytest.mark.gpu
 def test_get_meter_values_overlapped_chunks_and_early_close(tmp_path, monkeypatch):
     """Small chunks, so that the library works on chunk k + 1 while chunk k is consumed: same results as one big chunk,
     with a file for the host branch in the middle (no overlap across that chunk); a generator dropped half way
