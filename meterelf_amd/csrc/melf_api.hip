@@ -1237,6 +1237,9 @@ extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = ensure_fused_tables(c)) return rc;   // first use: builds them (synchronises the context's stream once)
     hipStream_t st = (hipStream_t)stream_;  // NULL = the null (legacy default) stream, as everywhere in HIP
+    // One kernel per call.  Round 4 tried one call as two half-batch kernels on the context's two lane streams (what two caller
+    // streams buy, inside one call): 0.1075 ms per B = 256 call against 0.0691 -- the fork / join events cost more than the
+    // overlapped ramp and tail save (profiles/r04/fused_split_and_lds_stream.txt); not kept.
     for (int f0 = 0; f0 < n; f0 += MAX_FRAMES_PER_LAUNCH) {
         const int m = n - f0 < MAX_FRAMES_PER_LAUNCH ? n - f0 : MAX_FRAMES_PER_LAUNCH;
         const uint8_t* fin = (const uint8_t*)d_frames + (size_t)f0 * H * W * 3;
