@@ -22,6 +22,7 @@
 //    identity against a traced shoelace area;
 //  * drawContours(thickness=-1) paints F.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "melf_device.h"
 #include "melf_internal.h"
@@ -211,7 +212,7 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_dials_stamps(ui
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dials_stamps), sizeof(uint64_t) * 8 * (size_t)(nwaves < 8192 ? nwaves : 8192)) == hipSuccess ? 0 : -1;
 }
-#define DSTAMP(k) do { if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + d) < 8192) g_dials_stamps[8 * (blockIdx.x * (blockDim.x >> 6) + d) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DSTAMP(k) do { if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) g_dials_stamps[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DSTAMP(k) do { } while (0)
 #endif
@@ -236,10 +237,14 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // DIAL_LDS_BYTES per dial
 
     const int f = blockIdx.x;
-    const int lane = threadIdx.x & 63, d = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // one dial per wave.  (Round 4 tried rotating the dial <-> wave assignment by the frame index, in case wave k of every
+    // workgroup landed on SIMD k and one SIMD got all the small dials: no difference, 0.0631 / 0.0702 ms against 0.0639 / 0.0701
+    // with event brackets, profiles/r04/dials_rotate_ab.txt -- the dispatcher already mixes them.)
+    const int d = wv;
     DSTAMP(0);
     const uint8_t* frame = src.base + (size_t)f * src.frame_stride;
-    uint8_t* const lds = s_dyn + (size_t)d * DIAL_LDS_BYTES;
+    uint8_t* const lds = s_dyn + (size_t)wv * DIAL_LDS_BYTES;
     uint32_t* const list_px = (uint32_t*)lds;                       // pixel phase
     uint16_t* const list_pos = (uint16_t*)(lds + 3072);             // pixel phase
     double* const s_ra_d = (double*)lds;                            // angle phase
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         mx = mi % rw;
         my = mi / rw;
         if ((double)mv < P.match_threshold) {
-            if (d == 0) write_record(results + f, lane, MELF_FRAME_DIALS_NOT_FOUND, mx, my, mv, -1, 0u, 0.0, 0.0, 0.0);
+            if (wv == 0) write_record(results + f, lane, MELF_FRAME_DIALS_NOT_FOUND, mx, my, mv, -1, 0u, 0.0, 0.0, 0.0);
             return;
         }
     }
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
 
     // ---- error aggregation + digit combine (_reading.py:98-111): wave 0, the record written field by field from LDS (a local
     // melf_result indexed by name_order lived in scratch: 168 bytes of private segment per lane of every wave, round 3) ----
-    if (d == 0) {
+    if (wv == 0) {
         int st = MELF_FRAME_OK, failed = -1;
         uint32_t unread = 0;
         double value = 0.0;
