@@ -268,10 +268,27 @@ def match_roofline(P, H, W, kt, frames_total, traffic_entry):
         'avg_launch_ms': round(match_avg_ms, 4), 'launches': match_n,
         'algorithmic': '%d int MAC/frame x %d frames/launch, 2 ops per MAC' % (mac_per_frame, frames_per_launch),
         'note': 'exact integer TM_CCOEFF on v_mfma_i32_32x32x32_i8; algorithmic MACs only (Toeplitz zero padding is not '
-                'counted), priced against the dense i8 MFMA peak.  Since round 3 the tuned kernel (k_match_mfma) also adds up '
-                'the window sums of TM_CCOEFF itself (round 2: a separate k_colsum launch of 15 us that the prep figure carried): '
-                'its launch is ~10 us longer for that and the step ~14 us shorter',
+                'counted), priced against the dense i8 MFMA peak.  The match kernels also add up the window sums of TM_CCOEFF '
+                'themselves (k_match_mfma since round 3, k_match_gen since round 4; before, a separate column-sum launch of 8-15 us): '
+                'their launches are 5-10 us longer for that and the step 8-14 us shorter',
     }
+
+
+def dials_roofline(kernel_ms, traffic, label):
+    """k_dials is bound by vector-instruction issue, not by bytes or matrix FLOPs: its 'roofline' is the share of the vector units'
+    cycles the launch keeps busy.  The counters come from the PMC pass of tools/profile_round.sh (rocprofv3 cannot run inside
+    this process; traffic.json is stamped with the kernel sources it was measured on), the launch time from this run."""
+    v = traffic.valu_entry(label + ':k_dials')
+    out = {'kernel': 'k_dials', 'bound': 'valu-issue', 'avg_launch_ms': kernel_ms.get('k_dials'), 'source': traffic.source,
+           'note': 'avg_launch_ms: hipEvents around each launch in the per-kernel pass of this run (a few microseconds more than an '
+                   'unbracketed launch); counters per launch from the PMC pass'}
+    if v:
+        out.update({'achieved': round(v['valu_busy_frac'], 4), 'peak': 1.0, 'unit': 'fraction of vector-unit cycles busy', 'frac': round(v['valu_busy_frac'], 4),
+                    'insts_valu_per_launch': v.get('insts_valu_per_launch'), 'waves': v.get('waves'),
+                    'formula': '4 x SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)'})
+    else:
+        out.update({'achieved': None, 'frac': None})
+    return out
 
 
 def kernel_sources_sha():
@@ -292,6 +309,7 @@ class Traffic:
 
     def __init__(self):
         self.table = {}
+        self.valu = {}
         self.source = None
         cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'traffic.json')), reverse=True)
         if not cands:
@@ -303,9 +321,13 @@ class Traffic:
             self.source += ' (stale: kernel sources changed since those PMC passes)'
         else:
             self.table = t.get('per_launch_bytes', {})
+            self.valu = t.get('valu', {})
 
     def get(self, key, default=None):
         return (self.table.get(key), self.source)
+
+    def valu_entry(self, key):
+        return self.valu.get(key)
 
 
 def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustained_s, traffic, cpu_sample, label, two_stream_s=0.0,
@@ -772,6 +794,7 @@ def main():
     roofline = full['roofline']
     roofline['k_dials_avg_launch_ms'] = full['kernel_ms'].get('k_dials')
     roofline['k_prep_avg_launch_ms'] = full['kernel_ms'].get('k_lplane')
+    roofline_dials = dials_roofline(full['kernel_ms'], traffic, main_label)
 
     fused = None
     if 'fused' in blocks:
@@ -805,7 +828,8 @@ def main():
                 'frames_per_s': round(world * B * args.steps / f4['elapsed'], 1), 'ms_per_step': round(f4['elapsed'] / args.steps * 1e3, 4),
                 'per_rank_ms_per_step': f4['per_rank_ms'], 'frames_read_ok_batch0': int((f4['recs'][:B]['status'] == 0).sum()),
                 'kernel_ms': f4['kernel_ms'], 'step_events': f4.get('step_events'), 'match_layout': f4.get('match_layout'),
-                'roofline': f4['roofline'], 'two_streams': f4.get('two_streams'), 'resident_hint': f4.get('resident_hint'),
+                'roofline': f4['roofline'], 'roofline_dials': dials_roofline(f4['kernel_ms'], traffic, 'config4'),
+                'two_streams': f4.get('two_streams'), 'resident_hint': f4.get('resident_hint'),
                 'cpu_baseline': f4.get('cpu')}
         f4['ctx'].close()
 
@@ -824,7 +848,7 @@ def main():
                        'untimed_preheat_steps': args.preheat},
             'per_rank_ms_per_step': full['per_rank_ms'], 'rccl_ranks': rccl_ranks, 'backend': env.backend,
             'kernel_ms': full['kernel_ms'], 'step_events': full.get('step_events'), 'match_layout': full.get('match_layout'),
-            'roofline': roofline, 'sustained': full.get('sustained'), 'two_streams': full.get('two_streams'),
+            'roofline': roofline, 'roofline_dials': roofline_dials, 'sustained': full.get('sustained'), 'two_streams': full.get('two_streams'),
             'resident_hint': full.get('resident_hint'),
             'cpu_baseline': full.get('cpu'),
             'fused_mask': fused, 'config4': cfg4, 'config5': cfg5, 'host_fed': hostfed, 'jpeg_decode': jpeg,

@@ -730,7 +730,7 @@ __device__ __forceinline__ McuWindow jpeg_zero_window(const JpegImageDev* R, con
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg_huff(const JpegImageDev* __restrict__ imgs, const HuffSlow* __restrict__ g_slow,
                                                  const uint8_t* __restrict__ scan, int16_t* __restrict__ coefs,
-                                                 int32_t* __restrict__ status, JpegWindow win)
+                                                 int32_t* __restrict__ status, JpegWindow win, int limit_to_window)
 {
     __shared__ uint32_t tab[4 << TAB_BITS];
     __shared__ uint32_t longtab[2 * LONG_N];
@@ -794,14 +794,44 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     }
     __syncthreads();
     JSTAMP(2);
+    // Window-limited convergence (round 4).  When only a window of the frame is wanted (melf_jpeg_process_batch: the
+    // meter_rect crop, MCU rows 9-27 of 40 on the fixtures), nothing behind the window's last MCU row is ever read: not
+    // the coefficients, not the DC predictors.  The synchronisation rounds then only have to settle the segments up to the
+    // one that holds the window's end, and the output pass skips the segments behind it.  Where that segment lies is
+    // estimated from the speculative pass's block counts (a wrongly-phased decoder still counts blocks almost right: a
+    // block too many or too few per segment at worst, i.e. a random walk of a few dozen blocks over 512 segments) with a
+    // margin of one and a half MCU rows, and CHECKED against the exact counts once the rounds are over: if the settled
+    // prefix does not reach the window's end after all, the rounds go on over every segment.  What is given up: a stream
+    // damaged only BEHIND the window is no longer reported corrupt (libjpeg would decode the window just the same).
+    const int wend = limit_to_window ? min(total_blocks, mwin.my1 * mcus_x * L.bpm) : total_blocks;   // first block behind the window
+    int cut = nseg - 1;                                               // last segment the rounds have to settle
+    if (wend < total_blocks) {
+        const int mine_n = sc_n[tid];
+        __syncthreads();
+        for (int off = 1; off < T; off <<= 1) {
+            const int a = tid >= off ? sc_n[tid - off] : 0;
+            __syncthreads();
+            sc_n[tid] += a;
+            __syncthreads();
+        }
+        // segments whose (estimated) first block lies behind the window's end + margin: not needed
+        const int first_blk = sc_n[tid] - mine_n;
+        const int need = mine && first_blk < wend + (3 * mcus_x * L.bpm) / 2 ? 1 : 0;
+        const int nneed = __syncthreads_count(need);                  // the needed segments are a prefix: their number
+        cut = max(0, min(nseg, nneed) - 1);
+        sc_n[tid] = mine_n;                                            // back to per-segment counts for the rounds
+        __syncthreads();
+    }
     int rounds = 0, redone = 0;  // reported by the diagnostic build only
     (void)rounds;
     (void)redone;
+    int nblk = 0, done_blocks = 0;
+    for (;;) {   // rounds over the segments up to `cut`, then the exact block counts; once more over all segments if they fall short
     for (;;) {
         // which segments see a new entry state?
         uint32_t np = 0, ns = 0;
         if (tid > 0) { np = e_p[tid - 1]; ns = e_s[tid - 1]; }
-        const bool ch = mine && (np != n_p[tid] || ns != n_s[tid]);
+        const bool ch = mine && tid <= cut && (np != n_p[tid] || ns != n_s[tid]);
         // compact them: position = number of changed segments before this one
         const uint64_t bal = __ballot(ch);
         const int wave = tid >> 6, lane = tid & 63;
@@ -859,9 +889,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
     }
     JSTAMP(3);
     // exclusive prefix over the segments: blocks completed
-    const int nblk = sc_n[tid];
-    const SegState entry = {n_p[tid], (int)(n_s[tid] >> 8), (int)(n_s[tid] & 255u)};
-    const uint32_t p_end = min((uint32_t)(tid + 1) * S, bits + 32u);
+    nblk = sc_n[tid];
     __syncthreads();
     for (int off = 1; off < T; off <<= 1) {
         const int a = tid >= off ? sc_n[tid - off] : 0;
@@ -869,13 +897,23 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
         sc_n[tid] += a;
         __syncthreads();
     }
+    done_blocks = sc_n[T - 1];
+    // the settled prefix must reach the window's end (it always does unless the estimate above was off by more than its margin)
+    if (cut >= nseg - 1 || sc_n[cut] >= wend) break;
+    __syncthreads();
+    sc_n[tid] = nblk;
+    cut = nseg - 1;
+    __syncthreads();
+    }
+    const bool limited = cut < nseg - 1;
+    const SegState entry = {n_p[tid], (int)(n_s[tid] >> 8), (int)(n_s[tid] & 255u)};
+    const uint32_t p_end = min((uint32_t)(tid + 1) * S, bits + 32u);
     JSTAMP(4);
-    const int done_blocks = sc_n[T - 1];
     const int nb_in = sc_n[tid] - (mine ? nblk : 0);
     // output pass: every segment from its true entry state and first block, DC predictors starting at ZERO -- the DC
     // coefficients it stores are sums of the segment's own differences; what they lack is known only after a prefix sum
     // over the segments of those sums (three 16-bit lanes of one 64-bit word), and a fix-up pass adds it
-    const bool ran = mine && nb_in < total_blocks;
+    const bool ran = mine && tid <= cut && nb_in < wend;   // (wend = total_blocks when the whole frame is wanted)
     int q0 = 0, q1 = 0, q2 = 0, ndc = 0;
     if (ran) {
         if (entry.blk != nb_in % L.bpm) bad = 1;  // the propagated state and the block count disagree: corrupt stream
@@ -935,10 +973,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80))) void k_jpeg
         __syncthreads();
         if (tid == 0 && img < 8192) g_jpeg_rounds[img] = ((uint32_t)rounds << 16) | (uint32_t)min(s_redone * 100 / max(nseg, 1), 65535);
     }
-    if (tid == 0) status[img] = (anybad || done_blocks < total_blocks) ? 2 : 0;
-#else
-    if (tid == 0) status[img] = (anybad || done_blocks < total_blocks) ? 2 : 0;
 #endif
+    // the whole scan settled: it must hold every block of the frame; a window-limited decode: the settled prefix reached the
+    // window's end (checked above) and the segments it decoded were consistent
+    if (tid == 0) status[img] = (anybad || (!limited && done_blocks < total_blocks)) ? 2 : 0;
 }
 
 // Streams with restart intervals need no speculation: every interval starts byte aligned with the DC
@@ -1479,8 +1517,9 @@ int jpeg_decode_batch_kernels(JpegWorkspace* w, int n, int H, int W, uint8_t* d_
         if (tenv < 0) { const char* e = getenv("MELF_JPEG_T"); tenv = e ? atoi(e) : 0; }
         // 512 lanes per image; a batch with a scan too long for 512 segments of the length the kernel can address takes 1024
         const int tsel = tenv ? tenv : (w->max_par_scan > JPEG_MAX_PAR_SCAN / 2 ? 1024 : 512);
+        static const int limit = getenv("MELF_JPEG_WINDOW_LIMIT") ? atoi(getenv("MELF_JPEG_WINDOW_LIMIT")) : 1;   // A/B switch
 #define LAUNCH_HUFF(TT) \
-    hipLaunchKernelGGL(k_jpeg_huff<TT>, dim3(n), dim3(TT), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status, win)
+    hipLaunchKernelGGL(k_jpeg_huff<TT>, dim3(n), dim3(TT), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status, win, limit)
         if (tsel == 128) LAUNCH_HUFF(128);
         else if (tsel == 256) LAUNCH_HUFF(256);
         else if (tsel == 1024) LAUNCH_HUFF(1024);

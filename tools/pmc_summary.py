@@ -7,7 +7,7 @@ import glob
 import sys
 
 NAMES = [('k_match_mfma', 'k_match_mfma'), ('k_match_gen', 'k_match_gen'), ('k_prep_lplane', 'k_prep_lplane'), ('k_rowsum', 'k_rowsum'),
-         ('k_colsum', 'k_colsum'), ('k_dials', 'k_dials'), ('k_fused_mask', 'k_fused_mask'), ('k_match', 'k_match_dot4'),
+         ('k_dials', 'k_dials'), ('k_fused_mask', 'k_fused_mask'), ('k_match', 'k_match_dot4'),
          ('k_jpeg_huff', 'k_jpeg_huff'), ('k_jpeg_idct', 'k_jpeg_idct'), ('k_jpeg_color', 'k_jpeg_color')]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects a round's profiles on the GPU box:  tools/profile_round.sh r03
+# Collects a round's profiles on the GPU box:  tools/profile_round.sh r04
 # Order matters: the PMC passes and traffic.json FIRST, so that the bench run under rocprofv3 finds a fresh traffic.json
 # (round 2 ran the bench first and its line carried `traffic: null (stale)`).
 #  1. HBM traffic counters, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md: they do not fit one
@@ -20,7 +20,7 @@
 # Everything lands in gpurun_out/prof_<round>/; copy it to profiles/<round>/ to commit it.
 set -e
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/prof_$R
 rm -rf $OUT /tmp/prof && mkdir -p $OUT /tmp/prof
 pmc() {  # name, command...
@@ -33,6 +33,18 @@ pmc() {  # name, command...
 }
 pmc config3 python3 tools/run_stage.py full --iters 8
 pmc config4 python3 tools/run_stage.py full --iters 8 --sample-dir sample-images2
+# k_dials is VALU-issue bound: issued vector instructions and the cycles the vector units were busy (SQ_ACTIVE_INST_VALU counts
+# quad-cycles per SIMD, MI355X_MICROARCH.md), the waves' lifetime, and the chip's active cycles (GRBM_GUI_ACTIVE: the sum over
+# the 8 XCDs) for the clock the launch ran at -- one pass, SQ has eight slots and GRBM two
+valu() {  # name, command...
+  name=$1; shift
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv \
+      --kernel-include-regex 'k_dials' -d /tmp/prof/valu_$name -- "$@" > /dev/null 2>&1
+  python3 tools/pmc_summary.py /tmp/prof/valu_$name > $OUT/pmc_dials_$name.txt
+  echo "valu $name done" >> $OUT/progress.txt
+}
+valu config3 python3 tools/run_stage.py full --iters 8
+valu config4 python3 tools/run_stage.py full --iters 8 --sample-dir sample-images2
 pmc config2 python3 tools/run_stage.py fused --iters 8
 pmc config5 python3 tools/run_stage.py fused --iters 4 --hw 1080x1920 --batch 512 --nbuf 1
 pmc jpeg python3 tools/jpeg_timing.py sample-images1 1024
@@ -52,8 +64,8 @@ def bytes_of(k):  # KiB counters; FETCH_SIZE doubled (gfx950 wide coalesced read
     return int(round((2 * k.get('FETCH_SIZE', 0.0) + k.get('WRITE_SIZE', 0.0)) * 1024))
 per = {}
 detail = {}
-for (cfg, kernels) in (('config3', ('k_match_mfma', 'k_match_gen', 'k_prep_lplane', 'k_colsum', 'k_dials')),
-                       ('config4', ('k_match_mfma', 'k_match_gen', 'k_prep_lplane', 'k_colsum', 'k_dials')),
+for (cfg, kernels) in (('config3', ('k_match_mfma', 'k_match_gen', 'k_prep_lplane', 'k_dials')),
+                       ('config4', ('k_match_mfma', 'k_match_gen', 'k_prep_lplane', 'k_dials')),
                        ('config2', ('k_fused_mask',)), ('config5', ('k_fused_mask',)),
                        ('jpeg', ('k_jpeg_huff', 'k_jpeg_idct', 'k_jpeg_color'))):
     d = load(cfg)
@@ -62,9 +74,23 @@ for (cfg, kernels) in (('config3', ('k_match_mfma', 'k_match_gen', 'k_prep_lplan
             short = 'k_match' if k.startswith('k_match') else k
             detail['%s:%s' % (cfg, k)] = bytes_of(d[k])
             per['%s:%s' % (cfg, short)] = bytes_of(d[k])
+valu = {}
+for cfg in ('config3', 'config4'):
+    try:
+        d = load('dials_' + cfg).get('k_dials', {})
+    except OSError:
+        d = {}
+    if d.get('SQ_ACTIVE_INST_VALU') and d.get('GRBM_GUI_ACTIVE'):
+        # vector units busy: quad-cycles x 4, summed over the 1024 SIMDs / (1024 SIMDs x the launch's cycles); GRBM_GUI_ACTIVE is
+        # the sum over the 8 XCDs of the cycles the launch kept the chip active
+        cyc = d['GRBM_GUI_ACTIVE'] / 8.0
+        valu[cfg + ':k_dials'] = {'insts_valu_per_launch': d.get('SQ_INSTS_VALU'), 'active_inst_valu_quadcycles': d['SQ_ACTIVE_INST_VALU'],
+                                  'wave_quadcycles': d.get('SQ_WAVE_CYCLES'), 'waves': d.get('SQ_WAVES'), 'busy_cycles': d.get('SQ_BUSY_CYCLES'),
+                                  'wait_inst_any_quadcycles': d.get('SQ_WAIT_INST_ANY'), 'gui_active_cycles_per_xcd': cyc,
+                                  'valu_busy_frac': 4.0 * d['SQ_ACTIVE_INST_VALU'] / (1024.0 * cyc)}
 json.dump({'_note': 'HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes '
-                    '(tools/profile_round.sh; raw counters: pmc_*.txt next to this file)',
-           'kernel_sources_sha16': bench.kernel_sources_sha(), 'per_launch_bytes': per, 'per_kernel': detail},
+                    '(tools/profile_round.sh; raw counters: pmc_*.txt next to this file); valu: k_dials vector-unit counters of one more pass',
+           'kernel_sources_sha16': bench.kernel_sources_sha(), 'per_launch_bytes': per, 'per_kernel': detail, 'valu': valu},
           open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
 print(json.dumps(per, indent=1))
 PY
