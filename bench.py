@@ -690,12 +690,30 @@ def jpeg_block(ctx, sample_dir, H, W):
     n_api = sum(1 for r in get_meter_values(pfile, names) if r.error is None)
     tg = time.perf_counter() - tg0
     release_cached_contexts()
+    # the same over TWO contexts on this GPU (METERELF_DEVICES=0,0: the multi-device fan-out of the API -- one reader, one host
+    # thread, one begin / end pipeline per entry -- exercised on the one GPU a rank has; on a node the entries are the node's GPUs)
+    dev = os.environ.get('METERELF_DEVICES')
+    os.environ['METERELF_DEVICES'] = '%d,%d' % (ctx.device, ctx.device)
+    try:
+        sum(1 for _ in get_meter_values(pfile, names[:4096]))
+        tg20 = time.perf_counter()
+        n_api2 = sum(1 for r in get_meter_values(pfile, names) if r.error is None)
+        tg2 = time.perf_counter() - tg20
+    finally:
+        if dev is None:
+            os.environ.pop('METERELF_DEVICES', None)
+        else:
+            os.environ['METERELF_DEVICES'] = dev
+        release_cached_contexts()
     return {'workload': '%d JPEG files (%d distinct %s fixtures, %.1f KB average) -> decode + full reading path, '
                         'file bytes in host memory to result records' % (JB, len(blobs), sample_dir, sum(map(len, blobs)) / len(blobs) / 1024),
             'files_per_s': round(JB / tj, 1), 'ms_per_call': round(tj * 1e3, 3),
             'get_meter_values': {'files_per_s': round(len(names) / tg, 1), 'files': len(names), 'values_read': n_api,
                                  'what': 'meterelf_amd.get_meter_values(params.yml, file names): the reference API, files read '
-                                         'from the page cache inside the library, MeterImageData objects out'},
+                                         'from the page cache inside the library, MeterImageData objects out',
+                                 'two_contexts_on_this_gpu': {'files_per_s': round(len(names) / tg2, 1), 'values_read': n_api2,
+                                                              'what': 'METERELF_DEVICES=d,d: the API\'s multi-device fan-out with both entries on this GPU '
+                                                                      '(same host cores, same GPU: a functional figure, not a scaling one)'}},
             'kernel_ms_per_call': {k: round(ms, 4) for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
             'kernel_launches_per_call': {k: c for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
             'decoded_frames_equal_libjpeg_turbo': same, 'files_ok': int((jstatus == 0).sum())}

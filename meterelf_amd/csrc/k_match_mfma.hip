@@ -263,8 +263,8 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     i32x4 buf[NBUF][NKB];
     // ONE set of template fragments (28 registers instead of 56): the request for the next template row's fragment d
     // is placed behind this row's last MFMA that reads fragment d -- a full step (70 MFMAs) ahead of its use, as
-    // before.  With the two-row epilogue batches this takes the kernel from 492 to ~390 of the SIMD's 512 registers:
-    // a wave of the other pipeline lane's dials kernel (104) or prep kernel (64) fits beside it.
+    // before.  (The kernel uses 447-488 of the SIMD's 512 registers, one wave per SIMD; round 2's register cap for a
+    // co-resident wave of another kernel is gone: profiles/r03/match_vgpr_cap_ab.txt.)
     i32x4 a[ND];
     // fused window sums: wsa[16 xb + e] of map row y0 for this lane's (frame, half); rwv = the row in flight
     uint32_t wsa[32];
