@@ -412,9 +412,15 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
 template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */>
 __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const uint8_t* __restrict__ frames, int n, int H, int W, int hue_shift, Bounds B,
-    const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB, int plain_store)
+    const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB, int plain_store, int rc_dma)
 {
     constexpr bool PREFETCH = PD > 0;
+    // PD < 0 (round 4, experiment MELF_FUSED_CONFIG=6): the pixel rows of a pass arrive by LDS-DMA with the non-temporal policy
+    // (global_load_lds_dwordx4 ... nt: 1 KiB lane-contiguous pieces straight into a staging buffer in LDS, two buffers: the
+    // next pass's rows land while this pass is processed), and every thread reads its 48 bytes back with three ds_read_b128.
+    // A bare stream of this traffic mix runs 5 % faster that way (tools/ubench/stream_lds.hip).  LDS: 64 KiB of tables + two
+    // staging buffers + the rings = one 1024-thread workgroup per CU, rows per pass cut to what fits (rc_dma).
+    constexpr bool DMA = PD < 0;
     constexpr bool AMB = VAR == 4;
     constexpr bool IV = VAR >= 6;
     constexpr bool SINGLE = VAR < 3 || VAR == 5;
@@ -456,7 +462,15 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     bool tables_ready = false;
 
     const int G16 = W >> 4;
-    const int RC = min(THREADS / G16, FUSED_MAX_RC);  // rows per pass
+    const int RC = DMA ? rc_dma : min(THREADS / G16, FUSED_MAX_RC);  // rows per pass
+    // DMA staging: two buffers of whole 1 KiB pieces behind the rings
+    const int pass_bytes = RC * W * 3, npieces = (pass_bytes + 1023) >> 10;
+    uint8_t* const stage_base = (uint8_t*)ring + (((size_t)2 * NB * wpr * 4 + 1023) & ~(size_t)1023);
+    const long frame_bytes = (long)H * W * 3;
+    auto lds_barrier = [&]() {   // a barrier that does NOT drain the vector-memory counter (an LDS-DMA in flight stays in flight)
+        if (DMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    };
     const int trow = tid / G16, tg = tid - trow * G16;
     const bool active = trow < RC;
     const int tgc = active ? tg : 0;
@@ -480,9 +494,31 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             const u32x4* p = (const u32x4*)(frame + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tgc) * 3u);
             dst.q0 = p[0]; dst.q1 = p[1]; dst.q2 = p[2];
         };
+        // DMA mode: request the rows [a, a + RC) of the frame into staging buffer `slot` (wave w takes pieces w, w + 16, ...)
+        auto issue = [&](int a, int slot) {
+            const long row0 = (long)a * W * 3;
+            for (int p = tid >> 6; p < npieces; p += THREADS / 64) {
+                long o = row0 + (long)p * 1024 + (long)(tid & 63) * 16;
+                o = o < 0 ? 0 : (o > frame_bytes - 16 ? frame_bytes - 16 : o);   // rows outside the frame: anything valid (their bits are zeroed)
+                __builtin_amdgcn_global_load_lds((const u32x4*)(frame + o),
+                                                 (__attribute__((address_space(3))) void*)(stage_base + (size_t)slot * npieces * 1024 + (size_t)p * 1024), 16, 0, 2 /* nt */);
+            }
+        };
+        int dma_slot = 0;
         auto pass = [&](int a, const Px16& cur) {
             // ---- (1) in-range bits of input rows [a, a+RC) ----
-            if (PREFETCH) {
+            if (DMA) {
+                const int y = a + trow;
+                uint32_t bits = 0;
+                if (active) {
+                    const u32x4* sp = (const u32x4*)(stage_base + (size_t)dma_slot * npieces * 1024 + (size_t)tid * 48);
+                    Px16 px;
+                    px.q0 = sp[0]; px.q1 = sp[1]; px.q2 = sp[2];
+                    bits = inrange16<VAR>(px, hue, ls, hue_shift, B);
+                }
+                bits = (y >= 0 && y < H) ? bits : 0u;
+                if (active && y < r1 + 2) ((uint16_t*)raw)[__umul24((y + 4 * NB) & nbm, wpr * 2) + tg] = (uint16_t)bits;
+            } else if (PREFETCH) {
                 const int y = a + trow;
                 uint32_t bits = inrange16<VAR>(cur, hue, ls, hue_shift, B);
                 bits = (y >= 0 && y < H) ? bits : 0u;
@@ -501,7 +537,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                     ((uint16_t*)raw)[((y + 4 * NB) & nbm) * wpr * 2 + tg] = (uint16_t)bits;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- (2) rows [a-1, a+RC-2]: 3x3 dilation, then the horizontal part of the erosion.
             //      Pixels outside the image are neutral (never win): 0 for the dilation, 1 for the erosion.
             if (drow < RC) {
@@ -530,13 +566,14 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                     he[__umul24((y + 4 * NB) & nbm, wpr) + dk] = v;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- (3) rows [a-2, a+RC-3] of the segment: vertical AND, expand, store ----
             // gfx9 counts loads and stores in the same vmcnt and the compiler treats them as completing
             // out of order, so a wait for the prefetched pixels issued AFTER this pass's store would also
             // wait for the store's write-ack (a full memory round trip per pass).  Waiting here, just
             // before the store is issued, costs nothing: the only store in flight is one pass old.
             if (PD > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (PD - 1)));  // vmcnt(3*(PD-1)), others untouched
+            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next pass's rows have landed (this wave's pieces); the store below is younger
             {
                 const int y = a - 2 + trow;
                 if (active && y >= r0 && y < r1) {
@@ -555,11 +592,26 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                 }
             }
             // no barrier needed here: the rings (NB >= 2*RC + 4 rows) keep this pass's rows apart
-            // from the rows the next pass writes
+            // from the rows the next pass writes.  DMA mode: every wave's pieces of the next pass must have landed before
+            // any wave reads the staging buffer
+            if (DMA) { asm volatile("s_barrier" ::: "memory"); dma_slot ^= 1; }
         };
         int a = r0 - 2;
         const int aend = r1 + 2;
-        if (PREFETCH) {
+        if constexpr (DMA) {
+            dma_slot = 0;
+            issue(a, 0);
+            if (!tables_ready) {  // the first rows are in flight while LDS is filled
+                fill_tables();
+                tables_ready = true;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const Px16 unused = {};
+            for (; a < aend; a += RC) {
+                if (a + RC < aend) issue(a + RC, dma_slot ^ 1);
+                pass(a, unused);
+            }
+        } else if constexpr (PREFETCH) {
             // PD + 1 rotating register sets: the loads of the next PD passes are in flight while the
             // current pass is processed (all indices are compile-time after unrolling)
             Px16 pbuf[PD + 1];
@@ -591,7 +643,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             const Px16 unused = {};
             for (; a < aend; a += RC) pass(a, unused);
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -616,10 +668,21 @@ template <int V, int T, int PF, int WPS>
 static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
                          const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
-    const int G16 = W >> 4, RC = T / G16 < FUSED_MAX_RC ? T / G16 : FUSED_MAX_RC, wpr = (W + 31) >> 5;
+    const int G16 = W >> 4, wpr = (W + 31) >> 5;
+    int RC = T / G16 < FUSED_MAX_RC ? T / G16 : FUSED_MAX_RC;
     int NB = 8;
     while (NB < 2 * RC + 4) NB <<= 1;
-    const int per_cu = WPS * 256 / T;          // resident workgroups per CU
+    size_t dma_bytes = 0;   // PF < 0: two staging buffers behind the rings; rows per pass cut to what the CU's 160 KiB hold
+    if (PF < 0) {
+        for (;; --RC) {
+            NB = 8;
+            while (NB < 2 * RC + 4) NB <<= 1;
+            const size_t ringb = (((size_t)2 * NB * wpr * 4 + 1023) & ~(size_t)1023), sb = (((size_t)RC * W * 3 + 1023) >> 10) << 10;
+            dma_bytes = ringb + 2 * sb - (size_t)2 * NB * wpr * 4;
+            if (RC <= 1 || 65664 + ringb + 2 * sb <= 160 * 1024) break;   // 65 600 bytes of static LDS (tables, expand table)
+        }
+    }
+    const int per_cu = PF < 0 ? 1 : WPS * 256 / T;          // resident workgroups per CU
     const int target = 256 * (per_cu < 1 ? 1 : per_cu);
     static const int seg_mult = getenv("MELF_FUSED_SEGMULT") ? atoi(getenv("MELF_FUSED_SEGMULT")) : 1;  // experiments
     static const int plain_store = getenv("MELF_FUSED_PLAINSTORE") ? atoi(getenv("MELF_FUSED_PLAINSTORE")) : 0;
@@ -629,12 +692,12 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     segs = (H + seg_rows - 1) / seg_rows;
     const long total = (long)n * segs;
     const int grid = (int)(total < target ? total : target);
-    const size_t shmem = (size_t)(2 * NB * wpr) * sizeof(uint32_t);
+    const size_t shmem = (size_t)(2 * NB * wpr) * sizeof(uint32_t) + dma_bytes;
     static bool attr_set[64] = {false};  // per device (several contexts on several GPUs may live in one process)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, PF < 0 ? 160 * 1024 - 65664 : 28 * 1024);
         if (getenv("MELF_FUSED_TRACE")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fused_mask_lut<V, T, PF, WPS>, T, shmem);
@@ -645,7 +708,7 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // timing events (optional, set by the caller through fused_mask_timing_events): the dispatch's own start / stop stamps,
     // no event-record packets in the queue around the kernel
     hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
-                          n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, plain_store);
+                          n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, plain_store, RC);
     g_fused_ev_start = g_fused_ev_stop = nullptr;
 }
 
@@ -660,6 +723,7 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
             case 3: launch_lut_t<V, 1024, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 4: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 5: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 6: launch_lut_t<V, 1024, -1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;   // LDS-DMA staging
             case 0: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             default: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         }
@@ -688,10 +752,9 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
 {
     Bounds B;
     for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
-    static bool env_read = false;
-    if (!env_read) {
-        if (const char* e = getenv("MELF_FUSED_CONFIG")) g_fused_config = atoi(e) & 7;
-        env_read = true;
+    {   // read at every launch (a getenv is nothing beside a launch): tests and A/B scripts switch it inside one process
+        const char* e = getenv("MELF_FUSED_CONFIG");
+        g_fused_config = e ? atoi(e) & 7 : -1;
     }
     switch (variant) {
         case 0: launch_lut_v<0>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;

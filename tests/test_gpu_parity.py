@@ -205,6 +205,25 @@ def test_fused_mask_other_bounds(env, tmp_path, needle):
         reader.close()
 
 
+def test_fused_mask_lds_dma_launch_shape(env, monkeypatch):
+    """MELF_FUSED_CONFIG=6 (round 4's experiment: pixel rows through LDS-DMA into two staging buffers, one workgroup per CU)
+    must stay what it is measured as: the same masks as the oracle's, on an aligned and on a narrow shape and at 1080p."""
+    from meterelf_amd import MeterReader
+    from oracle import pyoracle as po
+    monkeypatch.setenv('MELF_FUSED_CONFIG', '6')     # read by the library at every fused launch
+    rng = np.random.default_rng(66)
+    reader = MeterReader(env['sample-images1']['params'])
+    try:
+        p = reader.ctx.params
+        for (n, H, W) in ((2, 640, 480), (1, 1080, 1920), (3, 50, 64)):
+            frames = _blobby(rng, n, H, W)
+            got = reader.ctx.hls_inrange_close(frames)
+            for f in range(n):
+                assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
+    finally:
+        reader.close()
+
+
 def test_fused_mask_on_fixture_frames(env):
     from meterelf_amd._image import imread_bgr
     from oracle import pyoracle as po
