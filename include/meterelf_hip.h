@@ -233,9 +233,11 @@ int melf_jpeg_process_files(melf_ctx* ctx, const char* const* paths, int n, int3
 /* The same call in two halves, for a host that wants to work on the previous chunk's records meanwhile
  * (get_meter_values does: meterelf_amd/_api.py): _begin returns at once and the call runs on a thread of the library,
  * _end waits for the OLDEST call begun and returns its status code (message via melf_last_error as usual).  Up to
- * two calls may be in flight per context: the second one's files are read while the first one decodes (a third
- * _begin fails with MELF_ERR_INVALID); every pointer must stay valid until the call's own _end; no other call on the
- * context while any is in flight. */
+ * MELF_FILES_IN_FLIGHT_MAX calls may be in flight per context -- one reading its files, one preparing and enqueueing
+ * its GPU work, one waiting for its kernels (one more _begin fails with MELF_ERR_INVALID); every pointer must stay
+ * valid until the call's own _end; no other call on the context while any is in flight. */
+#define MELF_FILES_IN_FLIGHT_MAX 3
+int melf_jpeg_files_in_flight_max(void); /* the value the library was built with */
 int melf_jpeg_process_files_begin(melf_ctx* ctx, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                                   melf_result* out_host, int32_t* status);
 int melf_jpeg_process_files_end(melf_ctx* ctx);

@@ -144,11 +144,11 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
         except ImageProcessingError as e:
             return e
 
-    # GPU decode: the library works on the chunks k + 1 and k + 2 on its own threads (melf_jpeg_process_files_begin / _end,
-    # two calls in flight: chunk k + 2's files are read while chunk k + 1 decodes) while this thread turns chunk k's
-    # records into Python objects and the consumer handles them.
+    # GPU decode: the library works on the chunks k + 1 .. k + 3 on its own threads (melf_jpeg_process_files_begin / _end,
+    # three calls in flight: one reading its files, one preparing and enqueueing, one waiting for its kernels) while this
+    # thread turns chunk k's records into Python objects and the consumer handles them.
     clean = False  # the generator ran to its end (or was closed between chunks with nothing in flight)
-    DEPTH = 2
+    DEPTH = _hip.FILES_IN_FLIGHT_MAX
 
     def _gpu_read(chunk: List[str]):
         if hasattr(reader, 'read_jpeg_paths_batch'):

@@ -190,8 +190,8 @@ class MeterReader:
 
     def read_jpeg_paths_begin(self, paths: List[str]) -> None:
         """read_jpeg_paths_batch in two halves: the library works on `paths` on its own thread until
-        read_jpeg_paths_end() collects (records, ok) of the OLDEST list begun.  Up to two lists may be in flight (the
-        second one's files are read while the first decodes); nothing else may use this reader while any is --
+        read_jpeg_paths_end() collects (records, ok) of the OLDEST list begun.  Up to _hip.FILES_IN_FLIGHT_MAX lists may be in
+        flight (a later one's files are read while an earlier one decodes); nothing else may use this reader while any is --
         drain_jpeg_paths() first."""
         paths = list(paths)
         self.ctx.jpeg_process_files_begin(paths)

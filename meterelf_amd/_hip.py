@@ -26,6 +26,7 @@ FRAME_ANGLE_UNDETERMINED = 3
 
 K_LPLANE, K_MATCH, K_DIALS, K_FUSED_MASK, K_HLS, K_JPEG_HUFF, K_JPEG_IDCT, K_JPEG_COLOR, K_COUNT = range(9)
 JPEG_OK, JPEG_UNSUPPORTED, JPEG_CORRUPT, JPEG_SIZE_MISMATCH, JPEG_UNREADABLE = 0, 1, 2, 3, 4
+FILES_IN_FLIGHT_MAX = 3   # MELF_FILES_IN_FLIGHT_MAX (include/meterelf_hip.h); tests compare with melf_jpeg_files_in_flight_max()
 
 
 class MelfDial(C.Structure):
@@ -78,7 +79,7 @@ EXPORTS = [
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_match_gen_plan_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
-    'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end',
+    'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end', 'melf_jpeg_files_in_flight_max',
 ]
 
 _lib = None
@@ -136,6 +137,7 @@ def lib():
     L.melf_jpeg_process_files.argtypes = [vp, vp, C.c_int, i32p, i32p, vp, vp]
     L.melf_jpeg_process_files_begin.argtypes = [vp, vp, C.c_int, i32p, i32p, vp, vp]
     L.melf_jpeg_process_files_end.argtypes = [vp]
+    L.melf_jpeg_files_in_flight_max.argtypes = []
     if L.melf_abi_version() != ABI_VERSION:
         raise HipError('libmeterelf_hip.so ABI version mismatch')
     _lib = L
@@ -428,8 +430,8 @@ class Context:
 
     def jpeg_process_files_begin(self, paths):
         """Starts jpeg_process_files(paths) on a thread of the library and returns at once; jpeg_process_files_end()
-        waits for the oldest call begun.  Up to two calls in flight per context (the second one's files are read while
-        the first decodes), no other call on the context in between."""
+        waits for the oldest call begun.  Up to FILES_IN_FLIGHT_MAX calls in flight per context (one reading its files, one
+        preparing and enqueueing, one waiting for its kernels), no other call on the context in between."""
         n = len(paths)
         out = np.zeros(n, dtype=RESULT_DTYPE)
         status = np.zeros(n, np.int32)

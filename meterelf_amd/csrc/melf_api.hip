@@ -278,9 +278,10 @@ struct melf_ctx {
     JpegWorkspace* jpeg_ring[NJ] = {};  // [0] is unused: slot 0 is `jpeg` itself
     hipStream_t jpeg_stream[NJ] = {};   // [0] unused: slot 0 decodes on the context's stream
     hipEvent_t ev_jup[NJ] = {}, ev_jdec[NJ] = {};
-    // per CALL slot (two calls of the file-name API may overlap: the second one's preparation and uploads run while the
-    // first one's kernels do): the decoded frames, the records, the files' decode status in pinned memory, "call done"
-    static const int NJC = 2;
+    // per CALL slot (calls of the file-name API overlap: the next one's preparation and uploads run while the previous
+    // one's kernels do): the decoded frames, the records and the files' decode status in pinned memory, "call done".
+    // As many slots as calls in flight: call k + NJC can only be begun after call k's _end.
+    static const int NJC = MELF_FILES_IN_FLIGHT_MAX;
     uint8_t* d_jframes[NJC] = {};
     size_t jframes_cap[NJC] = {};
     melf_result* d_jresults[NJC] = {};
@@ -293,7 +294,9 @@ struct melf_ctx {
     // call no fresh pages to fault in), and the call in flight of the begin / end pair
     // Up to NFJ begin / end calls in flight: each on its own thread, which READS its files at once (into the arena of its
     // slot) and then waits for its turn at the context (decode + reading path, in the order of the _begin calls).
-    static const int NFJ = 2;
+    // Three stages, three calls: one reads its files, one prepares and enqueues, one waits for its kernels (with two, the
+    // file reads of call k + 2 could only start when call k was over and the GPU sat idle meanwhile).
+    static const int NFJ = MELF_FILES_IN_FLIGHT_MAX;
     struct FilesJob {
         std::thread th;
         int rc = 0;
@@ -1492,6 +1495,12 @@ extern "C" int melf_jpeg_decode_batch(melf_ctx* c, const uint8_t* const* data, c
 // assumes the GPU is its own.
 // INVARIANT: once a call has run (*tl_jpeg_enqueued)() it touches nothing of the context but its own call slot
 // (d_jframes / d_jresults / h_jstatus / ev_jcall [slot]); everything else belongs to the next call from that moment on.
+static size_t jrecs_offset(size_t n) { return (n * sizeof(int32_t) + 127) / 64 * 64; }   // records behind n status words
+static double trace_clock_ms(std::chrono::steady_clock::time_point t)
+{
+    static const auto epoch = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t - epoch).count();
+}
 static thread_local int tl_jpeg_slot = 0;
 static thread_local bool tl_jpeg_files_thread = false;
 static thread_local std::function<void()>* tl_jpeg_enqueued = nullptr;
@@ -1638,7 +1647,10 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     if (c->jstatus_cap[cs] < (size_t)n) {
         if (c->h_jstatus[cs]) HIP_TRY(hipHostFree(c->h_jstatus[cs]));
         c->h_jstatus[cs] = nullptr; c->jstatus_cap[cs] = 0;
-        HIP_TRY(hipHostMalloc((void**)&c->h_jstatus[cs], (size_t)n * sizeof(int32_t) + 64, hipHostMallocDefault));
+        // status words, then (64-byte aligned) the call's records: hipMemcpyAsync into the CALLER's pageable array would
+        // not return before the copy has run, i.e. before all of the call's kernels have -- the hand-over below would come
+        // at the end of the call instead of at "enqueued" (rounds 3-4 measured two calls in flight no faster than one)
+        HIP_TRY(hipHostMalloc((void**)&c->h_jstatus[cs], jrecs_offset((size_t)n) + (size_t)n * sizeof(melf_result), hipHostMallocDefault));
         c->jstatus_cap[cs] = (size_t)n;
     }
     if (!c->ev_jcall[cs]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jcall[cs], hipEventDisableTiming));
@@ -1656,8 +1668,7 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     }
     // records and the decode status back, one synchronisation
     const auto tc1 = std::chrono::steady_clock::now();
-    std::vector<melf_result> ordered;
-    melf_result* const recs = perm.empty() ? out_host : (ordered.resize(n), ordered.data());
+    melf_result* const recs = (melf_result*)((uint8_t*)c->h_jstatus[cs] + jrecs_offset(c->jstatus_cap[cs]));   // pinned
     HIP_TRY(hipMemcpyAsync(recs, c->d_jresults[cs], (size_t)n * sizeof(melf_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_jcall[cs], c->stream));
     // everything of this call is enqueued: from here on it touches only its own slot's buffers, and the next call in flight
@@ -1665,18 +1676,16 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     if (tl_jpeg_enqueued) (*tl_jpeg_enqueued)();
     HIP_TRY(hipEventSynchronize(c->ev_jcall[cs]));
     if (trace) {
-        static const auto t_first = tc0;  // absolute times (ms since the first traced call) show how consecutive calls overlap
-        const auto tc2 = std::chrono::steady_clock::now();
+        const auto tc2 = std::chrono::steady_clock::now();  // absolute times (process clock) show how consecutive calls overlap
         fprintf(stderr, "[melf jpeg] pipelined call n=%d (%d sparse files first): %.2f ms enqueueing (host prepare + launches), %.2f ms waiting for the GPU"
                         " [start %.2f, enqueued %.2f, done %.2f]\n", n,
                 nsparse, std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(tc2 - tc1).count(),
-                std::chrono::duration<double, std::milli>(tc0 - t_first).count(), std::chrono::duration<double, std::milli>(tc1 - t_first).count(),
-                std::chrono::duration<double, std::milli>(tc2 - t_first).count());
+                trace_clock_ms(tc0), trace_clock_ms(tc1), trace_clock_ms(tc2));
     }
     for (int i = 0; i < n; ++i) {
         const int o = perm.empty() ? i : perm[i];
         status[o] = hstat[i] ? hstat[i] : (c->h_jstatus[cs][i] ? MELF_JPEG_CORRUPT : MELF_JPEG_OK);
-        if (!perm.empty()) out_host[o] = recs[i];
+        out_host[o] = recs[i];
     }
     return MELF_SUCCESS;
 }
@@ -1828,16 +1837,16 @@ extern "C" int melf_jpeg_process_files(melf_ctx* c, const char* const* paths, in
 // The same call split in two for a scripting host: _begin returns at once, the work (file reads, Huffman tables,
 // upload, kernels, records) runs on a thread of the library, _end waits for the OLDEST call begun and returns its
 // code.  Between the two the caller can turn the previous chunk's records into its own objects -- with a helper thread
-// of the host language instead, the interpreter lock's hand-over (5 ms in CPython) eats the overlap.  Up to two calls
-// may be in flight per context: the second one's files are read while the first one decodes (the decode stages run
-// one after the other, in the order of the _begin calls).  All pointers must stay valid until the call's _end; no
+// of the host language instead, the interpreter lock's hand-over (5 ms in CPython) eats the overlap.  Up to
+// MELF_FILES_IN_FLIGHT_MAX calls may be in flight per context: a later one's files are read while an earlier one decodes
+// (the decode stages run one after the other, in the order of the _begin calls).  All pointers must stay valid until the call's _end; no
 // other call on the context while any is in flight.
 extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                                              melf_result* out_host, int32_t* status)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
     if ((int)c->files_jobs.size() >= melf_ctx::NFJ)
-        return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_begin: two calls are already in flight on this context");
+        return fail(MELF_ERR_INVALID, "melf_jpeg_process_files_begin: as many calls as the context takes are already in flight (MELF_FILES_IN_FLIGHT_MAX)");
     melf_ctx::FilesJob* job = nullptr;
     try {
         job = new melf_ctx::FilesJob();
@@ -1846,15 +1855,21 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
             // whatever happens in the stages, the ticket must be handed on: the next call's decode stage waits for it
             int rc = MELF_SUCCESS;
             FilesRead R;
+            static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+            const auto tb0 = std::chrono::steady_clock::now();
             try {
                 rc = jpeg_files_read(c, (int)(ticket % melf_ctx::NFJ), paths, n, H_used, W_used, out_host, status, R);
             } catch (const std::exception& e) {
                 rc = fail(MELF_ERR_INVALID, std::string("out of host memory: ") + e.what());
             }
+            const auto tb1 = std::chrono::steady_clock::now();
             {
                 std::unique_lock<std::mutex> lk(c->files_m);
                 c->files_cv.wait(lk, [&]() { return c->files_decode_turn == ticket; });
             }
+            if (trace)
+                fprintf(stderr, "[melf jpeg] call %llu: thread up at %.2f, files read by %.2f, its turn at %.2f (process clock, ms)\n",
+                        (unsigned long long)ticket, trace_clock_ms(tb0), trace_clock_ms(tb1), trace_clock_ms(std::chrono::steady_clock::now()));
             // the turn goes on as soon as this call has ENQUEUED all its GPU work (the next call then prepares and enqueues
             // while this one's kernels run), at the latest when the call is over
             bool released = false;
@@ -1887,6 +1902,8 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
     c->files_jobs.push_back(job);
     return MELF_SUCCESS;
 }
+
+extern "C" int melf_jpeg_files_in_flight_max(void) { return MELF_FILES_IN_FLIGHT_MAX; }
 
 extern "C" int melf_jpeg_process_files_end(melf_ctx* c)
 {

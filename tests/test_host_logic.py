@@ -31,6 +31,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert sorted(_hip.EXPORTS) == declared
+    # constants the Python side mirrors from the header
+    assert L.melf_jpeg_files_in_flight_max() == _hip.FILES_IN_FLIGHT_MAX == int(re.search(r'#define MELF_FILES_IN_FLIGHT_MAX (\d+)', text).group(1))
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -274,7 +276,7 @@ class _TwoInFlightReader:
         return self._records(paths)
 
     def read_jpeg_paths_begin(self, paths):
-        assert len(self.flight) < 2, 'third list in flight'
+        assert len(self.flight) < _hip.FILES_IN_FLIGHT_MAX, 'one list too many in flight'
         self.flight.append(list(paths))
         _TwoInFlightReader.log.append('begin %d' % len(paths))
 
@@ -335,8 +337,8 @@ def test_get_meter_values_keeps_two_chunks_in_flight(tmp_path, monkeypatch):
     assert log.count('close') == 1 and log[-1] == 'close'
     assert log.count('begin 100') == 6 and log.count('begin 30') == 1      # chunks 2..8 went through begin / end
     assert log.count('drain') >= 6                                          # every chunk with a host-branch file
-    # two lists are begun right after the first chunk came back, before its records are used
-    assert log[:2] == ['begin 100', 'begin 100']
+    # as many lists as the library takes are begun right after the first chunk came back, before its records are used
+    assert log[:3] == ['begin 100'] * _hip.FILES_IN_FLIGHT_MAX
     # a consumer that stops early leaves nothing in flight
     _TwoInFlightReader.log = []
     gen = _api.get_meter_values(pfile, files)

@@ -335,8 +335,8 @@ def test_get_meter_values_never_touches_the_host_decoder_for_fixtures(sd, monkey
 
 @pytest.mark.gpu
 def test_process_files_in_two_halves(tmp_path):
-    """melf_jpeg_process_files_begin / _end: the records of the one-piece call; TWO calls may be in flight (the second one's
-    files are read while the first decodes) and come back in order; a third _begin, the one-piece call meanwhile and an _end
+    """melf_jpeg_process_files_begin / _end: the records of the one-piece call; THREE calls may be in flight (a later one's
+    files are read while an earlier one decodes) and come back in order; a fourth _begin, the one-piece call meanwhile and an _end
     without _begin are refused; files of two frame sizes and an unreadable one are routed as in the one-piece call."""
     from meterelf_amd import MeterReader, _hip, _params
     reader = MeterReader(_params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml')))
@@ -349,17 +349,21 @@ def test_process_files_in_two_halves(tmp_path):
             reader.ctx._files_pending = [(None, None, (None, None), None, None)]
             reader.ctx.jpeg_process_files_end()  # nothing in flight
         assert reader.ctx.files_in_flight() == 0
+        assert _hip.FILES_IN_FLIGHT_MAX == 3
         reader.ctx.jpeg_process_files_begin(files)
         reader.ctx.jpeg_process_files_begin(other)
-        assert reader.ctx.files_in_flight() == 2
+        reader.ctx.jpeg_process_files_begin(files)
+        assert reader.ctx.files_in_flight() == 3
         pending = list(reader.ctx._files_pending)
         with pytest.raises(_hip.HipError):
-            reader.ctx.jpeg_process_files_begin(files[:3])  # two calls in flight per context, not three
+            reader.ctx.jpeg_process_files_begin(files[:3])  # three calls in flight per context, not four
         with pytest.raises(_hip.HipError):
             reader.ctx.jpeg_process_files(files[:3])  # nor the one-piece call meanwhile
         reader.ctx._files_pending = pending
         (got, status, hw) = reader.ctx.jpeg_process_files_end()
         (got2, status2, hw2) = reader.ctx.jpeg_process_files_end()
+        (got3, status3, hw3) = reader.ctx.jpeg_process_files_end()
+        assert hw3 == ref_hw and np.array_equal(status3, ref_status) and got3[status3 == 0].tobytes() == ref[ref_status == 0].tobytes()
         assert hw == ref_hw and np.array_equal(status, ref_status)
         assert hw2 == ref2_hw and np.array_equal(status2, ref2_status)
         ok2 = status2 == _hip.JPEG_OK

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The file-name C entry points alone (melf_jpeg_process_files_begin / _end, two calls in flight), without the Python side
+"""The file-name C entry points alone (melf_jpeg_process_files_begin / _end, one to three calls in flight), without the Python side
 of get_meter_values: path arrays marshalled once, records not converted -- what a compiled host gets.
     python3 tools/files_api_rate.py [chunk]"""
 import ctypes as C
@@ -33,7 +33,7 @@ def begin(j):
     _hip.check(L.melf_jpeg_process_files_begin(h, arr, n, C.byref(H), C.byref(W), out.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)))
 
 
-for depth in (1, 2):
+for depth in range(1, _hip.FILES_IN_FLIGHT_MAX + 1):
     for rep in range(2):
         t0 = time.perf_counter()
         inflight = 0
