@@ -1526,9 +1526,22 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
                                  std::vector<int32_t>& hstat, bool read_chunks, int first_len, uint8_t* d_frames, melf_result* d_results,
                                  int32_t* h_status, bool overlapped)
 {
-    // 512 files per chunk: the Huffman kernel's time hardly depends on the chunk size (critical path), so fewer, larger
-    // chunks cost fewer launches; measured per 1024-file call: chunks of 128 / 256 / 512 files 6.1 / 3.4 / 2.8 ms
-    const int chunk = getenv("MELF_JPEG_CHUNK") ? std::max(32, atoi(getenv("MELF_JPEG_CHUNK"))) : 512;
+    // 256 files per chunk.  A call's critical path is: first chunk parsed and prepared -> ALL uploads back to back (36 MB at
+    // ~42 GB/s: 0.85 ms per 1024 fixture files, the longest item) -> the LAST chunk's Huffman kernel (0.4-0.5 ms whatever the
+    // chunk's size: its rounds are a latency chain) -> IDCT / colour of that chunk -> the reading path.  Smaller chunks start
+    // the uploads earlier and leave less behind the last one; below 256 the per-chunk launches cost more than that gains
+    // (round 4, tools/jpeg_call_rate.py, medians of 96 interleaved calls: 512 / 256 / 128+4x256.. = 2.37 / 2.30 / 2.36 ms on
+    // sample-images1, 1.85 / 1.83 / 1.92 on sample-images2; round 3 with every header parsed up front: 2.43 / 1.93).
+    // MELF_JPEG_CHUNK: one size, or a comma-separated plan "a,b,c" (the last entry repeats)
+    std::vector<int> plan;
+    if (const char* e = getenv("MELF_JPEG_CHUNK")) {
+        for (const char* q = e; *q;) {
+            plan.push_back(std::max(32, atoi(q)));
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    if (plan.empty()) plan.push_back(256);
     constexpr int NJ = melf_ctx::NJ;
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int b = 0; b < NJ; ++b) {
@@ -1552,15 +1565,24 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
     // the ring position moves on past every chunk this call touched, also when it fails half way through one
     struct SeqGuard { melf_ctx* c; uint64_t seq0; const int* k; bool done; ~SeqGuard() { c->jpeg_chunk_seq = seq0 + (uint64_t)*k + (done ? 0 : 1); } } seq_guard{c, seq0, &k, false};
     // every file's headers in one parallel pass; the chunks then only build tables and clean scans
-    struct ParsedGuard { JpegParsed* p; ~ParsedGuard() { jpeg_parsed_free(p); } } parsed{jpeg_parse_files(data, sizes, n, H, W, hstat.data())};
-    for (int f0 = 0, m = 0; f0 < n; f0 += m, ++k) {
-        m = (k == 0 && first_len > 0) ? first_len : chunk;
+    // (MELF_JPEG_PARSE=all, the round-3 arrangement; by default each chunk parses its own files, so that only the first
+    // chunk's headers are parsed before the first upload can start: 0.24 ms of a 1024-file call's head otherwise)
+    const char* pmode = getenv("MELF_JPEG_PARSE");
+    const bool parse_all = pmode && !strcmp(pmode, "all");
+    struct ParsedGuard { JpegParsed* p; ~ParsedGuard() { if (p) jpeg_parsed_free(p); } } parsed{parse_all ? jpeg_parse_files(data, sizes, n, H, W, hstat.data()) : nullptr};
+    for (int f0 = 0, m = 0, planned = 0; f0 < n; f0 += m, ++k) {
+        m = (k == 0 && first_len > 0) ? first_len : plan[std::min(planned++, (int)plan.size() - 1)];
         if (m > n - f0) m = n - f0;
         const uint64_t seq = seq0 + (uint64_t)k;
         const int b = (int)(seq % NJ);
+        static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+        double tt[5] = {};
+        if (trace) tt[0] = trace_clock_ms(std::chrono::steady_clock::now());
         // the upload that last read this workspace's pinned stage buffer must be done before the host refills it
         if (seq >= (uint64_t)NJ) HIP_TRY(hipEventSynchronize(c->ev_jup[b]));
+        if (trace) tt[1] = trace_clock_ms(std::chrono::steady_clock::now());
         if (int rc = jpeg_prepare_batch(ws[b], data + f0, sizes + f0, m, H, W, hstat.data() + f0, &err, parsed.p, f0)) return fail(rc, err);
+        if (trace) tt[2] = trace_clock_ms(std::chrono::steady_clock::now());
         // ... and the kernels that last read its device buffers before the upload overwrites them
         if (seq >= (uint64_t)NJ) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_jdec[b], 0));
         if (int rc = jpeg_upload_batch(*ws[b], m, c->copy_stream, &err)) return fail(rc, err);
@@ -1570,6 +1592,7 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
         if (int rc = jpeg_decode_batch_kernels(*ws[b], m, H, W, d_frames + (size_t)f0 * H * W * 3, dstream[b], &err, jpeg_timer_hook, &t, rect))
             return fail(rc, err);
         HIP_TRY(hipMemcpyAsync(h_status + f0, jpeg_device_status(*ws[b]), (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, dstream[b]));
+        if (trace) tt[3] = trace_clock_ms(std::chrono::steady_clock::now());
         if (read_chunks) {
             c->active_lane = k % melf_ctx::NLANES;
             if (int rc = claim_lane(c, c->active_lane, dstream[b])) return rc;
@@ -1578,6 +1601,11 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
                 return rc;
         }
         HIP_TRY(hipEventRecord(c->ev_jdec[b], dstream[b]));
+        if (trace) {
+            tt[4] = trace_clock_ms(std::chrono::steady_clock::now());
+            fprintf(stderr, "[melf jpeg]   chunk %d (%d files, ring slot %d): at %.2f, slot free %.2f, prepared %.2f, decode enqueued %.2f, all enqueued %.2f\n",
+                    k, m, b, tt[0], tt[1], tt[2], tt[3], tt[4]);
+        }
     }
     // the context's stream continues when this call's decode streams are done (a slot's latest record covers its earlier ones)
     for (int q = k > NJ ? k - NJ : 0; q < k; ++q) {
@@ -1639,7 +1667,8 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     }
     std::vector<int32_t> hstat;
     // the reading path: ONE pass over all n frames behind the last chunk (the tuned match kernel in its full-batch layout);
-    // MELF_JPEG_READ=chunk runs it per chunk on the chunk's stream instead (measured equal within noise)
+    // MELF_JPEG_READ=chunk runs it per chunk on the chunk's stream instead (3 % faster on sample-images1, 1 % slower on
+    // sample-images2, equal with three calls in flight: not the default, the full-batch layout is what the tests assert)
     const char* rmode = getenv("MELF_JPEG_READ");
     const bool read_chunks = rmode && !strcmp(rmode, "chunk");
     if (int rc = grow(&c->d_jframes[cs], &c->jframes_cap[cs], bytes)) return rc;

@@ -629,11 +629,13 @@ def test_exif_oriented_file_takes_the_host_branch(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('chunk,read', [('512', 'whole'), ('96', 'whole'), ('200', 'chunk')])
-def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read):
-    """melf_jpeg_process_batch decodes in chunks on two alternating streams while the host prepares the next chunk: same
+@pytest.mark.parametrize('chunk,read,parse', [('', 'whole', ''), ('512', 'whole', 'all'), ('96', 'whole', ''), ('200', 'chunk', ''),
+                                              ('64,300,128', 'chunk', 'all'), ('40,260', 'whole', '')])
+def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read, parse):
+    """melf_jpeg_process_batch decodes in chunks on a ring of streams while the host prepares the next chunk: same
     records and per-file status as the one-piece path (MELF_JPEG_SERIAL), with a corrupt file, a file of another size,
-    a progressive file and a greyscale file spread over different chunks, and when called twice in a row."""
+    a progressive file and a greyscale file spread over different chunks, and when called twice in a row -- at the default
+    chunk size, at other sizes, with an uneven plan, with the headers parsed per chunk (default) and all up front."""
     rng = np.random.default_rng(77)
     good = [open(f, 'rb').read() for f in _files('sample-images1')]
     from meterelf_amd import _hip
@@ -647,7 +649,10 @@ def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read
     monkeypatch.setenv('MELF_JPEG_SERIAL', '1')
     (ref, rstat) = ctx.jpeg_process_batch(batch, H, W)
     monkeypatch.delenv('MELF_JPEG_SERIAL')
-    monkeypatch.setenv('MELF_JPEG_CHUNK', chunk)
+    if chunk:
+        monkeypatch.setenv('MELF_JPEG_CHUNK', chunk)
+    if parse:
+        monkeypatch.setenv('MELF_JPEG_PARSE', parse)
     monkeypatch.setenv('MELF_JPEG_READ', read)
     for _ in range(2):
         (got, gstat) = ctx.jpeg_process_batch(batch, H, W)
