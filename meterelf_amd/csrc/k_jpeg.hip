@@ -19,6 +19,7 @@
 #include "melf_threads.h"
 
 #include <algorithm>
+#include <climits>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -234,6 +235,10 @@ struct JpegImageDev {
     uint8_t pad[3];
     uint32_t rst_off, rst_cnt;    // restart intervals: table of their byte offsets in the clean scan (relative to the
                                   // scan area), number of intervals
+    // Filled by the host; scan_len and rst_cnt (and the bytes they describe) by k_jpeg_clean on the GPU (round 4):
+    uint32_t scan_cap;            // bytes of the scan area reserved for this file's clean scan (zero-filled behind scan_len)
+    uint32_t raw_off, raw_len;    // the file's entropy-coded segment as it is in the file (stuffing, fill bytes, RSTn, EOI and
+                                  // whatever follows), in the raw area
 };
 static_assert(sizeof(JpegImageDev) % 4 == 0, "record must stay dword aligned");
 
@@ -263,33 +268,108 @@ static void build_huff(const HuffSpec& t, HuffSlow* slow)
     }
 }
 
-// Copies the entropy-coded segment without byte stuffing (FF 00 -> FF), fill bytes and RSTn markers;
-// stops at any other marker (normally EOI).  rst[k] receives the offset (in the clean stream) at which
-// restart interval k begins (rst[0] = 0); *rst_found counts the intervals seen.
-static size_t clean_scan(const uint8_t* s, size_t n, uint8_t* out, uint32_t* rst, int rst_cap, int* rst_found)
+// ------------------------------------------------------------ J0: scan cleaning ----
+// The entropy-coded segment without byte stuffing (FF 00 -> FF), fill bytes and RSTn markers, up to the first other marker
+// (normally EOI) -- on the GPU since round 4 (rounds 1-3: a host pass, clean_scan): the host no longer touches the entropy-coded bytes except to copy them (or, for
+// the file-name entry points, not at all: the files are read straight into the pinned buffer the upload starts from).
+// One workgroup per file, 4 KiB per round, 16 consecutive bytes per thread.  In entropy-coded data every FF is special and
+// the byte behind it says how: 00 = a stuffed FF (keep the FF, drop the 00), FF = fill (drop this one, look at the next),
+// D0..D7 = RSTn (drop both, the next restart interval begins at the clean offset reached), anything else -- or the end of
+// the data -- ends the scan.  Per round: (1) the first scan-ending FF of the round (minimum over the workgroup), (2) keep
+// flags and restart markers below it, one packed prefix scan of both counts, (3) byte stores of the kept bytes at their
+// clean offsets, restart offsets into the table behind the scan.  Leaves scan_len / rst_cnt in the file's record and the
+// rest of the file's scan region zeroed, exactly what the host pass left.
+__global__ __launch_bounds__(256) void k_jpeg_clean(JpegImageDev* __restrict__ imgs, const uint8_t* __restrict__ raw,
+                                                    uint8_t* __restrict__ scan)
 {
-    size_t o = 0, i = 0;
-    *rst_found = 1;
-    if (rst && rst_cap > 0) rst[0] = 0;
-    while (i < n) {
-        const uint8_t* f = (const uint8_t*)memchr(s + i, 0xFF, n - i);
-        const size_t run = f ? (size_t)(f - (s + i)) : n - i;
-        memcpy(out + o, s + i, run);
-        o += run;
-        i += run;
-        if (!f) break;
-        if (i + 1 >= n) break;
-        const uint8_t m = s[i + 1];
-        if (m == 0x00) { out[o++] = 0xFF; i += 2; }
-        else if (m == 0xFF) { i += 1; }                   // fill byte
-        else if (m >= 0xD0 && m <= 0xD7) {                // RSTn: the next interval starts here, byte aligned
-            if (rst && *rst_found < rst_cap) rst[*rst_found] = (uint32_t)o;
-            ++*rst_found;
-            i += 2;
+    __shared__ int s_end;
+    __shared__ uint32_t s_wsum[4];
+    JpegImageDev* R = imgs + blockIdx.x;
+    if (!R->ok) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint8_t* __restrict__ s = raw + R->raw_off;
+    const int n = (int)R->raw_len;
+    uint8_t* __restrict__ out = scan + R->scan_off;
+    const bool has_rst = R->restart_interval != 0;
+    uint32_t* __restrict__ rst = (uint32_t*)(scan + R->rst_off);
+    const int rst_cap = has_rst ? (int)R->rst_cnt + 1 : 0;   // the host left the EXPECTED number of intervals here
+    int o_base = 0, r_base = 0;   // clean bytes written, restart markers seen, before this round
+    bool ended = false;
+    for (int base = 0; base < n && !ended; base += 4096) {
+        if (tid == 0) s_end = INT_MAX;
+        const int my = base + tid * 16;
+        // bytes my - 1 .. my + 16 (the raw area is padded: reads past n stay inside it; their values are never used)
+        uint32_t w[5] = {0, 0, 0, 0, 0};
+        uint32_t prev = 0;
+        if (my < n) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) __builtin_memcpy(&w[q], s + my + 4 * q, 4);
+            if (my > 0) prev = s[my - 1];
         }
-        else break;                                        // EOI or another marker: end of scan
+        auto byte_at = [&](int j) { return (w[j >> 2] >> (8 * (j & 3))) & 255u; };
+        auto special_next = [](uint32_t b) { return b == 0x00u || b == 0xFFu || (b >= 0xD0u && b <= 0xD7u); };
+        int first_end = INT_MAX;
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const int p = my + j;
+            if (p < n && byte_at(j) == 0xFFu && (p + 1 >= n || !special_next(byte_at(j + 1)))) first_end = p;
+        }
+        __syncthreads();
+        if (first_end != INT_MAX) atomicMin(&s_end, first_end);
+        __syncthreads();
+        const int end = min(s_end, n);
+        uint32_t keep = 0, mark = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = my + j;
+            const uint32_t b = byte_at(j), nx = byte_at(j + 1), pv = j ? byte_at(j - 1) : prev;
+            const bool live = p < end;
+            const bool isff = b == 0xFFu;
+            const bool k = live && (isff ? (nx == 0x00u && p + 1 < n) : !(pv == 0xFFu && (b == 0x00u || (b >= 0xD0u && b <= 0xD7u))));
+            const bool m = live && isff && p + 1 < n && nx >= 0xD0u && nx <= 0xD7u;
+            keep |= (uint32_t)k << j;
+            mark |= (uint32_t)m << j;
+        }
+        // exclusive prefix of (kept bytes | markers << 16) over the workgroup
+        const uint32_t mine = (uint32_t)__popc(keep) | ((uint32_t)__popc(mark) << 16);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t t = s_wsum[q];
+            if (q < wv) before += t;
+            total += t;
+        }
+        int ko = o_base + (int)(before & 0xffffu), ro = r_base + (int)(before >> 16);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if ((mark >> j) & 1u) {   // the interval behind this marker begins at the clean offset reached here
+                ++ro;
+                if (ro < rst_cap) rst[ro] = (uint32_t)ko;
+            }
+            if ((keep >> j) & 1u) out[ko++] = (uint8_t)byte_at(j);
+        }
+        o_base += (int)(total & 0xffffu);
+        r_base += (int)(total >> 16);
+        ended = end < base + 4096;   // uniform: the scan ended inside this round (or the data did)
+        __syncthreads();              // s_end and s_wsum are rewritten by the next round
     }
-    return o;
+    const int cap = (int)R->scan_cap;
+    for (int i = o_base + tid; i < cap; i += 256) out[i] = 0;
+    if (tid == 0) {
+        R->scan_len = (uint32_t)o_base;
+        if (has_rst) {
+            rst[0] = 0;
+            R->rst_cnt = (uint32_t)(r_base + 1);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ J1: Huffman ----
@@ -1063,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImageDev* __restric
                                                    uint8_t* __restrict__ planes, JpegWindow win)
 {
     const int img = blockIdx.y;
-    const JpegImageDev I = imgs[img];
+    const JpegImageDev& I = imgs[img];   // a reference: a local copy indexed by the component lives in scratch
     if (!I.ok || status[img] != 0) return;
     // blocks of the MCUs that overlap the pixel window (16-aligned, so whole MCUs in every sampling mode)
     const int mw = 8 * I.hs0, mh = 8 * I.vs0;
@@ -1236,7 +1316,7 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImageDev* __restri
     const int img = blockIdx.z, y = win.y0 + blockIdx.y;
     const int x0 = win.x0 + (blockIdx.x * 256 + threadIdx.x) * 4;
     if (x0 >= win.x1) return;
-    const JpegImageDev I = imgs[img];
+    const JpegImageDev& I = imgs[img];   // a reference: a local copy indexed by the component lives in scratch
     if (fast420 && I.ok && I.ncomp == 3 && I.hs0 == 2 && I.vs0 == 2) return;  // k_jpeg_color420 did it
     uint8_t* out = frames + ((size_t)img * H + y) * W * 3 + (size_t)x0 * 3;
     const int npx = min(4, W - x0);
@@ -1275,10 +1355,16 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImageDev* __restri
 
 // ------------------------------------------------------------------ workspace ----
 struct JpegWorkspace {
-    uint8_t* h_stage = nullptr;  // pinned: records, tables and clean scans of one batch
+    uint8_t* h_stage = nullptr;  // pinned: records and tables of one batch
     size_t h_cap = 0;
-    uint8_t* d_stage = nullptr;
+    uint8_t* d_stage = nullptr;  // the same on the device, and behind them the clean scans (written by k_jpeg_clean)
     size_t d_cap = 0;
+    uint8_t* h_raw = nullptr;    // pinned: the files' entropy-coded segments as they are in the files
+    size_t h_raw_cap = 0;
+    uint8_t* d_raw = nullptr;
+    size_t d_raw_cap = 0;
+    size_t raw_total = 0;        // bytes of the raw area in use
+    const uint8_t* raw_src = nullptr;  // where the upload of the raw area starts: h_raw, or the caller's own pinned buffer
     int16_t* d_coefs = nullptr;
     size_t coef_cap = 0;  // int16 elements
     uint8_t* d_planes = nullptr;
@@ -1286,7 +1372,8 @@ struct JpegWorkspace {
     int32_t* d_status = nullptr;
     size_t status_cap = 0;
     // layout of the current batch inside the stage buffers
-    size_t off_imgs = 0, off_qt = 0, off_slow = 0, off_scan = 0, total = 0;
+    size_t off_imgs = 0, off_qt = 0, off_slow = 0, off_scan = 0, total = 0;   // total: what is uploaded (records + tables)
+    size_t scan_bytes = 0;      // device-only scan area behind them
     size_t coef_elems = 0, plane_bytes = 0;
     int max_blocks = 0;
     int n_par = 0, n_seq = 0;   // images for the segment-parallel / the restart-interval Huffman kernel
@@ -1299,6 +1386,8 @@ void jpeg_workspace_free(JpegWorkspace* w)
     if (!w) return;
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->d_stage) (void)hipFree(w->d_stage);
+    if (w->h_raw) (void)hipHostFree(w->h_raw);
+    if (w->d_raw) (void)hipFree(w->d_raw);
     if (w->d_coefs) (void)hipFree(w->d_coefs);
     if (w->d_planes) (void)hipFree(w->d_planes);
     if (w->d_status) (void)hipFree(w->d_status);
@@ -1323,7 +1412,29 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // by chunk): status[i] 0 = for the GPU, 1 = valid but unsupported, 2 = unreadable, 3 = other size.
 struct JpegParsed {
     std::vector<JpegHeader> hdr;
+    std::vector<HuffSlow> slow;   // 4 per file (DC 0, DC 1, AC 0, AC 1), when built with the headers; else empty
 };
+static void build_slow4(const JpegHeader& h, HuffSlow* slow)
+{
+    for (int t = 0; t < 2; ++t) {
+        if (h.dc[t].set) build_huff(h.dc[t], slow + t); else memset(slow + t, 0, sizeof(HuffSlow));
+        if (h.ac[t].set) build_huff(h.ac[t], slow + 2 + t); else memset(slow + 2 + t, 0, sizeof(HuffSlow));
+    }
+}
+JpegParsed* jpeg_parsed_new(int n, bool with_tables)
+{
+    JpegParsed* p = new JpegParsed();
+    p->hdr.resize(n);
+    if (with_tables) p->slow.resize((size_t)n * 4);
+    return p;
+}
+void jpeg_parse_one(JpegParsed* p, int i, const uint8_t* data, size_t size, int* H, int* W, int* supported)
+{
+    JpegHeader& h = p->hdr[i];
+    if (!data || parse_headers(data, size, h) != 0) { *H = *W = 0; *supported = 0; return; }
+    *H = h.H; *W = h.W; *supported = h.why ? 0 : 1;
+    if (!h.why && !p->slow.empty()) build_slow4(h, p->slow.data() + (size_t)i * 4);
+}
 JpegParsed* jpeg_parse_files(const uint8_t* const* data, const size_t* sizes, int n, int H, int W, int32_t* host_status)
 {
     JpegParsed* p = new JpegParsed();
@@ -1343,14 +1454,15 @@ void jpeg_parsed_free(JpegParsed* p) { delete p; }
 // pass, host_status filled), lay the batch out, fill the pinned stage buffer.
 // host_status[i]: 0 = handed to the GPU, 1 = valid but unsupported, 2 = unreadable, 3 = other size.
 int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
-                       int32_t* host_status, std::string* err, const JpegParsed* parsed, int first)
+                       int32_t* host_status, std::string* err, const JpegParsed* parsed, int first, const int* pidx,
+                       const uint8_t* pin_base, size_t pin_len)
 {
     if (!*pws) *pws = new JpegWorkspace();
     JpegWorkspace* w = *pws;
     static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     std::vector<JpegHeader> own;
-    std::vector<size_t> scan_off(n + 1, 0);
+    std::vector<size_t> scan_off(n + 1, 0), raw_off(n + 1, 0);
     const int nthreads = host_pool().size() + 1;
     auto par_for = [&](const std::function<void(int)>& fn) { host_pool().run(n, fn); };
     if (!parsed) {
@@ -1363,7 +1475,25 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
             host_status[i] = 0;
         });
     }
-    const JpegHeader* hdr = parsed ? parsed->hdr.data() + first : own.data();
+    auto hidx = [&](int i) { return parsed ? (pidx ? pidx[first + i] : first + i) : i; };
+    const JpegHeader* const hbase = parsed ? parsed->hdr.data() : own.data();
+    // Every file of the batch already in the caller's pinned buffer: the upload starts there (one span from the first file's
+    // first byte to the last one's last; what lies between the files travels along), no byte is copied here.
+    bool direct = pin_base != nullptr && n > 0;
+    const uint8_t* span_lo = nullptr;
+    const uint8_t* span_hi = nullptr;
+    size_t bytes_sum = 0;
+    if (direct) {
+        for (int i = 0; i < n && direct; ++i) {
+            if (host_status[i] != 0) continue;
+            if (data[i] < pin_base || data[i] + sizes[i] + 64 > pin_base + pin_len) { direct = false; break; }
+            if (!span_lo || data[i] < span_lo) span_lo = data[i];
+            if (!span_hi || data[i] + sizes[i] > span_hi) span_hi = data[i] + sizes[i];
+            bytes_sum += sizes[i];
+        }
+        // a batch picked from all over the buffer (the flat files that go first, a second frame size): copy after all
+        if (direct && (!span_lo || (size_t)(span_hi - span_lo) > 2 * bytes_sum + (1u << 20))) direct = false;
+    }
     const auto tp1 = std::chrono::steady_clock::now();
     // layout
     size_t coef_blocks = 0, plane_bytes = 0;
@@ -1373,8 +1503,9 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         JpegImageDev& r = rec[i];
         memset(&r, 0, sizeof(r));
         scan_off[i + 1] = scan_off[i];
+        raw_off[i + 1] = raw_off[i];
         if (host_status[i] != 0) continue;
-        const JpegHeader& h = hdr[i];
+        const JpegHeader& h = hbase[hidx(i)];
         r.ok = 1;
         r.ncomp = (uint8_t)h.ncomp; r.hs0 = (uint8_t)h.hs[0]; r.vs0 = (uint8_t)h.vs[0];
         r.restart_interval = (uint16_t)h.restart_interval;
@@ -1393,7 +1524,11 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
             blocks += (int)nb;
         }
         max_blocks = std::max(max_blocks, blocks);
-        size_t region = align_up(sizes[i] - h.scan_begin + 128, 64);
+        const size_t raw_len = sizes[i] - h.scan_begin;
+        r.raw_off = direct ? (uint32_t)(data[i] + h.scan_begin - span_lo) : (uint32_t)raw_off[i];
+        r.raw_len = (uint32_t)raw_len;
+        raw_off[i + 1] = raw_off[i] + align_up(raw_len + 32, 64);   // k_jpeg_clean reads up to 20 bytes past the end
+        size_t region = align_up(raw_len + 128, 64);
         if (h.restart_interval) {  // room for the table of interval offsets behind the scan
             const size_t mcus = (size_t)r.mcus_x * r.mcus_y;
             r.rst_cnt = (uint32_t)((mcus + h.restart_interval - 1) / h.restart_interval);  // expected; replaced by the number found
@@ -1402,7 +1537,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
         }
         scan_off[i + 1] = scan_off[i] + region;
     }
-    if (coef_blocks >= (1ull << 32) / 64 || plane_bytes >= (1ull << 32) || scan_off[n] >= (1ull << 32)) {
+    if (coef_blocks >= (1ull << 32) / 64 || plane_bytes >= (1ull << 32) || scan_off[n] >= (1ull << 32) || raw_off[n] >= (1ull << 32)) {
         if (err) *err = "JPEG batch too large for 32-bit offsets; decode in smaller batches";
         return MELF_ERR_TOO_LARGE;
     }
@@ -1410,7 +1545,24 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
     w->off_qt = align_up(w->off_imgs + (size_t)n * sizeof(JpegImageDev), 256);
     w->off_slow = align_up(w->off_qt + (size_t)n * 4 * 64 * sizeof(uint16_t), 256);
     w->off_scan = align_up(w->off_slow + (size_t)n * 4 * sizeof(HuffSlow), 256);
-    w->total = w->off_scan + scan_off[n] + 64;
+    w->total = w->off_scan;                 // uploaded: records + tables
+    w->scan_bytes = scan_off[n] + 64;       // device only
+    w->raw_total = direct ? (size_t)(span_hi - span_lo) + 64 : raw_off[n] + 64;
+    if (w->raw_total >= (1ull << 32)) {
+        if (err) *err = "JPEG batch too large for 32-bit offsets; decode in smaller batches";
+        return MELF_ERR_TOO_LARGE;
+    }
+    if (!direct && w->raw_total > w->h_raw_cap) {
+        if (w->h_raw) (void)hipHostFree(w->h_raw);
+        w->h_raw = nullptr; w->h_raw_cap = 0;
+        const size_t want = w->raw_total + w->raw_total / 4;
+        if (hipHostMalloc((void**)&w->h_raw, want, hipHostMallocDefault) != hipSuccess) {
+            if (err) *err = "hipHostMalloc failed for the JPEG raw-scan buffer";
+            return MELF_ERR_HIP;
+        }
+        w->h_raw_cap = want;
+    }
+    w->raw_src = direct ? span_lo : w->h_raw;
     w->coef_elems = coef_blocks * 64;
     w->plane_bytes = plane_bytes;
     w->max_blocks = max_blocks;
@@ -1426,41 +1578,41 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
     }
     const auto tp2 = std::chrono::steady_clock::now();
     uint8_t* base = w->h_stage;
-    par_for([&](int i) {
+    const bool tables_ready = parsed && !parsed->slow.empty();
+    auto fill = [&](int i) {
         JpegImageDev& r = rec[i];
         uint16_t* qt = (uint16_t*)(base + w->off_qt) + (size_t)i * 256;
         HuffSlow* slow = (HuffSlow*)(base + w->off_slow) + (size_t)i * 4;
         if (host_status[i] != 0) return;
-        const JpegHeader& h = hdr[i];
+        const JpegHeader& h = hbase[hidx(i)];
         for (int t = 0; t < 4; ++t) {
             if (h.qt_set[t]) memcpy(qt + t * 64, h.qt[t], 128); else memset(qt + t * 64, 0, 128);
         }
-        for (int t = 0; t < 2; ++t) {
-            if (h.dc[t].set) build_huff(h.dc[t], slow + t); else memset(slow + t, 0, sizeof(HuffSlow));
-            if (h.ac[t].set) build_huff(h.ac[t], slow + 2 + t); else memset(slow + 2 + t, 0, sizeof(HuffSlow));
-        }
-        uint8_t* dst = base + w->off_scan + scan_off[i];
-        uint32_t* rst = h.restart_interval ? (uint32_t*)(dst + r.rst_off) : nullptr;
-        int found = 0;
-        const size_t len = clean_scan(data[i] + h.scan_begin, sizes[i] - h.scan_begin, dst, rst, (int)r.rst_cnt + 1, &found);
-        const size_t scan_region = h.restart_interval ? r.rst_off : scan_off[i + 1] - scan_off[i];
-        memset(dst + len, 0, scan_region - len);
+        if (tables_ready) memcpy(slow, parsed->slow.data() + (size_t)hidx(i) * 4, 4 * sizeof(HuffSlow));
+        else build_slow4(h, slow);
+        // the entropy-coded segment as it is: stuffing, fill bytes and restart markers are taken out on the GPU (k_jpeg_clean),
+        // which also writes the clean length and the restart table (r.rst_cnt: the EXPECTED number of intervals until then)
+        if (!direct) memcpy(w->h_raw + r.raw_off, data[i] + h.scan_begin, r.raw_len);
+        r.scan_cap = (uint32_t)(h.restart_interval ? r.rst_off : scan_off[i + 1] - scan_off[i]);
         r.scan_off = (uint32_t)scan_off[i];
-        r.scan_len = (uint32_t)len;
-        if (h.restart_interval) {
-            r.rst_off = (uint32_t)(scan_off[i] + r.rst_off);
-            r.rst_cnt = (uint32_t)found;
-        }
+        r.scan_len = 0;
+        if (h.restart_interval) r.rst_off = (uint32_t)(scan_off[i] + r.rst_off);
         r.ok = h.restart_interval != 0 ? 2 : 1;
-        if (!h.restart_interval && len > JPEG_MAX_PAR_SCAN) {  // longer than 1024 lanes x the segment length k_jpeg_huff can address
+        // longer than 1024 lanes x the segment length k_jpeg_huff can address (the raw length: the clean one is only known on
+        // the GPU and at most 1/128 shorter)
+        if (!h.restart_interval && r.raw_len > JPEG_MAX_PAR_SCAN) {
             r.ok = 0;
             host_status[i] = 1;  // valid, but for the host decoder
         }
-    });
+    };
+    // nothing but two small copies per file left to do: not worth waking the pool (whose threads the file reads of the next
+    // call are using)
+    if (direct && tables_ready) { for (int i = 0; i < n; ++i) fill(i); }
+    else par_for(fill);
     w->n_par = w->n_seq = w->n_420 = 0;
     w->max_par_scan = 0;
     for (int i = 0; i < n; ++i) {
-        if (rec[i].ok == 1) { ++w->n_par; w->max_par_scan = std::max(w->max_par_scan, (size_t)rec[i].scan_len); }
+        if (rec[i].ok == 1) { ++w->n_par; w->max_par_scan = std::max(w->max_par_scan, (size_t)rec[i].raw_len); }
         else if (rec[i].ok == 2) ++w->n_seq;
         if (rec[i].ok && rec[i].ncomp == 3 && rec[i].hs0 == 2 && rec[i].vs0 == 2) ++w->n_420;
     }
@@ -1468,7 +1620,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
     if (trace) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[melf jpeg] prepare: parse %.2f ms, layout %.2f ms, tables + clean scans %.2f ms (%d threads)\n", ms(tp0, tp1), ms(tp1, tp2),
+        fprintf(stderr, "[melf jpeg] prepare: parse %.2f ms, layout %.2f ms, tables + scan copies %.2f ms (%d threads)\n", ms(tp0, tp1), ms(tp1, tp2),
                 ms(tp2, tp3), nthreads);
     }
     return MELF_SUCCESS;
@@ -1487,11 +1639,13 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
     } while (0)
 int jpeg_upload_batch(JpegWorkspace* w, int n, hipStream_t copy_stream, std::string* err)
 {
-    JTRY(grow_dev(&w->d_stage, &w->d_cap, w->total));
+    JTRY(grow_dev(&w->d_stage, &w->d_cap, w->total + w->scan_bytes));
+    JTRY(grow_dev(&w->d_raw, &w->d_raw_cap, w->raw_total));
     JTRY(grow_dev(&w->d_coefs, &w->coef_cap, w->coef_elems + 64));
     JTRY(grow_dev(&w->d_planes, &w->plane_cap, w->plane_bytes + 64));
     JTRY(grow_dev(&w->d_status, &w->status_cap, (size_t)n));
     JTRY(hipMemcpyAsync(w->d_stage, w->h_stage, w->total, hipMemcpyHostToDevice, copy_stream));
+    JTRY(hipMemcpyAsync(w->d_raw, w->raw_src, w->raw_total, hipMemcpyHostToDevice, copy_stream));
     return MELF_SUCCESS;
 }
 
@@ -1512,6 +1666,8 @@ int jpeg_decode_batch_kernels(JpegWorkspace* w, int n, int H, int W, uint8_t* d_
     const HuffSlow* slow = (const HuffSlow*)(w->d_stage + w->off_slow);
     const uint8_t* scan = w->d_stage + w->off_scan;
     if (timer) timer(timer_arg, 0, 0);
+    if (w->n_par + w->n_seq > 0)   // J0: stuffing, fill bytes and restart markers out of the uploaded segments
+        hipLaunchKernelGGL(k_jpeg_clean, dim3(n), dim3(256), 0, stream, (JpegImageDev*)(w->d_stage + w->off_imgs), w->d_raw, w->d_stage + w->off_scan);
     if (w->n_par > 0) {  // one workgroup per image, one lane per stream segment
         static int tenv = -1;
         if (tenv < 0) { const char* e = getenv("MELF_JPEG_T"); tenv = e ? atoi(e) : 0; }

@@ -290,8 +290,9 @@ struct melf_ctx {
     size_t jstatus_cap[NJC] = {};
     hipEvent_t ev_jcall[NJC] = {};
     uint64_t jpeg_chunk_seq = 0;       // chunks decoded since the context was created: chunk q uses ring slot q % NJ
-    // melf_jpeg_process_files: the files' bytes (grow-only: no per-file allocation, no zero fill, and after the first
-    // call no fresh pages to fault in), and the call in flight of the begin / end pair
+    // melf_jpeg_process_files: the files' bytes, in PINNED host memory (round 4: the upload starts from here, the host copies
+    // no byte of a file after read() has; grow-only: no per-file allocation, no zero fill, and after the first call no fresh
+    // pages to fault in or to pin), and the call in flight of the begin / end pair
     // Up to NFJ begin / end calls in flight: each on its own thread, which READS its files at once (into the arena of its
     // slot) and then waits for its turn at the context (decode + reading path, in the order of the _begin calls).
     // Three stages, three calls: one reads its files, one prepares and enqueues, one waits for its kernels (with two, the
@@ -603,7 +604,7 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     if (!c) return;
     for (auto* j : c->files_jobs) { if (j->th.joinable()) j->th.join(); delete j; }
     c->files_jobs.clear();
-    for (int a = 0; a < melf_ctx::NFJ; ++a) free(c->file_arena[a]);
+    for (int a = 0; a < melf_ctx::NFJ; ++a) if (c->file_arena[a]) (void)hipHostFree(c->file_arena[a]);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int l = 0; l < melf_ctx::NLANES; ++l)   // resident mode and the split modes run whole calls on the lanes' own streams
@@ -1516,6 +1517,15 @@ static thread_local std::function<void()>* tl_jpeg_enqueued = nullptr;
 // here waits for the context's stream; what protects a ring slot is its own pair of events, across calls as within one.
 static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int W, size_t frame_stride,
                             void* d_results, melf_result* out_host, hipStream_t st, const int* rect, int row_stride);
+// What a caller inside the library may already have of the files it hands to the decode path (the file-name entry points
+// do): the parsed headers + Huffman decode data (of file index[k] of that parse for the call's file k), and the pinned buffer
+// the files' bytes lie in.
+struct JpegSource {
+    const JpegParsed* parsed;
+    const int* index;
+    const uint8_t* pin_base;
+    size_t pin_len;
+};
 // read_chunks: the reading path runs per chunk, right behind the chunk's decode on the chunk's stream (records into
 // c->d_results), instead of once over all frames afterwards -- its kernels then run beside the later chunks' Huffman
 // kernels, which leave most of the chip's throughput unused.
@@ -1524,7 +1534,7 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
 // does so beside the other chunks' preparation and kernels instead of at the end of one of them).
 static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W, const int* rect,
                                  std::vector<int32_t>& hstat, bool read_chunks, int first_len, uint8_t* d_frames, melf_result* d_results,
-                                 int32_t* h_status, bool overlapped)
+                                 int32_t* h_status, bool overlapped, const JpegSource* src)
 {
     // 256 files per chunk.  A call's critical path is: first chunk parsed and prepared -> ALL uploads back to back (36 MB at
     // ~42 GB/s: 0.85 ms per 1024 fixture files, the longest item) -> the LAST chunk's Huffman kernel (0.4-0.5 ms whatever the
@@ -1569,7 +1579,9 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
     // chunk's headers are parsed before the first upload can start: 0.24 ms of a 1024-file call's head otherwise)
     const char* pmode = getenv("MELF_JPEG_PARSE");
     const bool parse_all = pmode && !strcmp(pmode, "all");
-    struct ParsedGuard { JpegParsed* p; ~ParsedGuard() { if (p) jpeg_parsed_free(p); } } parsed{parse_all ? jpeg_parse_files(data, sizes, n, H, W, hstat.data()) : nullptr};
+    struct ParsedGuard { JpegParsed* p; ~ParsedGuard() { if (p) jpeg_parsed_free(p); } } parsed{
+        parse_all && !src ? jpeg_parse_files(data, sizes, n, H, W, hstat.data()) : nullptr};
+    // (a caller that brings the headers has checked them: every file is one for the GPU, of this frame size: hstat stays 0)
     for (int f0 = 0, m = 0, planned = 0; f0 < n; f0 += m, ++k) {
         m = (k == 0 && first_len > 0) ? first_len : plan[std::min(planned++, (int)plan.size() - 1)];
         if (m > n - f0) m = n - f0;
@@ -1581,7 +1593,10 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
         // the upload that last read this workspace's pinned stage buffer must be done before the host refills it
         if (seq >= (uint64_t)NJ) HIP_TRY(hipEventSynchronize(c->ev_jup[b]));
         if (trace) tt[1] = trace_clock_ms(std::chrono::steady_clock::now());
-        if (int rc = jpeg_prepare_batch(ws[b], data + f0, sizes + f0, m, H, W, hstat.data() + f0, &err, parsed.p, f0)) return fail(rc, err);
+        if (int rc = src ? jpeg_prepare_batch(ws[b], data + f0, sizes + f0, m, H, W, hstat.data() + f0, &err, src->parsed, f0, src->index,
+                                              src->pin_base, src->pin_len)
+                         : jpeg_prepare_batch(ws[b], data + f0, sizes + f0, m, H, W, hstat.data() + f0, &err, parsed.p, f0))
+            return fail(rc, err);
         if (trace) tt[2] = trace_clock_ms(std::chrono::steady_clock::now());
         // ... and the kernels that last read its device buffers before the upload overwrites them
         if (seq >= (uint64_t)NJ) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_jdec[b], 0));
@@ -1616,8 +1631,15 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
     return MELF_SUCCESS;
 }
 
+static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                                   melf_result* out_host, int32_t* status, const JpegSource* src);
 extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
                                        melf_result* out_host, int32_t* status)
+{
+    return jpeg_process_batch_from(c, data, sizes, n, H, W, out_host, status, nullptr);
+}
+static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
+                                   melf_result* out_host, int32_t* status, const JpegSource* src)
 {
     if (!c) return fail(MELF_ERR_INVALID, "ctx is NULL");
     if (n == 0) return MELF_SUCCESS;
@@ -1650,6 +1672,8 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     std::vector<int> perm;
     std::vector<const uint8_t*> pdata;
     std::vector<size_t> psizes;
+    std::vector<int> pindex;
+    JpegSource psrc;
     int nsparse = 0;
     if (!getenv("MELF_JPEG_NO_REORDER")) {
         const double blocks = ((H + 7) / 8) * (double)((W + 7) / 8) * 1.5;
@@ -1661,6 +1685,12 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
             for (int i = 0; i < n; ++i) { pdata[i] = data[perm[i]]; psizes[i] = sizes[perm[i]]; }
             data = pdata.data();
             sizes = psizes.data();
+            if (src) {   // the caller's headers follow their files
+                pindex.resize(n);
+                for (int i = 0; i < n; ++i) pindex[i] = src->index ? src->index[perm[i]] : perm[i];
+                psrc = {src->parsed, pindex.data(), src->pin_base, src->pin_len};
+                src = &psrc;
+            }
         } else {
             nsparse = 0;
         }
@@ -1684,7 +1714,7 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
     }
     if (!c->ev_jcall[cs]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jcall[cs], hipEventDisableTiming));
     int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks, nsparse, c->d_jframes[cs], c->d_jresults[cs], c->h_jstatus[cs],
-                                   overlapped);
+                                   overlapped, src);
     if (rc == MELF_SUCCESS && !read_chunks) {
         if (c->lanes > 1) rc = claim_all_lanes(c, c->stream);
         else rc = acquire_lane(c, c->stream, &c->active_lane);
@@ -1723,8 +1753,15 @@ extern "C" int melf_jpeg_process_batch(melf_ctx* c, const uint8_t* const* data, 
 // so that a scripting host pays one call per chunk instead of an open/read per file.
 struct FilesRead {  // what the read stage hands to the decode stage
     std::vector<int> hs, ws, oks;
-    std::vector<size_t> off;
-    uint8_t* base = nullptr;
+    std::vector<size_t> off;     // file i's bytes: base + off[i], len[i] of them (64-byte aligned, 64 spare bytes behind each)
+    std::vector<size_t> len;
+    uint8_t* base = nullptr;     // the context's pinned arena of this call's slot
+    size_t cap = 0;
+    JpegParsed* parsed = nullptr;  // every file's header and Huffman decode data, made by the thread that read the file
+    ~FilesRead() { if (parsed) jpeg_parsed_free(parsed); }
+    FilesRead() = default;
+    FilesRead(const FilesRead&) = delete;
+    FilesRead& operator=(const FilesRead&) = delete;
 };
 
 // Stage 1: the files' bytes into arena `slot` of the context, header check.  Touches nothing else of the context.
@@ -1740,10 +1777,12 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
     static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int>&hs = R.hs, &ws = R.ws, &oks = R.oks;
-    std::vector<size_t>& off = R.off;
+    std::vector<size_t>&off = R.off, &len = R.len;
     try {
         hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0);
         off.assign((size_t)n + 1, 0);
+        len.assign(n, 0);
+        R.parsed = jpeg_parsed_new(n, true);
     } catch (const std::exception&) {
         return fail(MELF_ERR_INVALID, "out of host memory");
     }
@@ -1758,19 +1797,25 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
             status[i] = regular && sb.st_size > max_file ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_UNREADABLE;
             return;
         }
-        off[(size_t)i + 1] = (size_t)sb.st_size;
+        len[i] = (size_t)sb.st_size;
         status[i] = MELF_JPEG_OK;
     });
     const auto t_opened = std::chrono::steady_clock::now();
-    for (int i = 0; i < n; ++i) off[(size_t)i + 1] += off[i];
-    if (off[n] > c->file_arena_cap[slot]) {
+    // 64-byte aligned files with 64 spare bytes behind each (the GPU's scan cleaner reads a few bytes past a file's end)
+    for (int i = 0; i < n; ++i) off[(size_t)i + 1] = off[i] + (len[i] ? (len[i] + 64 + 63) / 64 * 64 : 0);
+    if (off[n] + 128 > c->file_arena_cap[slot]) {
+        // pinned: the uploads start from this buffer.  Nothing of the GPU reads the old one any more: the slot's previous
+        // call has been collected (its _end) before this one could be begun.
         const size_t want = off[n] + off[n] / 4 + (1u << 20);
-        uint8_t* q = (uint8_t*)realloc(c->file_arena[slot], want);
-        if (!q) return fail(MELF_ERR_INVALID, "out of host memory");
-        c->file_arena[slot] = q;
+        HIP_TRY(hipSetDevice(c->device));
+        if (c->file_arena[slot]) HIP_TRY(hipHostFree(c->file_arena[slot]));
+        c->file_arena[slot] = nullptr;
+        c->file_arena_cap[slot] = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->file_arena[slot], want, hipHostMallocDefault));
         c->file_arena_cap[slot] = want;
     }
     uint8_t* const base = R.base = c->file_arena[slot];
+    R.cap = c->file_arena_cap[slot];
     const auto t_arena = std::chrono::steady_clock::now();
     // pass 2: open, read the size seen in pass 1, close (a file that shrank meanwhile is unreadable; of one that grew
     // the decoder sees the first part and reports a corrupt stream: both go to the caller's host branch)
@@ -1778,7 +1823,7 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
         if (status[i] != MELF_JPEG_OK) return;
         const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
         if (fd < 0) { status[i] = MELF_JPEG_UNREADABLE; return; }
-        const size_t sz = off[(size_t)i + 1] - off[i];
+        const size_t sz = len[i];
         size_t got = 0;
         while (got < sz) {
             const ssize_t r = read(fd, base + off[i] + got, sz - got);
@@ -1788,13 +1833,15 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
         }
         close(fd);
         if (got != sz) { status[i] = MELF_JPEG_UNREADABLE; return; }
-        jpeg_probe(base + off[i], sz, &hs[i], &ws[i], &oks[i], nullptr);
+        // header and Huffman decode data right here, while the file's first lines are in this core's cache: the decode stage
+        // then has nothing to compute per file
+        jpeg_parse_one(R.parsed, i, base + off[i], sz, &hs[i], &ws[i], &oks[i]);
     });
     if (trace) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): sizes %.2f ms, arena %.2f ms, open + read + probe %.2f ms\n", n, off[n] / 1e6,
+        fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): sizes %.2f ms, arena %.2f ms, open + read + parse %.2f ms\n", n, off[n] / 1e6,
                 ms(t0, t_opened), ms(t_opened, t_arena), ms(t_arena, std::chrono::steady_clock::now()));
     }
     return MELF_SUCCESS;
@@ -1828,7 +1875,7 @@ static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_use
             if (!todo[i]) continue;
             if (!H) { H = R.hs[i]; W = R.ws[i]; }
             if (R.hs[i] != H || R.ws[i] != W) continue;
-            ptr.push_back(R.base + R.off[i]); len.push_back(R.off[(size_t)i + 1] - R.off[i]); where.push_back(i);
+            ptr.push_back(R.base + R.off[i]); len.push_back(R.len[i]); where.push_back(i);
             todo[i] = 0;
         }
         if (!*H_used) { *H_used = H; *W_used = W; }
@@ -1840,7 +1887,9 @@ static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_use
         tl_jpeg_enqueued = left == 0 ? enqueued : nullptr;
         tl_jpeg_slot = call_slot;
         tl_jpeg_files_thread = files_thread;
-        const int rc = melf_jpeg_process_batch(c, ptr.data(), len.data(), m, H, W, res.data(), st.data());
+        // the files' headers are parsed (file where[k] of the read stage's pass) and their bytes lie in the pinned arena
+        const JpegSource src = {R.parsed, where.data(), R.base, R.cap};
+        const int rc = jpeg_process_batch_from(c, ptr.data(), len.data(), m, H, W, res.data(), st.data(), &src);
         tl_jpeg_enqueued = nullptr;
         tl_jpeg_files_thread = false;
         if (rc) return rc;

@@ -140,11 +140,19 @@ void launch_inrange3(const uint8_t* d_img, int npx, const int lo[3], const int h
 // ---- k_jpeg.hip: baseline JPEG decode ----
 struct JpegWorkspace;
 int jpeg_probe(const uint8_t* data, size_t size, int* H, int* W, int* supported, std::string* why);
-struct JpegParsed;
+struct JpegParsed;   // headers (and, when asked for, the Huffman decode data built from them) of n files
 JpegParsed* jpeg_parse_files(const uint8_t* const* data, const size_t* sizes, int n, int H, int W, int32_t* host_status);
+// the same file by file, from any thread (one thread per index): the file-name entry points parse a file right after
+// reading it, on the thread that read it, and build its decode tables there too
+JpegParsed* jpeg_parsed_new(int n, bool with_tables);
+void jpeg_parse_one(JpegParsed* p, int i, const uint8_t* data, size_t size, int* H, int* W, int* supported);
 void jpeg_parsed_free(JpegParsed* p);
+// parsed: headers made earlier -- of file pidx[first + j] for the batch's file j (pidx NULL: of file first + j); host_status is
+// then the caller's.  pin_base / pin_len: a pinned host buffer the files' bytes may already lie in (the file-name entry points
+// read into one): a batch whose files all do is uploaded from there, no byte of it is copied on the host.
 int jpeg_prepare_batch(JpegWorkspace** ws, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
-                       int32_t* host_status, std::string* err, const JpegParsed* parsed = nullptr, int first = 0);
+                       int32_t* host_status, std::string* err, const JpegParsed* parsed = nullptr, int first = 0,
+                       const int* pidx = nullptr, const uint8_t* pin_base = nullptr, size_t pin_len = 0);
 int jpeg_launch_batch(JpegWorkspace* ws, int n, int H, int W, uint8_t* d_frames, int32_t* status_out_host,
                       hipStream_t stream, std::string* err, void (*timer)(void*, int, int), void* timer_arg,
                       const int* rect /* x0, y0, x1, y1: only this part of each frame is needed; NULL = all */);

@@ -130,14 +130,17 @@ inline WorkerPool& host_pool()
     return pool_of(pools, m, "MELF_HOST_THREADS", 1, 3, 15);   // the device's share of the cores, 4 .. 16 threads with the caller
 }
 
-// A second, smaller pool for the file reads of melf_jpeg_process_files: with two calls in flight the next chunk's
-// reads run WHILE the current chunk is prepared and decoded, and one pool (one parallel loop at a time) made each wait
-// for the other (read stage 0.9 -> 1.5 ms, the decode stage's host part 0.8 -> 2.2 ms).
+// A second pool for the read stage of melf_jpeg_process_files: with several calls in flight the next call's files are read
+// WHILE the current one is prepared and decoded, and one pool (one parallel loop at a time) made each wait for the other
+// (read stage 0.9 -> 1.5 ms, the decode stage's host part 0.8 -> 2.2 ms).  Since round 4 the read stage is all the per-file
+// host work there is (read() into the pinned arena, header parse, Huffman decode data, on the thread that read the file;
+// the decode stage runs no parallel loop for such a call), so this pool gets the device's share of the cores: up to 12
+// threads with the caller (6 / 8 / 12 / 16 threads: 0.35-0.40 / 0.48-0.50 / 0.54-0.55 / 0.50-0.55 M files/s on a 16-core box).
 inline WorkerPool& io_pool()
 {
     static WorkerPool* pools[64] = {};
     static std::mutex m;
-    return pool_of(pools, m, "MELF_IO_THREADS", 2, 1, 7);
+    return pool_of(pools, m, "MELF_IO_THREADS", 1, 1, 11);
 }
 
 }  // namespace melf

@@ -166,6 +166,75 @@ def test_restart_intervals_and_greyscale(ctx):
         assert np.array_equal(got, ref), (i, int((got != ref).sum()), np.argwhere(got != ref)[:3])
 
 
+def _scan_begin(data):
+    """Offset of the first entropy-coded byte (behind the SOS header)."""
+    i = 2
+    while True:
+        assert data[i] == 0xFF
+        (m, L) = (data[i + 1], (data[i + 2] << 8) | data[i + 3])
+        if m == 0xDA:
+            return i + 2 + L
+        i += 2 + L
+
+
+def _with_fill_bytes_and_tail(data, rng):
+    """The same image with everything a scan cleaner must step over: one to three fill bytes (FF) in front of every RSTn
+    marker and in front of EOI (legal: B.1.1.2), and bytes behind EOI that look like stuffing, restart markers and data."""
+    b = _scan_begin(data)
+    out = bytearray(data[:b])
+    i = b
+    while True:
+        if data[i] == 0xFF and data[i + 1] != 0x00:
+            out += b'\xff' * int(rng.integers(1, 4))
+            out += data[i:i + 2]
+            if data[i + 1] == 0xD9:
+                break
+            assert 0xD0 <= data[i + 1] <= 0xD7
+            i += 2
+        elif data[i] == 0xFF:
+            out += data[i:i + 2]
+            i += 2
+        else:
+            out.append(data[i])
+            i += 1
+    out += b'\xff\x00\xff\xd3\x12\xff\xff\x00\xff' + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes() + b'\xff'
+    return bytes(out)
+
+
+@pytest.mark.gpu
+def test_scan_cleaning_on_the_gpu_fill_bytes_markers_and_tails(ctx):
+    """k_jpeg_clean takes byte stuffing, fill bytes and RSTn markers out of the scan on the GPU and stops at EOI: files with
+    fill bytes in front of every marker and with marker-like garbage behind EOI decode to the same pixels as libjpeg's (which
+    steps over both); scans of many 4 KiB rounds (noise at quality 95: a stuffed FF on every round and thread boundary sooner
+    or later); a scan cut in the middle of a stuffed pair; a file that ends with FF."""
+    from meterelf_amd import _hip
+    rng = np.random.default_rng(4242)
+    (H, W) = (120, 200)
+    img = _natural_image(rng, H, W)
+    noise = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    plain = [_encode(img, quality=80, subsampling='4:2:0', restart_marker_blocks=3),
+             _encode(img, quality=90, subsampling='4:4:4', restart_marker_rows=1),
+             _encode(noise, quality=95, subsampling='4:4:4', restart_marker_blocks=2),
+             _encode(noise, quality=95, subsampling='4:2:0'),
+             _encode(img, quality=85),
+             _encode(img[..., 1], quality=85, restart_marker_blocks=7)]
+    files = plain + [_with_fill_bytes_and_tail(d, rng) for d in plain]
+    assert all(len(v) > len(d) + 5000 for (d, v) in zip(plain, files[len(plain):])) and len(plain[2]) > 40000
+    (frames, status) = ctx.jpeg_decode(files, H, W)
+    assert (status == 0).all(), status
+    for (i, (d, got)) in enumerate(zip(files, frames)):
+        ref = _pillow_bgr(d)
+        assert np.array_equal(got, ref), (i, int((got != ref).sum()), np.argwhere(got != ref)[:3])
+        assert np.array_equal(got, frames[i % len(plain)]), i
+    # data that end inside the scan: right behind an FF (the stuffed pair cut in two), and with a lone FF as the last byte
+    d = plain[3]
+    b = _scan_begin(d)
+    cut = next(k for k in range(b + 3000, len(d) - 2) if d[k] == 0xFF and d[k + 1] == 0x00)
+    (frames2, status2) = ctx.jpeg_decode([d[:cut + 1], d[:cut], d[:cut + 2], d], H, W)
+    assert status2[3] == 0 and np.array_equal(frames2[3], _pillow_bgr(d))
+    assert all(st in (_hip.JPEG_OK, _hip.JPEG_CORRUPT) for st in status2[:3])   # out of data: reported, or zero bits filled every block
+
+
 @pytest.mark.gpu
 def test_bad_input_is_reported_per_file(ctx):
     from meterelf_amd import _hip

@@ -33,9 +33,11 @@ def begin(j):
     _hip.check(L.melf_jpeg_process_files_begin(h, arr, n, C.byref(H), C.byref(W), out.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)))
 
 
+ROUNDS = int(os.environ.get('FILES_RATE_ROUNDS', '8'))   # passes over the job list per depth
 for depth in range(1, _hip.FILES_IN_FLIGHT_MAX + 1):
-    for rep in range(2):
-        t0 = time.perf_counter()
+    stamps = []
+    t0 = time.perf_counter()
+    for rep in range(ROUNDS):
         inflight = 0
         nxt = 0
         done = 0
@@ -43,7 +45,11 @@ for depth in range(1, _hip.FILES_IN_FLIGHT_MAX + 1):
             while inflight < depth and nxt < len(jobs):
                 begin(jobs[nxt]); nxt += 1; inflight += 1
             _hip.check(L.melf_jpeg_process_files_end(h)); inflight -= 1; done += 1
-        dt = time.perf_counter() - t0
+            stamps.append(time.perf_counter())
+    dt = time.perf_counter() - t0
     ok = sum(int((j[4] == 0).sum()) for j in jobs)
-    print('%d call(s) in flight, chunks of %d: %d files in %.1f ms = %.0f files/s (%d decoded)' % (depth, chunk, len(files), dt * 1e3, len(files) / dt, ok))
+    gaps = np.diff(np.array(stamps)) * 1e3   # time between consecutive calls' completions: the pipeline's period
+    print('%d call(s) in flight, chunks of %d: %d files in %.1f ms = %.0f files/s overall; per call: median %.3f ms (= %.0f files/s), p10 %.3f, p90 %.3f  (%d decoded in the last pass)'
+          % (depth, chunk, ROUNDS * len(files), dt * 1e3, ROUNDS * len(files) / dt, np.median(gaps), chunk / np.median(gaps) * 1e3,
+             np.percentile(gaps, 10), np.percentile(gaps, 90), ok))
 reader.close()
