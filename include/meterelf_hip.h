@@ -226,7 +226,9 @@ int melf_jpeg_process_batch(melf_ctx* ctx, const uint8_t* const* data, const siz
 /* The same for n file names (the loop of get_meter_values, meterelf/_api.py:22-33): the library reads the files
  * (on threads) and processes them frame size by frame size (a list may mix sizes; H_used / W_used return the size of
  * the first file its decoder accepts); files it does not decode come back with status 1 / 2 / 4 for the caller to
- * route (host decode for another format).  Status 3 is not used by this call. */
+ * route (host decode for another format).  Status 3 is not used by this call.  The files are read straight into a
+ * pinned buffer of the context, from which they are uploaded as they are (byte stuffing and restart markers are taken
+ * out on the GPU): the host touches no byte of a file after read() has written it. */
 int melf_jpeg_process_files(melf_ctx* ctx, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                             melf_result* out_host, int32_t* status);
 

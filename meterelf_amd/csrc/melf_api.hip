@@ -1507,7 +1507,7 @@ static thread_local bool tl_jpeg_files_thread = false;
 static thread_local std::function<void()>* tl_jpeg_enqueued = nullptr;
 
 // Decode of n files into d_frames in chunks, pipelined: while chunk k's kernels run (on one of two decode streams),
-// the host parses chunk k + 1, builds its Huffman data, cleans its scan bytes into the other workspace's pinned stage
+// the host parses chunk k + 1, builds its Huffman data, copies its scan bytes (as they are: the GPU cleans them) into the other workspace's pinned stage
 // buffer, and the copy stream uploads it.  Serial, a 1024-file call spent more than half its time in host preparation,
 // the upload and the status read-back with the GPU idle.  The Huffman kernel is bound by its critical path (every
 // workgroup walks the same ~12 synchronisation rounds whatever the batch size: 0.8 ms for 256 files, 1.07 ms for 1024),
