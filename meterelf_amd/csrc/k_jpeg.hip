@@ -1428,9 +1428,15 @@ JpegParsed* jpeg_parsed_new(int n, bool with_tables)
     if (with_tables) p->slow.resize((size_t)n * 4);
     return p;
 }
+void jpeg_parsed_resize(JpegParsed* p, int n)   // keeps what it has allocated: entries are reset by jpeg_parse_one
+{
+    if ((int)p->hdr.size() < n) p->hdr.resize(n);
+    if (!p->slow.empty() && p->slow.size() < (size_t)n * 4) p->slow.resize((size_t)n * 4);
+}
 void jpeg_parse_one(JpegParsed* p, int i, const uint8_t* data, size_t size, int* H, int* W, int* supported)
 {
     JpegHeader& h = p->hdr[i];
+    h = JpegHeader();   // the object may be a previous call's
     if (!data || parse_headers(data, size, h) != 0) { *H = *W = 0; *supported = 0; return; }
     *H = h.H; *W = h.W; *supported = h.why ? 0 : 1;
     if (!h.why && !p->slow.empty()) build_slow4(h, p->slow.data() + (size_t)i * 4);

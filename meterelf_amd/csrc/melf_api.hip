@@ -305,6 +305,8 @@ struct melf_ctx {
     };
     uint8_t* file_arena[NFJ] = {};
     size_t file_arena_cap[NFJ] = {};
+    JpegParsed* files_parsed[NFJ] = {};     // the slot's parsed headers + decode data (re-used call after call)
+    size_t file_arena_per_file[NFJ] = {};   // arena bytes per file of the slot's last call: sizes the arena for the next one
     std::deque<FilesJob*> files_jobs;      // oldest first
     uint64_t files_next_ticket = 0;        // of the next _begin
     uint64_t files_decode_turn = 0;        // the ticket whose decode stage may run
@@ -604,7 +606,10 @@ extern "C" void melf_ctx_destroy(melf_ctx* c)
     if (!c) return;
     for (auto* j : c->files_jobs) { if (j->th.joinable()) j->th.join(); delete j; }
     c->files_jobs.clear();
-    for (int a = 0; a < melf_ctx::NFJ; ++a) if (c->file_arena[a]) (void)hipHostFree(c->file_arena[a]);
+    for (int a = 0; a < melf_ctx::NFJ; ++a) {
+        if (c->file_arena[a]) (void)hipHostFree(c->file_arena[a]);
+        if (c->files_parsed[a]) jpeg_parsed_free(c->files_parsed[a]);
+    }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int l = 0; l < melf_ctx::NLANES; ++l)   // resident mode and the split modes run whole calls on the lanes' own streams
@@ -1753,12 +1758,14 @@ static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, cons
 // so that a scripting host pays one call per chunk instead of an open/read per file.
 struct FilesRead {  // what the read stage hands to the decode stage
     std::vector<int> hs, ws, oks;
-    std::vector<size_t> off;     // file i's bytes: base + off[i], len[i] of them (64-byte aligned, 64 spare bytes behind each)
+    std::vector<const uint8_t*> where;  // file i's bytes (len[i] of them, 64-byte aligned, 64 spare bytes behind), NULL: not read
+    std::vector<size_t> off;     // ... = base + off[i] for a file in the arena
     std::vector<size_t> len;
     uint8_t* base = nullptr;     // the context's pinned arena of this call's slot
     size_t cap = 0;
+    std::vector<uint8_t> spill;  // files the arena had no room for
     JpegParsed* parsed = nullptr;  // every file's header and Huffman decode data, made by the thread that read the file
-    ~FilesRead() { if (parsed) jpeg_parsed_free(parsed); }
+                                   // (the slot's object: 3 MB per 1024 files, allocated -- and its pages faulted in -- once)
     FilesRead() = default;
     FilesRead(const FilesRead&) = delete;
     FilesRead& operator=(const FilesRead&) = delete;
@@ -1771,78 +1778,123 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
     if (n == 0) return MELF_SUCCESS;
     if (!paths || !out_host || !status || !H_used || !W_used || n < 0 || n > 32768) return fail(MELF_ERR_INVALID, "bad argument");
     pool_use_device(c->device);
-    // Two passes on the host pool: open + size, then -- the offsets known -- read into ONE grow-only arena (no per-file
-    // allocation, no zero fill, no fresh pages to fault in after the first call: with sixteen threads faulting pages
-    // of the same address space the per-file buffers cost more than the reads).
+    // ONE pass on the I/O pool (round 4; two before: a stat pass for the sizes, then the reads at known offsets): open, fstat,
+    // claim the file's place in the slot's pinned arena from a bump counter, read, close, parse.  The arena is grow-only (no
+    // per-file allocation, no zero fill, no fresh pages to fault in or to pin after the first calls); a file that no longer
+    // fits -- the first call of a context, or a list of larger files than any before -- is read again behind the pass into
+    // pageable memory (the decode stage then copies it like a caller's buffer), and the arena is replaced by a larger one
+    // before the slot's NEXT call reads into it.  Files sit in the arena in the order the threads claimed their places; the
+    // decode stage forms its chunks in arena order, so that a chunk's upload is still one contiguous span.
     static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int>&hs = R.hs, &ws = R.ws, &oks = R.oks;
     std::vector<size_t>&off = R.off, &len = R.len;
     try {
         hs.assign(n, 0); ws.assign(n, 0); oks.assign(n, 0);
-        off.assign((size_t)n + 1, 0);
+        off.assign(n, 0);
         len.assign(n, 0);
-        R.parsed = jpeg_parsed_new(n, true);
+        R.where.assign(n, nullptr);
+        if (!c->files_parsed[slot]) c->files_parsed[slot] = jpeg_parsed_new(n, true);
+        else jpeg_parsed_resize(c->files_parsed[slot], n);
+        R.parsed = c->files_parsed[slot];
     } catch (const std::exception&) {
         return fail(MELF_ERR_INVALID, "out of host memory");
     }
     // a camera frame is tens of KiB; a "JPEG" of more than 64 MiB is not one of ours (and n of them would not fit)
     const off_t max_file = (off_t)64 << 20;
-    // pass 1: sizes only.  No descriptor stays open between the passes: a chunk of 1024 files would sit right at the
-    // usual soft limit of 1024 open files, and a call may carry 32 768.
-    io_pool().run(n, [&](int i) {
-        struct stat sb;
-        const bool regular = paths[i] && stat(paths[i], &sb) == 0 && S_ISREG(sb.st_mode);
-        if (!regular || sb.st_size <= 0 || sb.st_size > max_file) {
-            status[i] = regular && sb.st_size > max_file ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_UNREADABLE;
-            return;
-        }
-        len[i] = (size_t)sb.st_size;
-        status[i] = MELF_JPEG_OK;
-    });
-    const auto t_opened = std::chrono::steady_clock::now();
-    // 64-byte aligned files with 64 spare bytes behind each (the GPU's scan cleaner reads a few bytes past a file's end)
-    for (int i = 0; i < n; ++i) off[(size_t)i + 1] = off[i] + (len[i] ? (len[i] + 64 + 63) / 64 * 64 : 0);
-    if (off[n] + 128 > c->file_arena_cap[slot]) {
+    {
         // pinned: the uploads start from this buffer.  Nothing of the GPU reads the old one any more: the slot's previous
         // call has been collected (its _end) before this one could be begun.
-        const size_t want = off[n] + off[n] / 4 + (1u << 20);
-        HIP_TRY(hipSetDevice(c->device));
-        if (c->file_arena[slot]) HIP_TRY(hipHostFree(c->file_arena[slot]));
-        c->file_arena[slot] = nullptr;
-        c->file_arena_cap[slot] = 0;
-        HIP_TRY(hipHostMalloc((void**)&c->file_arena[slot], want, hipHostMallocDefault));
-        c->file_arena_cap[slot] = want;
+        // what the slot's last call needed per file (48 KiB before there was one) x this call's files, + 25 %
+        const size_t per_file = c->file_arena_per_file[slot] ? c->file_arena_per_file[slot] : (size_t)48 << 10;
+        // (grown with room to spare: lists of slightly different sizes must not replace the arena call after call)
+        const size_t need = std::min<size_t>((size_t)n * (per_file + per_file / 8) + (1u << 20), (size_t)2 << 30);
+        const size_t want = need > c->file_arena_cap[slot] ? need + need / 2 : 0;
+        if (want > c->file_arena_cap[slot]) {
+            HIP_TRY(hipSetDevice(c->device));
+            if (c->file_arena[slot]) HIP_TRY(hipHostFree(c->file_arena[slot]));
+            c->file_arena[slot] = nullptr;
+            c->file_arena_cap[slot] = 0;
+            HIP_TRY(hipHostMalloc((void**)&c->file_arena[slot], want, hipHostMallocDefault));
+            c->file_arena_cap[slot] = want;
+        }
     }
     uint8_t* const base = R.base = c->file_arena[slot];
-    R.cap = c->file_arena_cap[slot];
+    const size_t cap = R.cap = c->file_arena_cap[slot];
     const auto t_arena = std::chrono::steady_clock::now();
-    // pass 2: open, read the size seen in pass 1, close (a file that shrank meanwhile is unreadable; of one that grew
-    // the decoder sees the first part and reports a corrupt stream: both go to the caller's host branch)
-    io_pool().run(n, [&](int i) {
-        if (status[i] != MELF_JPEG_OK) return;
-        const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
-        if (fd < 0) { status[i] = MELF_JPEG_UNREADABLE; return; }
-        const size_t sz = len[i];
+    std::atomic<size_t> bump{0};
+    std::atomic<int> spilled{0};
+    auto read_all = [](int fd, uint8_t* dst, size_t sz) {
         size_t got = 0;
         while (got < sz) {
-            const ssize_t r = read(fd, base + off[i] + got, sz - got);
+            const ssize_t r = read(fd, dst + got, sz - got);
             if (r > 0) got += (size_t)r;
             else if (r < 0 && errno == EINTR) continue;
             else break;
         }
+        return got;
+    };
+    io_pool().run(n, [&](int i) {
+        status[i] = MELF_JPEG_UNREADABLE;
+        const int fd = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+        if (fd < 0) return;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { close(fd); return; }
+        if (!S_ISREG(sb.st_mode) || sb.st_size <= 0 || sb.st_size > max_file) {
+            if (S_ISREG(sb.st_mode) && sb.st_size > max_file) status[i] = MELF_JPEG_UNSUPPORTED;
+            close(fd);
+            return;
+        }
+        const size_t sz = len[i] = (size_t)sb.st_size;
+        // 64-byte aligned, 64 spare bytes behind each file (the GPU's scan cleaner reads a few bytes past a file's end)
+        const size_t space = (sz + 64 + 63) / 64 * 64;
+        const size_t o = bump.fetch_add(space, std::memory_order_relaxed);
+        if (o + space + 64 > cap) {   // no room (any more): second pass below
+            close(fd);
+            spilled.fetch_add(1, std::memory_order_relaxed);
+            status[i] = MELF_JPEG_OK;
+            return;
+        }
+        off[i] = o;
+        const size_t got = read_all(fd, base + o, sz);
         close(fd);
-        if (got != sz) { status[i] = MELF_JPEG_UNREADABLE; return; }
+        if (got != sz) return;   // the file shrank meanwhile (one that grew: the decoder sees the first part and reports a corrupt stream)
+        status[i] = MELF_JPEG_OK;
+        R.where[i] = base + o;
         // header and Huffman decode data right here, while the file's first lines are in this core's cache: the decode stage
         // then has nothing to compute per file
-        jpeg_parse_one(R.parsed, i, base + off[i], sz, &hs[i], &ws[i], &oks[i]);
+        jpeg_parse_one(R.parsed, i, base + o, sz, &hs[i], &ws[i], &oks[i]);
     });
+    const auto t_read = std::chrono::steady_clock::now();
+    c->file_arena_per_file[slot] = std::max<size_t>(bump.load() / (size_t)n, 4096);
+    if (spilled.load() > 0) {
+        std::vector<size_t> so((size_t)n + 1, 0);
+        for (int i = 0; i < n; ++i) so[(size_t)i + 1] = so[i] + ((status[i] == MELF_JPEG_OK && !R.where[i]) ? (len[i] + 64 + 63) / 64 * 64 : 0);
+        try {
+            R.spill.resize(so[n] + 128);
+        } catch (const std::exception&) {
+            return fail(MELF_ERR_INVALID, "out of host memory");
+        }
+        io_pool().run(n, [&](int i) {
+            if (status[i] != MELF_JPEG_OK || R.where[i]) return;
+            status[i] = MELF_JPEG_UNREADABLE;
+            const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
+            if (fd < 0) return;
+            uint8_t* dst = R.spill.data() + so[i];
+            const size_t got = read_all(fd, dst, len[i]);
+            close(fd);
+            if (got != len[i]) return;
+            status[i] = MELF_JPEG_OK;
+            R.where[i] = dst;
+            jpeg_parse_one(R.parsed, i, dst, len[i], &hs[i], &ws[i], &oks[i]);
+        });
+    }
     if (trace) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): sizes %.2f ms, arena %.2f ms, open + read + parse %.2f ms\n", n, off[n] / 1e6,
-                ms(t0, t_opened), ms(t_opened, t_arena), ms(t_arena, std::chrono::steady_clock::now()));
+        fprintf(stderr, "[melf jpeg] n=%d files read (%.1f MB): arena %.2f ms, open + read + parse %.2f ms, %d file(s) read again behind a full arena %.2f ms\n",
+                n, bump.load() / 1e6, ms(t0, t_arena), ms(t_arena, t_read), spilled.load(), ms(t_read, std::chrono::steady_clock::now()));
     }
     return MELF_SUCCESS;
 }
@@ -1859,6 +1911,7 @@ static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_use
     int left = 0;
     for (int i = 0; i < n; ++i) {
         if (status[i] != MELF_JPEG_OK) continue;
+        if (!R.where[i]) { status[i] = MELF_JPEG_UNREADABLE; continue; }
         if (!R.oks[i]) { status[i] = R.hs[i] > 0 ? MELF_JPEG_UNSUPPORTED : MELF_JPEG_CORRUPT; continue; }
         todo[i] = 1;
         ++left;
@@ -1875,9 +1928,13 @@ static int jpeg_files_decode(melf_ctx* c, int n, int32_t* H_used, int32_t* W_use
             if (!todo[i]) continue;
             if (!H) { H = R.hs[i]; W = R.ws[i]; }
             if (R.hs[i] != H || R.ws[i] != W) continue;
-            ptr.push_back(R.base + R.off[i]); len.push_back(R.len[i]); where.push_back(i);
+            where.push_back(i);
             todo[i] = 0;
         }
+        // in the order the files lie in memory: a chunk of the pipelined decode is then one contiguous span of the pinned arena
+        // (the upload starts there); which files share a chunk is scheduling only, the records go back by `where`
+        std::sort(where.begin(), where.end(), [&](int a, int b) { return (uintptr_t)R.where[a] < (uintptr_t)R.where[b]; });
+        for (int i : where) { ptr.push_back(R.where[i]); len.push_back(R.len[i]); }
         if (!*H_used) { *H_used = H; *W_used = W; }
         const int m = (int)ptr.size();
         left -= m;

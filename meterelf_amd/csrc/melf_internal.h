@@ -145,6 +145,7 @@ JpegParsed* jpeg_parse_files(const uint8_t* const* data, const size_t* sizes, in
 // the same file by file, from any thread (one thread per index): the file-name entry points parse a file right after
 // reading it, on the thread that read it, and build its decode tables there too
 JpegParsed* jpeg_parsed_new(int n, bool with_tables);
+void jpeg_parsed_resize(JpegParsed* p, int n);   // room for n files; nothing is cleared (jpeg_parse_one resets its entry)
 void jpeg_parse_one(JpegParsed* p, int i, const uint8_t* data, size_t size, int* H, int* W, int* supported);
 void jpeg_parsed_free(JpegParsed* p);
 // parsed: headers made earlier -- of file pidx[first + j] for the batch's file j (pidx NULL: of file first + j); host_status is

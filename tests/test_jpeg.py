@@ -403,6 +403,46 @@ def test_get_meter_values_never_touches_the_host_decoder_for_fixtures(sd, monkey
 
 
 @pytest.mark.gpu
+def test_files_that_outgrow_the_pinned_arena(tmp_path):
+    """The file-name entry points read every file into a pinned arena sized from the slot's previous call; a list whose files
+    no longer fit (here: 300 camera frames after a call with three flat frames of a few KB) is read behind the pass into pageable memory
+    and decoded all the same; the call after that finds an arena that holds everything.  Records and status equal to the
+    bytes entry point's for the same files, whichever way they took."""
+    from meterelf_amd import MeterReader, _hip, _params
+    rng = np.random.default_rng(5)
+    reader = MeterReader(_params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml')))
+    try:
+        tiny = []
+        for k in range(3):
+            f = tmp_path / ('tiny%d.jpg' % k)
+            f.write_bytes(_encode(np.full((640, 480, 3), 40 * k + 17, np.uint8), quality=30))   # a flat frame: a few KB
+            tiny.append(str(f))
+        assert all(os.path.getsize(f) < 8000 for f in tiny)
+        good = [f for f in _files('sample-images1') if _hip.jpeg_probe(open(f, 'rb').read())[:2] == (640, 480)]
+        many = [good[i] for i in rng.integers(0, len(good), 300)] + [str(tmp_path / 'nope.jpg')]
+        (ref, ref_status) = reader.ctx.jpeg_process_batch([open(f, 'rb').read() for f in many[:-1]], 640, 480)
+        assert (ref_status == 0).all()
+        (r0, s0, hw0) = reader.ctx.jpeg_process_files(tiny)          # the context's first call: a small arena
+        assert hw0 == (640, 480) and (s0 == 0).all()
+        for attempt in range(3):                                      # 1: most files spill; 2, 3: the arena has grown
+            (got, status, hw) = reader.ctx.jpeg_process_files(many)
+            assert hw == (640, 480) and (status[:-1] == 0).all() and status[-1] == _hip.JPEG_UNREADABLE, attempt
+            assert got[:-1].tobytes() == ref.tobytes(), attempt
+        # and through the begin / end pair, every slot's first big call after a small one
+        for k in range(_hip.FILES_IN_FLIGHT_MAX):
+            reader.ctx.jpeg_process_files_begin(tiny)
+        for k in range(_hip.FILES_IN_FLIGHT_MAX):
+            reader.ctx.jpeg_process_files_end()
+        for k in range(_hip.FILES_IN_FLIGHT_MAX):
+            reader.ctx.jpeg_process_files_begin(many)
+        for k in range(_hip.FILES_IN_FLIGHT_MAX):
+            (got, status, hw) = reader.ctx.jpeg_process_files_end()
+            assert (status[:-1] == 0).all() and status[-1] == _hip.JPEG_UNREADABLE and got[:-1].tobytes() == ref.tobytes(), k
+    finally:
+        reader.close()
+
+
+@pytest.mark.gpu
 def test_process_files_in_two_halves(tmp_path):
     """melf_jpeg_process_files_begin / _end: the records of the one-piece call; THREE calls may be in flight (a later one's
     files are read while an earlier one decodes) and come back in order; a fourth _begin, the one-piece call meanwhile and an _end
