@@ -272,18 +272,26 @@ static void build_huff(const HuffSpec& t, HuffSlow* slow)
 // The entropy-coded segment without byte stuffing (FF 00 -> FF), fill bytes and RSTn markers, up to the first other marker
 // (normally EOI) -- on the GPU since round 4 (rounds 1-3: a host pass, clean_scan): the host no longer touches the entropy-coded bytes except to copy them (or, for
 // the file-name entry points, not at all: the files are read straight into the pinned buffer the upload starts from).
-// One workgroup per file, 4 KiB per round, 16 consecutive bytes per thread.  In entropy-coded data every FF is special and
+// One workgroup per file, 16 KiB per round, 16 consecutive bytes per thread.  In entropy-coded data every FF is special and
 // the byte behind it says how: 00 = a stuffed FF (keep the FF, drop the 00), FF = fill (drop this one, look at the next),
 // D0..D7 = RSTn (drop both, the next restart interval begins at the clean offset reached), anything else -- or the end of
 // the data -- ends the scan.  Per round: (1) the first scan-ending FF of the round (minimum over the workgroup), (2) keep
 // flags and restart markers below it, one packed prefix scan of both counts, (3) byte stores of the kept bytes at their
 // clean offsets, restart offsets into the table behind the scan.  Leaves scan_len / rst_cnt in the file's record and the
 // rest of the file's scan region zeroed, exactly what the host pass left.
-__global__ __launch_bounds__(256) void k_jpeg_clean(JpegImageDev* __restrict__ imgs, const uint8_t* __restrict__ raw,
-                                                    uint8_t* __restrict__ scan)
+constexpr int CLEAN_T = 1024;   // threads of k_jpeg_clean: 16 KiB per round, a camera frame's scan in two or three
+// 0x80 in every byte of x that is zero (exact: no borrow between bytes), and such flags gathered into a nibble
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }
+__device__ __forceinline__ uint32_t flag_nibble(uint32_t f)
+{
+    const uint32_t y = f >> 7;   // bits 0, 8, 16, 24
+    return (y | (y >> 7) | (y >> 14) | (y >> 21)) & 15u;
+}
+__global__ __launch_bounds__(CLEAN_T) void k_jpeg_clean(JpegImageDev* __restrict__ imgs, const uint8_t* __restrict__ raw,
+                                                        uint8_t* __restrict__ scan)
 {
     __shared__ int s_end;
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wsum[CLEAN_T / 64];
     JpegImageDev* R = imgs + blockIdx.x;
     if (!R->ok) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -295,10 +303,10 @@ __global__ __launch_bounds__(256) void k_jpeg_clean(JpegImageDev* __restrict__ i
     const int rst_cap = has_rst ? (int)R->rst_cnt + 1 : 0;   // the host left the EXPECTED number of intervals here
     int o_base = 0, r_base = 0;   // clean bytes written, restart markers seen, before this round
     bool ended = false;
-    for (int base = 0; base < n && !ended; base += 4096) {
+    for (int base = 0; base < n && !ended; base += CLEAN_T * 16) {
         if (tid == 0) s_end = INT_MAX;
         const int my = base + tid * 16;
-        // bytes my - 1 .. my + 16 (the raw area is padded: reads past n stay inside it; their values are never used)
+        // bytes my - 1 .. my + 16 (the raw area is padded: reads past n stay inside it; their values are masked below)
         uint32_t w[5] = {0, 0, 0, 0, 0};
         uint32_t prev = 0;
         if (my < n) {
@@ -306,32 +314,41 @@ __global__ __launch_bounds__(256) void k_jpeg_clean(JpegImageDev* __restrict__ i
             for (int q = 0; q < 5; ++q) __builtin_memcpy(&w[q], s + my + 4 * q, 4);
             if (my > 0) prev = s[my - 1];
         }
-        auto byte_at = [&](int j) { return (w[j >> 2] >> (8 * (j & 3))) & 255u; };
-        auto special_next = [](uint32_t b) { return b == 0x00u || b == 0xFFu || (b >= 0xD0u && b <= 0xD7u); };
-        int first_end = INT_MAX;
+        // One bit per byte 0 .. 16 of the thread's window: is it FF (F), 00 (Z), D0..D7 (D)?  The whole classification then
+        // is a handful of 17-bit mask operations (the per-byte form of this loop was 2 000 instructions per round).
+        uint32_t F = 0, Z = 0, D = 0;
 #pragma unroll
-        for (int j = 15; j >= 0; --j) {
-            const int p = my + j;
-            if (p < n && byte_at(j) == 0xFFu && (p + 1 >= n || !special_next(byte_at(j + 1)))) first_end = p;
+        for (int q = 0; q < 4; ++q) {
+            F |= flag_nibble(zero_bytes(~w[q])) << (4 * q);
+            Z |= flag_nibble(zero_bytes(w[q])) << (4 * q);
+            D |= flag_nibble(zero_bytes((w[q] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u)) << (4 * q);
         }
+        {
+            const uint32_t b16 = w[4] & 255u;
+            F |= (uint32_t)(b16 == 0xFFu) << 16;
+            Z |= (uint32_t)(b16 == 0x00u) << 16;
+            D |= (uint32_t)((b16 & 0xF8u) == 0xD0u) << 16;
+        }
+        const int left = n - my;                                                         // bytes of the data from `my` on (may be <= 0)
+        const uint32_t Vm = left >= 16 ? 0xFFFFu : (left > 0 ? (1u << left) - 1u : 0u);   // byte j exists
+        const uint32_t NV = left >= 17 ? 0xFFFFu : (left > 1 ? (1u << (left - 1)) - 1u : 0u);   // byte j + 1 exists
+        const uint32_t Fn = F >> 1, Zn = Z >> 1, Dn = D >> 1;
+        const uint32_t Fp = ((F << 1) | (uint32_t)(prev == 0xFFu)) & 0xFFFFu;
+        const uint32_t F16 = F & 0xFFFFu;
+        // an FF that ends the scan: no byte behind it, or one that is neither 00 nor FF nor D0..D7
+        const uint32_t endmask = F16 & Vm & ~((Zn | Fn | Dn) & NV);
         __syncthreads();
-        if (first_end != INT_MAX) atomicMin(&s_end, first_end);
+        if (endmask) atomicMin(&s_end, my + (int)__builtin_ctz(endmask));
         __syncthreads();
         const int end = min(s_end, n);
-        uint32_t keep = 0, mark = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = my + j;
-            const uint32_t b = byte_at(j), nx = byte_at(j + 1), pv = j ? byte_at(j - 1) : prev;
-            const bool live = p < end;
-            const bool isff = b == 0xFFu;
-            const bool k = live && (isff ? (nx == 0x00u && p + 1 < n) : !(pv == 0xFFu && (b == 0x00u || (b >= 0xD0u && b <= 0xD7u))));
-            const bool m = live && isff && p + 1 < n && nx >= 0xD0u && nx <= 0xD7u;
-            keep |= (uint32_t)k << j;
-            mark |= (uint32_t)m << j;
-        }
+        const int live = end - my;
+        const uint32_t Lm = live >= 16 ? 0xFFFFu : (live > 0 ? (1u << live) - 1u : 0u);
+        // kept: a stuffed FF (FF 00), and every other byte that is not the second byte of a stuffed pair or of a marker
+        const uint32_t keep = Lm & ((F16 & Zn & NV) | (~F16 & ~(Fp & (Z | D)) & 0xFFFFu));
+        const uint32_t mark = Lm & F16 & Dn & NV;
         // exclusive prefix of (kept bytes | markers << 16) over the workgroup
-        const uint32_t mine = (uint32_t)__popc(keep) | ((uint32_t)__popc(mark) << 16);
+        const uint32_t cnt = (uint32_t)__popc(keep);
+        const uint32_t mine = cnt | ((uint32_t)__popc(mark) << 16);
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -342,27 +359,63 @@ __global__ __launch_bounds__(256) void k_jpeg_clean(JpegImageDev* __restrict__ i
         __syncthreads();
         uint32_t before = incl - mine, total = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < CLEAN_T / 64; ++q) {
             const uint32_t t = s_wsum[q];
             if (q < wv) before += t;
             total += t;
         }
-        int ko = o_base + (int)(before & 0xffffu), ro = r_base + (int)(before >> 16);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if ((mark >> j) & 1u) {   // the interval behind this marker begins at the clean offset reached here
+        const int ko = o_base + (int)(before & 0xffffu);
+        // restart markers (rare: only files with restart intervals have any): the interval behind marker k begins at the
+        // clean offset reached where the marker stood
+        if (__builtin_amdgcn_ballot_w64(mark != 0u) != 0ull) {
+            int ro = r_base + (int)(before >> 16);
+            uint32_t m = mark;
+            while (m) {
+                const int j = __builtin_ctz(m);
+                m &= m - 1u;
                 ++ro;
-                if (ro < rst_cap) rst[ro] = (uint32_t)ko;
+                if (ro < rst_cap) rst[ro] = (uint32_t)(ko + __popc(keep & ((1u << j) - 1u)));
             }
-            if ((keep >> j) & 1u) out[ko++] = (uint8_t)byte_at(j);
+        }
+        // the kept bytes moved together: a dropped byte below the highest kept one is squeezed out of the 16-byte value, highest
+        // first (typically none or one per thread; the loop runs as often as the wave's worst lane needs)
+        uint32_t v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
+        uint32_t drop = keep ? (~keep & ((2u << (31 - __builtin_clz(keep))) - 1u)) : 0u;
+        while (__builtin_amdgcn_ballot_w64(drop != 0u) != 0ull) {
+            if (drop) {
+                const int q = 31 - __builtin_clz(drop);   // the byte to squeeze out
+                drop &= ~(1u << q);
+                const int dq = q >> 2;
+                const uint32_t lm = (1u << (8 * (q & 3))) - 1u;   // bytes of dword dq below it
+                const uint32_t s0 = __builtin_amdgcn_alignbit(v1, v0, 8), s1 = __builtin_amdgcn_alignbit(v2, v1, 8),
+                               s2 = __builtin_amdgcn_alignbit(v3, v2, 8), s3 = v3 >> 8;
+                v0 = dq == 0 ? ((v0 & lm) | (s0 & ~lm)) : v0;
+                v1 = dq == 1 ? ((v1 & lm) | (s1 & ~lm)) : (dq < 1 ? s1 : v1);
+                v2 = dq == 2 ? ((v2 & lm) | (s2 & ~lm)) : (dq < 2 ? s2 : v2);
+                v3 = dq == 3 ? ((v3 & lm) | (s3 & ~lm)) : s3;
+            }
+        }
+        {   // cnt bytes at out + ko: whole dwords (any alignment), then up to three single bytes
+            uint8_t* o = out + ko;
+            if (cnt >= 4u) __builtin_memcpy(o, &v0, 4);
+            if (cnt >= 8u) __builtin_memcpy(o + 4, &v1, 4);
+            if (cnt >= 12u) __builtin_memcpy(o + 8, &v2, 4);
+            if (cnt >= 16u) __builtin_memcpy(o + 12, &v3, 4);
+            const uint32_t full = cnt >> 2;
+            const uint32_t tailw = full == 0u ? v0 : (full == 1u ? v1 : (full == 2u ? v2 : v3));
+            const uint32_t r = cnt & 3u;
+            uint8_t* t = o + 4 * full;
+            if (r >= 1u) t[0] = (uint8_t)tailw;
+            if (r >= 2u) t[1] = (uint8_t)(tailw >> 8);
+            if (r >= 3u) t[2] = (uint8_t)(tailw >> 16);
         }
         o_base += (int)(total & 0xffffu);
         r_base += (int)(total >> 16);
-        ended = end < base + 4096;   // uniform: the scan ended inside this round (or the data did)
-        __syncthreads();              // s_end and s_wsum are rewritten by the next round
+        ended = end < base + CLEAN_T * 16;   // uniform: the scan ended inside this round (or the data did)
+        __syncthreads();                      // s_end and s_wsum are rewritten by the next round
     }
     const int cap = (int)R->scan_cap;
-    for (int i = o_base + tid; i < cap; i += 256) out[i] = 0;
+    for (int i = o_base + tid; i < cap; i += CLEAN_T) out[i] = 0;
     if (tid == 0) {
         R->scan_len = (uint32_t)o_base;
         if (has_rst) {
@@ -370,6 +423,47 @@ __global__ __launch_bounds__(256) void k_jpeg_clean(JpegImageDev* __restrict__ i
             R->rst_cnt = (uint32_t)(r_base + 1);
         }
     }
+}
+
+// Test entry (tests/test_jpeg.py; not part of the C ABI in include/): k_jpeg_clean on ONE byte string as if it were a file's
+// entropy-coded segment -- arbitrary bytes, so that the tests can feed it every FF pattern, legal or not, and compare with the
+// sequential rule.  restart_expected > 0: a file with restart intervals, table of restart_expected + 1 entries.
+extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_clean(const uint8_t* raw, int n, int restart_expected, uint8_t* out,
+                                                                            int32_t* out_len, uint32_t* rst, int32_t* rst_cnt)
+{
+    if (n < 0 || !out || !out_len || (n > 0 && !raw)) return -1;
+    const size_t scan_cap = ((size_t)n + 128 + 63) / 64 * 64, table = restart_expected > 0 ? ((size_t)restart_expected + 1) * 4 + 64 : 0;
+    JpegImageDev rec;
+    memset(&rec, 0, sizeof(rec));
+    rec.ok = restart_expected > 0 ? 2 : 1;
+    rec.restart_interval = restart_expected > 0 ? 1 : 0;
+    rec.rst_cnt = (uint32_t)std::max(restart_expected, 0);
+    rec.rst_off = (uint32_t)scan_cap;
+    rec.scan_cap = (uint32_t)scan_cap;
+    rec.raw_len = (uint32_t)n;
+    uint8_t *d_rec = nullptr, *d_raw = nullptr, *d_scan = nullptr;
+    int rc = -1;
+    if (hipMalloc((void**)&d_rec, sizeof(rec)) == hipSuccess && hipMalloc((void**)&d_raw, (size_t)n + 64) == hipSuccess &&
+        hipMalloc((void**)&d_scan, scan_cap + table + 64) == hipSuccess &&
+        hipMemset(d_raw, 0xFF, (size_t)n + 64) == hipSuccess &&   // what lies behind the data must not matter: make it hostile
+        hipMemset(d_scan, 0xEE, scan_cap + table + 64) == hipSuccess &&
+        hipMemcpy(d_rec, &rec, sizeof(rec), hipMemcpyHostToDevice) == hipSuccess &&
+        (n == 0 || hipMemcpy(d_raw, raw, (size_t)n, hipMemcpyHostToDevice) == hipSuccess)) {
+        hipLaunchKernelGGL(k_jpeg_clean, dim3(1), dim3(CLEAN_T), 0, 0, (JpegImageDev*)d_rec, d_raw, d_scan);
+        std::vector<uint8_t> back(scan_cap + table);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&rec, d_rec, sizeof(rec), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(back.data(), d_scan, back.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            *out_len = (int32_t)rec.scan_len;
+            memcpy(out, back.data(), scan_cap);   // the caller's buffer holds n + 192 bytes: clean bytes, then the zero fill
+            if (restart_expected > 0 && rst && rst_cnt) {
+                *rst_cnt = (int32_t)rec.rst_cnt;
+                memcpy(rst, back.data() + scan_cap, ((size_t)restart_expected + 1) * 4);
+            }
+            rc = 0;
+        }
+    }
+    (void)hipFree(d_rec); (void)hipFree(d_raw); (void)hipFree(d_scan);
+    return rc;
 }
 
 // ------------------------------------------------------------------ J1: Huffman ----
@@ -1673,7 +1767,7 @@ int jpeg_decode_batch_kernels(JpegWorkspace* w, int n, int H, int W, uint8_t* d_
     const uint8_t* scan = w->d_stage + w->off_scan;
     if (timer) timer(timer_arg, 0, 0);
     if (w->n_par + w->n_seq > 0)   // J0: stuffing, fill bytes and restart markers out of the uploaded segments
-        hipLaunchKernelGGL(k_jpeg_clean, dim3(n), dim3(256), 0, stream, (JpegImageDev*)(w->d_stage + w->off_imgs), w->d_raw, w->d_stage + w->off_scan);
+        hipLaunchKernelGGL(k_jpeg_clean, dim3(n), dim3(CLEAN_T), 0, stream, (JpegImageDev*)(w->d_stage + w->off_imgs), w->d_raw, w->d_stage + w->off_scan);
     if (w->n_par > 0) {  // one workgroup per image, one lane per stream segment
         static int tenv = -1;
         if (tenv < 0) { const char* e = getenv("MELF_JPEG_T"); tenv = e ? atoi(e) : 0; }

@@ -201,11 +201,79 @@ def _with_fill_bytes_and_tail(data, rng):
     return bytes(out)
 
 
+def _clean_scan_rule(s, rst_cap):
+    """The sequential rule k_jpeg_clean restates (ITU-T T.81 B.1.1.5 / F.1.2.3 as libjpeg reads them): FF 00 -> FF, an FF in
+    front of an FF is a fill byte, FF D0..D7 is a restart marker (both bytes go, the next interval starts at the clean offset
+    reached), any other FF xx -- or an FF with nothing behind it -- ends the scan."""
+    (out, rst, found, i, n) = (bytearray(), [0], 1, 0, len(s))
+    while i < n:
+        if s[i] != 0xFF:
+            out.append(s[i]); i += 1
+        elif i + 1 >= n:
+            break
+        elif s[i + 1] == 0x00:
+            out.append(0xFF); i += 2
+        elif s[i + 1] == 0xFF:
+            i += 1
+        elif 0xD0 <= s[i + 1] <= 0xD7:
+            if found < rst_cap:
+                rst.append(len(out))
+            found += 1; i += 2
+        else:
+            break
+    return bytes(out), rst, found
+
+
+@pytest.mark.gpu
+def test_scan_cleaner_kernel_against_the_sequential_rule():
+    """k_jpeg_clean alone (melf_debug_jpeg_clean) on byte strings no encoder would write: random bytes, strings made of nothing
+    but FF / 00 / D0..D7 / others, mostly-legal streams with stuffing, fill runs and markers at every alignment, lengths around
+    the 16-byte thread windows and the 16 KiB rounds, empty input, markers beyond the table's capacity.  Clean bytes, clean
+    length, restart table and count equal the sequential rule's; the region behind the clean bytes is zero."""
+    import ctypes as C
+    from meterelf_amd import _hip
+    L = _hip.lib()
+    L.melf_debug_jpeg_clean.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
+    rng = np.random.default_rng(20260410)
+    lengths = [0, 1, 2, 15, 16, 17, 31, 33, 255, 1000, 4095, 4097, 16383, 16384, 16385, 16400, 32768, 32769, 50000] + \
+        [int(v) for v in rng.integers(1, 70000, 40)]
+    for (trial, n) in enumerate(lengths * 2):
+        kind = trial % 4
+        if kind == 0:
+            a = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:
+            a = rng.choice(np.array([0xFF, 0x00, 0xD0, 0xD3, 0xD7, 0x12, 0xFF, 0x00, 0xFF, 0x55], np.uint8), n)
+        else:   # mostly legal: an FF is followed by 00, FF or a restart marker; kind 3 ends with EOI somewhere and garbage behind
+            a = rng.integers(0, 255, n, dtype=np.uint8)
+            for k in rng.integers(0, max(n - 2, 1), n // 6 + 1):
+                if n >= 2:
+                    a[k] = 0xFF
+                    a[k + 1] = rng.choice([0, 0, 0, 0xFF, 0xD1, 0xD5])
+            if kind == 3 and n > 40:
+                e = int(rng.integers(n // 2, n - 2))
+                a[e] = 0xFF
+                a[e + 1] = 0xD9
+        s = a.tobytes()
+        expected = int(rng.integers(1, 3000)) if trial % 3 else 0
+        out = np.full(n + 192, 0x77, np.uint8)
+        out_len = C.c_int32(-1)
+        rst = np.full(expected + 1, 0xFFFFFFFF, np.uint32)
+        rst_cnt = C.c_int32(-1)
+        rc = L.melf_debug_jpeg_clean(s, n, expected, out.ctypes.data_as(C.c_void_p), C.byref(out_len), rst.ctypes.data_as(C.c_void_p), C.byref(rst_cnt))
+        assert rc == 0
+        (ref, ref_rst, found) = _clean_scan_rule(s, expected + 1)
+        assert out_len.value == len(ref), (trial, n, kind, out_len.value, len(ref))
+        assert out[:len(ref)].tobytes() == ref, (trial, n, kind, int(np.argmax(np.frombuffer(ref, np.uint8) != out[:len(ref)])))
+        assert not out[len(ref):(n + 128 + 63) // 64 * 64].any(), (trial, n, kind)
+        if expected:
+            assert rst_cnt.value == found and list(rst[:len(ref_rst)]) == ref_rst, (trial, n, kind, rst_cnt.value, found)
+
+
 @pytest.mark.gpu
 def test_scan_cleaning_on_the_gpu_fill_bytes_markers_and_tails(ctx):
     """k_jpeg_clean takes byte stuffing, fill bytes and RSTn markers out of the scan on the GPU and stops at EOI: files with
     fill bytes in front of every marker and with marker-like garbage behind EOI decode to the same pixels as libjpeg's (which
-    steps over both); scans of many 4 KiB rounds (noise at quality 95: a stuffed FF on every round and thread boundary sooner
+    steps over both); scans of several 16 KiB rounds (noise at quality 95: a stuffed FF on every round and thread boundary sooner
     or later); a scan cut in the middle of a stuffed pair; a file that ends with FF."""
     from meterelf_amd import _hip
     rng = np.random.default_rng(4242)
