@@ -409,6 +409,19 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
 // from the table at context creation) -> no 3-way select, one 32 KiB table.
 // VAR 3: any sectors, no ties.  VAR 4: any sectors, ties re-evaluated exactly.
 // VAR 5: timing-only (memory traffic and barriers, no pixel math; output is garbage).
+#ifdef MELF_FUSED_STAMP
+// Diagnostic build only (make stamp; tools/fused_clock.py): per workgroup, the 100 MHz real-time clock at its start, when its
+// tables are in LDS, when its first pass has been stored and at its end; XCC id for the placement.
+__device__ uint64_t g_fused_stamps[8 * 4096];
+extern "C" __attribute__((visibility("default"))) int melf_debug_fused_stamps(uint64_t* out, int nwg)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), sizeof(uint64_t) * 8 * (size_t)(nwg < 4096 ? nwg : 4096)) == hipSuccess ? 0 : -1;
+}
+#define FSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_fused_stamps[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
+
 template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */>
 __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const uint8_t* __restrict__ frames, int n, int H, int W, int hue_shift, Bounds B,
@@ -436,6 +449,11 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     uint32_t* raw = ring;
     uint32_t* he = raw + NB * wpr;
     const int tid = threadIdx.x;
+    FSTAMP(0);
+#ifdef MELF_FUSED_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_fused_stamps[8 * blockIdx.x + 4] = xcc & 15u; uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_fused_stamps[8 * blockIdx.x + 5] = hw; }
+    int fstamp_passes = 0;
+#endif
     // Table fill, run once per workgroup AFTER the first frame loads have been issued (see below).
     auto fill_tables = [&]() {
         if (IV) {
@@ -587,7 +605,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                     o.z = *(const uint32_t*)((const char*)expand4 + ((h16 >> 6) & 0x3cu));
                     o.w = *(const uint32_t*)((const char*)expand4 + ((h16 >> 10) & 0x3cu));
                     u32x4* dstp = (u32x4*)(out + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tg));
-                    if (plain_store) *dstp = o;
+                    if (plain_store & 1) *dstp = o;
                     else __builtin_nontemporal_store(o, dstp);
                 }
             }
@@ -615,12 +633,23 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             // PD + 1 rotating register sets: the loads of the next PD passes are in flight while the
             // current pass is processed (all indices are compile-time after unrolling)
             Px16 pbuf[PD + 1];
+#ifdef MELF_FUSED_STAMP
+            // Experiment of the diagnostic build (MELF_FUSED_PRIO, tools/fused_clock.py): wave priorities that favour the CU's
+            // second workgroup (2), or each of the two half the time by the clock both read (5..9: half-periods of 2.5 .. 41 us).
+            // Outcome (profiles/r04/fused_workgroup_clock.txt): the priority decides WHICH workgroup of a CU finishes first
+            // (0.56 vs 0.74 ms at 1080p, either way round) and the complementary schemes make them finish together -- at the
+            // time the slower one needed before: the launch is as long as it was.  What the workgroups share is the memory
+            // system's throughput for this mix, not the CU's issue slots.
+            const int prio_mode = plain_store >> 8;
+            const bool young = blockIdx.x >= 256;   // the second workgroup a CU received
+#endif
 #pragma unroll
             for (int q = 0; q < PD; ++q) load(a + q * RC, pbuf[q]);
             if (!tables_ready) {  // the frame loads above are already in flight while LDS is filled
                 fill_tables();
                 tables_ready = true;
                 __syncthreads();
+                FSTAMP(1);
             }
             // same explicit wait as before each store (see pass()): the loop body then never waits on
             // a load that is younger than a store
@@ -628,8 +657,18 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             for (bool more = true; more;) {
 #pragma unroll
                 for (int q = 0; q <= PD; ++q) {
+#ifdef MELF_FUSED_STAMP
+                    if (prio_mode == 2) { if (young) __builtin_amdgcn_s_setprio(1); }
+                    else if (prio_mode >= 5) {
+                        const bool hi = (((uint32_t)__builtin_amdgcn_s_memrealtime() >> (prio_mode + 3)) & 1u) != (young ? 1u : 0u);
+                        if (hi) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                    }
+#endif
                     load(a + PD * RC, pbuf[(q + PD) % (PD + 1)]);
                     pass(a, pbuf[q]);
+#ifdef MELF_FUSED_STAMP
+                    if (fstamp_passes++ == 0) FSTAMP(2);
+#endif
                     a += RC;
                     if (a >= aend) { more = false; break; }
                 }
@@ -645,6 +684,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
         }
         lds_barrier();
     }
+    FSTAMP(3);
 }
 
 bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W)
@@ -708,7 +748,8 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // timing events (optional, set by the caller through fused_mask_timing_events): the dispatch's own start / stop stamps,
     // no event-record packets in the queue around the kernel
     hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
-                          n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, plain_store, RC);
+                          n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB,
+                          plain_store | ((getenv("MELF_FUSED_PRIO") ? atoi(getenv("MELF_FUSED_PRIO")) : 0) << 8), RC);
     g_fused_ev_start = g_fused_ev_stop = nullptr;
 }
 
