@@ -5,6 +5,7 @@ MI355X is visible, everything here raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -193,6 +194,30 @@ def _file_table(files):
 
 
 file_table = _file_table
+
+
+def _path_table(paths):
+    """list of file names (str or bytes) -> (char** as a numpy array of addresses, keep-alive).  One join + one encode for the
+    whole list instead of an os.fsencode and a ctypes conversion per name (0.45 -> 0.05 ms per 1024 names: the Python side
+    of get_meter_values is one thread, and its per-chunk cost is what long lists wait for)."""
+    n = len(paths)
+    if n == 0:
+        return np.zeros(1, np.uint64), None
+    if all(type(p) is str for p in paths):
+        blob = ('\0'.join(paths) + '\0').encode(sys.getfilesystemencoding(), 'surrogateescape')   # = os.fsencode, for all at once
+    else:
+        blob = b'\0'.join(os.fsencode(p) for p in paths) + b'\0'
+    buf = np.frombuffer(blob, np.uint8)
+    ends = np.flatnonzero(buf == 0)
+    if len(ends) != n:   # a name with an embedded NUL: the per-name route refuses it with a proper error
+        enc = [os.fsencode(p) for p in paths]
+        arr = (C.c_char_p * n)(*enc)
+        return np.frombuffer(arr, np.uint64), (arr, enc)
+    addr = np.empty(n, np.uint64)
+    addr[0] = 0
+    addr[1:] = ends[:-1] + 1
+    addr += np.uint64(buf.ctypes.data)
+    return addr, (blob, buf)
 
 
 def pack_blob(cparams, template):
@@ -428,9 +453,8 @@ class Context:
         status = np.zeros(n, np.int32)
         (H, W) = (C.c_int32(0), C.c_int32(0))
         if n:
-            enc = [os.fsencode(p) for p in paths]
-            arr = (C.c_char_p * n)(*enc)
-            check(self._L.melf_jpeg_process_files(self._h, arr, n, C.byref(H), C.byref(W), _ptr(out), _ptr(status)))
+            (addr, keep) = _path_table(paths)
+            check(self._L.melf_jpeg_process_files(self._h, _ptr(addr), n, C.byref(H), C.byref(W), _ptr(out), _ptr(status)))
         return out, status, (H.value, W.value)
 
     def jpeg_process_files_begin(self, paths):
@@ -441,12 +465,11 @@ class Context:
         out = np.zeros(n, dtype=RESULT_DTYPE)
         status = np.zeros(n, np.int32)
         hw = (C.c_int32(0), C.c_int32(0))
-        enc = [os.fsencode(p) for p in paths]
-        arr = (C.c_char_p * max(n, 1))(*enc)
-        check(self._L.melf_jpeg_process_files_begin(self._h, arr, n, C.byref(hw[0]), C.byref(hw[1]), _ptr(out), _ptr(status)))
+        (addr, keep) = _path_table(paths)
+        check(self._L.melf_jpeg_process_files_begin(self._h, _ptr(addr), n, C.byref(hw[0]), C.byref(hw[1]), _ptr(out), _ptr(status)))
         if getattr(self, '_files_pending', None) is None:
             self._files_pending = []
-        self._files_pending.append((out, status, hw, arr, enc))  # everything the library points into, alive until its _end
+        self._files_pending.append((out, status, hw, addr, keep))  # everything the library points into, alive until its _end
 
     def jpeg_process_files_end(self):
         (out, status, hw, _arr, _enc) = self._files_pending.pop(0)  # the library forgets the call whatever it returns
