@@ -278,9 +278,9 @@ _STOP = object()
 def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode: bool, batch: int) -> Iterator[MeterImageData]:
     """Chunk k goes to worker k mod D (one per entry of `devices`: its own thread, MeterReader and begin / end pipeline); the
     workers' chunk results come back through per-worker queues and are yielded in input order.  Every worker may hold
-    AHEAD chunks (the two its library works on, the one being converted, one waiting), so the consumer is at most
+    AHEAD chunks (those its library works on, the one being converted, one waiting), so the consumer is at most
     D x AHEAD chunks behind the file list.  A worker's exception is re-raised here, at the position of its chunk."""
-    AHEAD = 4
+    AHEAD = _hip.FILES_IN_FLIGHT_MAX + 2
     nw = len(devices)
     inq = [queue.Queue() for _ in range(nw)]
     outq = [queue.Queue() for _ in range(nw)]
@@ -303,6 +303,15 @@ def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode
             outq[w].put(_STOP)
 
     threads = [threading.Thread(target=work, args=(w,), name='meterelf-dev%d-%d' % (devices[w], w), daemon=True) for w in range(nw)]
+    # The workers and this thread hand the interpreter lock to each other once per chunk (a worker converts a chunk's records,
+    # this thread yields them); a thread that wants the lock while another runs Python code waits up to one switch interval --
+    # 5 ms by default, several chunks' worth.  A shorter interval for as long as the fan-out runs (restored afterwards;
+    # METERELF_SWITCH_INTERVAL=seconds, 0 = leave the interpreter's setting alone).
+    import sys
+    switch_before = sys.getswitchinterval()
+    want = float(os.getenv('METERELF_SWITCH_INTERVAL', '0.0005'))
+    if want > 0 and want < switch_before:
+        sys.setswitchinterval(want)
     for t in threads:
         t.start()
     dealt = 0        # chunks handed out
@@ -341,3 +350,5 @@ def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode
         # _process_chunks' own clean-up) and end; nothing of theirs is yielded any more
         for t in threads:
             t.join()
+        if sys.getswitchinterval() != switch_before:
+            sys.setswitchinterval(switch_before)

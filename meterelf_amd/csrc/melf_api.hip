@@ -1606,6 +1606,8 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
         // ... and the kernels that last read its device buffers before the upload overwrites them
         if (seq >= (uint64_t)NJ) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_jdec[b], 0));
         if (int rc = jpeg_upload_batch(*ws[b], m, c->copy_stream, &err)) return fail(rc, err);
+        double t_up = 0;
+        if (trace) t_up = trace_clock_ms(std::chrono::steady_clock::now());
         HIP_TRY(hipEventRecord(c->ev_jup[b], c->copy_stream));
         HIP_TRY(hipStreamWaitEvent(dstream[b], c->ev_jup[b], 0));
         JpegTimers t{c, dstream[b], {}, {false, false, false}};
@@ -1623,8 +1625,8 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
         HIP_TRY(hipEventRecord(c->ev_jdec[b], dstream[b]));
         if (trace) {
             tt[4] = trace_clock_ms(std::chrono::steady_clock::now());
-            fprintf(stderr, "[melf jpeg]   chunk %d (%d files, ring slot %d): at %.2f, slot free %.2f, prepared %.2f, decode enqueued %.2f, all enqueued %.2f\n",
-                    k, m, b, tt[0], tt[1], tt[2], tt[3], tt[4]);
+            fprintf(stderr, "[melf jpeg]   chunk %d (%d files, ring slot %d): at %.2f, slot free %.2f, prepared %.2f, uploads enqueued %.2f, decode enqueued %.2f, all enqueued %.2f\n",
+                    k, m, b, tt[0], tt[1], tt[2], t_up, tt[3], tt[4]);
         }
     }
     // the context's stream continues when this call's decode streams are done (a slot's latest record covers its earlier ones)
@@ -1717,7 +1719,10 @@ static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, cons
         HIP_TRY(hipHostMalloc((void**)&c->h_jstatus[cs], jrecs_offset((size_t)n) + (size_t)n * sizeof(melf_result), hipHostMallocDefault));
         c->jstatus_cap[cs] = (size_t)n;
     }
-    if (!c->ev_jcall[cs]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jcall[cs], hipEventDisableTiming));
+    // blocking sync: the thread that waits for a call's kernels sleeps instead of spinning (several calls wait at any time --
+    // three per context, times the contexts of a process -- and the cores are needed by the I/O pool's readers)
+    static const bool spin = getenv("MELF_JPEG_SPIN_WAIT") != nullptr;   // A/B
+    if (!c->ev_jcall[cs]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jcall[cs], hipEventDisableTiming | (spin ? 0 : hipEventBlockingSync)));
     int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks, nsparse, c->d_jframes[cs], c->d_jresults[cs], c->h_jstatus[cs],
                                    overlapped, src);
     if (rc == MELF_SUCCESS && !read_chunks) {
