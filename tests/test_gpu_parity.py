@@ -10,6 +10,7 @@ left-to-right sum.
 import glob
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -19,6 +20,7 @@ from tests.helpers import hip_runtime
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 POS_TOL = 1e-9
 NOISY_MATCH_VAL = '20180814021310-00-e02.jpg'
 REJECTED = ('20180814021309-01-e01.jpg', NOISY_MATCH_VAL)  # the two 'Dials not found' frames
@@ -378,6 +380,28 @@ def test_full_path_matches_golden_stdout(env, sd, count, capsys):
             continue
         bad.append((name, got, exp))
     assert bad == []
+
+
+def test_run_as_a_module_like_the_reference_integration_test():
+    """integration-tests/test_all_sample_images of the reference: `python3 -m <package> params.yml <all jpg files, sorted>` from
+    inside sample-images1, exit code 0, EMPTY stderr, stdout equal to the expected file -- here a fresh interpreter running
+    `python -m meterelf_amd` on the GPU (the one declared tolerance: the match value's last float digits in one line)."""
+    import subprocess
+    d = os.path.join(GOLDEN, 'sample-images1')
+    files = sorted(f for f in os.listdir(d) if f.endswith('.jpg'))
+    assert len(files) == 81
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    p = subprocess.run([sys.executable, '-m', 'meterelf_amd', 'params.yml'] + files, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stderr == b''
+    with open(os.path.join(GOLDEN, 'sample-images1_stdout.txt')) as fp:
+        expected = fp.read().splitlines()
+    got = p.stdout.decode().splitlines()
+    assert len(got) == len(expected) == 81
+    for (g, x) in zip(got, expected):
+        if g != x:
+            assert g.split(': ', 1)[0] == x.split(': ', 1)[0] == NOISY_MATCH_VAL, (g, x)
 
 
 @pytest.mark.parametrize('sd', ['sample-images1', 'sample-images2'])

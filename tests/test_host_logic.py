@@ -609,3 +609,20 @@ def test_no_scratch_in_the_hot_path_kernels():
     assert kinds['k_prep_lplane'] == 2 and kinds['k_match_mfma'] == 8 and kinds['k_match_gen'] == 7 and kinds['k_dials'] == 12, kinds
     assert kinds['k_fused_mask_lut'] >= 8 and kinds['k_jpeg_huff'] >= 4, kinds
     assert not any('k_colsum' in n for n in meta)       # the window sums are added up by the match waves since round 4
+
+
+def test_import_only_and_run_as_script():
+    """The reference's tests/test_main.py:9-22: importing the package's __main__ module does not run main(); running the
+    package as a script (`python -m meterelf_amd`, the reference's integration-tests/test_all_sample_images:20) calls it."""
+    import runpy
+    from unittest.mock import patch
+
+    import meterelf_amd
+    with patch.object(_main, 'main') as main_func_mock:
+        from meterelf_amd import __main__ as main_mod
+        main_func_mock.assert_not_called()
+        assert main_mod.__name__ == '{}.__main__'.format(meterelf_amd.__name__)
+        del sys.modules[main_mod.__name__]   # as the reference does: no "found in sys.modules" warning below
+    with patch.object(_main, 'main') as main_func_mock:
+        runpy.run_module(meterelf_amd.__name__, run_name='__main__')
+        main_func_mock.assert_called_with()
