@@ -291,6 +291,33 @@ def dials_roofline(kernel_ms, traffic, label):
     return out
 
 
+def prep_roofline(P, H, W, kernel_ms, traffic, label, frames_per_launch):
+    """k_prep_lplane is HBM-bound; priced on ALGORITHMIC bytes (SURVEY.md 8d's rule): per frame the meter_rect crop read once
+    (3 B/px) + the L' plane written once in the match kernels' fragment order (1 B/px, rows padded to whole 32-column blocks) +
+    the row-window sums written once (2 B per map column, padded to 32-column blocks).  The counter traffic of the PMC pass
+    stands beside it as `traffic`: the ratio is what the kernel moves beyond the bytes it has to."""
+    crows = min(P.rect_y1, H) - min(P.rect_y0, H)
+    ccols = min(P.rect_x1, W) - min(P.rect_x0, W)
+    nkb = (ccols + 31) // 32
+    rwp = 32 * ((ccols - P.tw + 1 + 31) // 32)
+    per_frame = crows * ccols * 3 + crows * nkb * 32 + crows * rwp * 2
+    ms = kernel_ms.get('k_lplane')
+    (tr, src) = traffic.get(label + ':k_prep_lplane')
+    out = {'kernel': 'k_prep_lplane', 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'avg_launch_ms': ms,
+           'algorithmic': '%d B/frame (crop %d read + L plane %d + row-window sums %d written) x %d frames/launch' % (
+               per_frame, crows * ccols * 3, crows * nkb * 32, crows * rwp * 2, frames_per_launch),
+           'traffic': tr, 'traffic_source': src,
+           'note': 'avg_launch_ms: hipEvents around each launch in the per-kernel pass of this run'}
+    if ms:
+        gbs = per_frame * frames_per_launch / (ms * 1e-3) / 1e9
+        out.update({'achieved': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4)})
+        if tr:
+            out['traffic_over_algorithmic'] = round(tr / (per_frame * frames_per_launch), 3)
+    else:
+        out.update({'achieved': None, 'frac': None})
+    return out
+
+
 def kernel_sources_sha():
     """Hash of the kernel sources (k_*.hip and the device header): what the measured HBM traffic depends on."""
     h = hashlib.sha256()
@@ -556,6 +583,53 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
         t2 = time.perf_counter() - t20
         two = {'launches': n2, 'ms_per_launch': round(t2 / n2 * 1e3, 4), 'GBps': round(alg_bytes * n2 / t2 / 1e9, 1),
                'frac_of_hbm_peak': round(alg_bytes * n2 / t2 / 1e9 / HBM_PEAK_GBS, 4)}
+    # What the part streams for this traffic mix, measured HERE: a bare persistent stream (48 B in, 16 B out per thread and
+    # step, no pixel arithmetic, the kernel's launch shape) over the same buffers in the same rotation, launches interleaved
+    # with the kernel's own so that both see the same clocks; the masks it overwrites are not used again.
+    ceiling = None
+    if hasattr(ctx, 'stream_probe_dev'):
+        in_bytes = FB * H * W * 3
+        variants = [('static', 0), ('static_prefetch', -1), ('queue2', 2), ('queue4', 4)]
+        ctx.set_profiling(1)
+        ctx.timings()
+        rounds = max(6, min(steps, 24))
+        for i in range(rounds + 2):
+            if i == 2:
+                env.sync()
+                ctx.timings()       # the first two rounds are warm-up
+            b = i % nbuf
+            for (_name, ch) in variants:
+                ctx.stream_probe_dev(frames.data_ptr() + b * in_bytes, in_bytes, masks.data_ptr() + b * FB * H * W, ch, stream=env.stream)
+        env.sync()
+        (pms, pn) = ctx.timings()['k_stream_probe']
+        # per variant: the launches alternate, so a second pass with one variant at a time gives the split
+        per = {}
+        for (name, ch) in variants:
+            for i in range(rounds):
+                b = i % nbuf
+                ctx.stream_probe_dev(frames.data_ptr() + b * in_bytes, in_bytes, masks.data_ptr() + b * FB * H * W, ch, stream=env.stream)
+            env.sync()
+            (vms, vn) = ctx.timings()['k_stream_probe']
+            moved = (in_bytes // (48 * 1024)) * 64 * 1024
+            per[name] = {'avg_launch_ms': round(vms / max(vn, 1), 4), 'GBps': round(moved / (vms / max(vn, 1) * 1e-3) / 1e9, 1)}
+        # the kernel again, right after, for a same-minute comparison
+        for i in range(rounds):
+            launch(i)
+        env.sync()
+        (kms, kn) = ctx.timings()['k_fused_mask']
+        ctx.set_profiling(0)
+        best = max(v['GBps'] for v in per.values())
+        k_gbs = alg_bytes / (kms / max(kn, 1) * 1e-3) / 1e9
+        ceiling = {'what': 'bare persistent 3:1 stream (48 B read + 16 B written per thread and step, lane-contiguous 16-byte loads, '
+                           'non-temporal stores, 512 workgroups of 1024 threads, no arithmetic) over the SAME buffers in the same '
+                           'rotation, dispatch time stamps like the kernel\'s; static = grid-stride split, static_prefetch = the same with the '
+                           'next chunk requested before this one is stored (the kernel\'s register prefetch), queueN = blocks of N '
+                           'chunks from a work queue',
+                   'variants': per, 'best_GBps': best, 'frac_of_hbm_peak': round(best / HBM_PEAK_GBS, 4),
+                   'interleaved_avg_launch_ms': round(pms / max(pn, 1), 4),
+                   'kernel_right_after': {'avg_launch_ms': round(kms / max(kn, 1), 4), 'GBps': round(k_gbs, 1),
+                                          'frac_of_hbm_peak': round(k_gbs / HBM_PEAK_GBS, 4)},
+                   'kernel_frac_of_achievable': round(k_gbs / best, 4)}
     del masks
     return {
         'workload': 'B=%d %dx%d uniform-random u8 frames, fused HLS+inRange+closing only, %d distinct buffer pairs '
@@ -565,6 +639,7 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
                      'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': tr, 'traffic_source': src,
                      'avg_launch_ms': round(favg, 4), 'launches': fn,
                      'algorithmic': '%d B/frame x %d frames/launch' % (H * W * 4, FB)},
+        'stream_ceiling': ceiling,
         'two_streams': two,
     }
 
@@ -686,6 +761,8 @@ def jpeg_block(ctx, sample_dir, H, W):
     from meterelf_amd import get_meter_values, release_cached_contexts
     pfile = os.path.join(GOLDEN, sample_dir, 'params.yml')
     names = [jfiles[i % len(jfiles)] for i in range(64 * 1024)]  # a long list: the per-call costs (params, calibration blob) stop mattering
+    dev = os.environ.get('METERELF_DEVICES')
+    os.environ['METERELF_DEVICES'] = '%d' % ctx.device   # ONE context on this rank's GPU, whatever the caller's environment says
     sum(1 for _ in get_meter_values(pfile, names[:2048]))  # warm-up: the context the API keeps between calls
     tg0 = time.perf_counter()
     n_api = sum(1 for r in get_meter_values(pfile, names) if r.error is None)
@@ -693,7 +770,6 @@ def jpeg_block(ctx, sample_dir, H, W):
     release_cached_contexts()
     # the same over TWO contexts on this GPU (METERELF_DEVICES=0,0: the multi-device fan-out of the API -- one reader, one host
     # thread, one begin / end pipeline per entry -- exercised on the one GPU a rank has; on a node the entries are the node's GPUs)
-    dev = os.environ.get('METERELF_DEVICES')
     os.environ['METERELF_DEVICES'] = '%d,%d' % (ctx.device, ctx.device)
     try:
         sum(1 for _ in get_meter_values(pfile, names[:4096]))
@@ -709,7 +785,7 @@ def jpeg_block(ctx, sample_dir, H, W):
     return {'workload': '%d JPEG files (%d distinct %s fixtures, %.1f KB average) -> decode + full reading path, '
                         'file bytes in host memory to result records (melf_jpeg_process_batch, mean of 20 calls; the pointer table built once)' % (JB, len(blobs), sample_dir, sum(map(len, blobs)) / len(blobs) / 1024),
             'files_per_s': round(JB / tj, 1), 'ms_per_call': round(tj * 1e3, 3),
-            'get_meter_values': {'files_per_s': round(len(names) / tg, 1), 'files': len(names), 'values_read': n_api,
+            'get_meter_values': {'files_per_s': round(len(names) / tg, 1), 'files': len(names), 'values_read': n_api, 'devices': 1,
                                  'what': 'meterelf_amd.get_meter_values(params.yml, file names): the reference API, files read '
                                          'from the page cache inside the library, MeterImageData objects out',
                                  'two_contexts_on_this_gpu': {'files_per_s': round(len(names) / tg2, 1), 'values_read': n_api2,
@@ -814,6 +890,7 @@ def main():
     roofline['k_dials_avg_launch_ms'] = full['kernel_ms'].get('k_dials')
     roofline['k_prep_avg_launch_ms'] = full['kernel_ms'].get('k_lplane')
     roofline_dials = dials_roofline(full['kernel_ms'], traffic, main_label)
+    roofline_prep = prep_roofline(full['P'], full['H'], full['W'], full['kernel_ms'], traffic, main_label, args.batch)
 
     fused = None
     if 'fused' in blocks:
@@ -848,6 +925,7 @@ def main():
                 'per_rank_ms_per_step': f4['per_rank_ms'], 'frames_read_ok_batch0': int((f4['recs'][:B]['status'] == 0).sum()),
                 'kernel_ms': f4['kernel_ms'], 'step_events': f4.get('step_events'), 'match_layout': f4.get('match_layout'),
                 'roofline': f4['roofline'], 'roofline_dials': dials_roofline(f4['kernel_ms'], traffic, 'config4'),
+                'roofline_prep': prep_roofline(f4['P'], f4['H'], f4['W'], f4['kernel_ms'], traffic, 'config4', args.batch),
                 'two_streams': f4.get('two_streams'), 'resident_hint': f4.get('resident_hint'),
                 'cpu_baseline': f4.get('cpu')}
         f4['ctx'].close()
@@ -867,7 +945,7 @@ def main():
                        'untimed_preheat_steps': args.preheat},
             'per_rank_ms_per_step': full['per_rank_ms'], 'rccl_ranks': rccl_ranks, 'backend': env.backend,
             'kernel_ms': full['kernel_ms'], 'step_events': full.get('step_events'), 'match_layout': full.get('match_layout'),
-            'roofline': roofline, 'roofline_dials': roofline_dials, 'sustained': full.get('sustained'), 'two_streams': full.get('two_streams'),
+            'roofline': roofline, 'roofline_dials': roofline_dials, 'roofline_prep': roofline_prep, 'sustained': full.get('sustained'), 'two_streams': full.get('two_streams'),
             'resident_hint': full.get('resident_hint'),
             'cpu_baseline': full.get('cpu'),
             'fused_mask': fused, 'config4': cfg4, 'config5': cfg5, 'host_fed': hostfed, 'jpeg_decode': jpeg,

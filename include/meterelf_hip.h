@@ -37,7 +37,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 #define MELF_MAX_DIALS 8
-#define MELF_ABI_VERSION 2
+#define MELF_ABI_VERSION 3
 
 /* API status codes (negative) */
 enum {
@@ -156,6 +156,15 @@ int melf_hls_inrange_close(melf_ctx* ctx, const uint8_t* frames_host, int n, int
 int melf_hls_inrange_close_dev(melf_ctx* ctx, const void* d_frames, int n, int H, int W,
                                void* d_masks, void* stream);
 
+/* Measurement aid for the fused stage's roofline (bench.py: fused_mask.stream_ceiling), nothing the reference has: one launch
+ * of a BARE persistent stream with the fused kernel's traffic mix and launch shape -- 48 bytes read and 16 bytes written per
+ * thread and step, no pixel arithmetic -- over the caller's device buffers: floor(in_bytes / 48 KiB) chunks of d_in are read,
+ * a third as many bytes of d_out are overwritten with garbage (XOR of the input: point it at a mask buffer that is rewritten
+ * afterwards).  chunks_per_block = 0: static grid-stride split; < 0: the same with the kernel's register prefetch (the next
+ * chunk requested before this one is stored); > 0: blocks of that many chunks from a work queue.  The launch
+ * is timed like the fused kernel's (melf_ctx_set_profiling(1), entry MELF_K_STREAM_PROBE of melf_ctx_timings). */
+int melf_stream_probe_dev(melf_ctx* ctx, const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, void* stream);
+
 /* Number of entries of the fused stage's hue lookup table whose in-range answer
  * depends on the float32 rounding of the individual BGR triple (exact rounding
  * ties at a bound).  > 0 selects the kernel variant that re-evaluates those
@@ -259,7 +268,7 @@ int melf_ctx_set_frames_resident(melf_ctx* ctx, int on);
  * by hipEvents on its stream; melf_ctx_timings drains them (synchronising) and
  * returns per-kernel accumulated milliseconds and launch counts. */
 enum { MELF_K_LPLANE = 0, MELF_K_MATCH = 1, MELF_K_DIALS = 2, MELF_K_FUSED_MASK = 3, MELF_K_HLS = 4,
-       MELF_K_JPEG_HUFF = 5, MELF_K_JPEG_IDCT = 6, MELF_K_JPEG_COLOR = 7, MELF_K_COUNT = 8 };
+       MELF_K_JPEG_HUFF = 5, MELF_K_JPEG_IDCT = 6, MELF_K_JPEG_COLOR = 7, MELF_K_STREAM_PROBE = 8, MELF_K_COUNT = 9 };
 /* Which kernel, in which layout, computed the template match (meterelf/_utils.py:91-97: ONE cv2.matchTemplate code
  * path in the reference; here the batch size and the crop shape select among three kernels and, for the tuned one,
  * among wave layouts) of the context's most recent call.  Tests assert it, so that a change of a dispatch threshold

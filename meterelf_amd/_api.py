@@ -9,8 +9,10 @@ works on the next two chunks while the current chunk's results are consumed, so 
 are read ahead of the consumer.
 
 Several GPUs in one process (round 4): the chunks are dealt round-robin over METERELF_DEVICES (a comma list of
-device indices; default "all" = every visible device; "0,0" = two contexts on one GPU), one MeterReader and one
-begin / end pipeline per device, each on its own thread; the results are yielded in input order.  Frames are
+device indices; "all" = every visible device; "0,0" = two contexts on one GPU), one MeterReader and one
+begin / end pipeline per device, each on its own thread; the results are yielded in input order.  Unset, ONE device is
+used -- LOCAL_RANK's under torchrun (one process per GPU), else device 0: a rank of a
+process-per-GPU job must not open contexts on its neighbours' GPUs, so fanning out is always an explicit choice.  Frames are
 independent (meterelf/_api.py:22-33), so there is no collective: the process holds the calibration blob and every
 device gets its own context from it.  With one device nothing changes (no threads).
 
@@ -111,9 +113,13 @@ if hasattr(os, 'register_at_fork'):
 
 
 def _device_list() -> List[int]:
-    """METERELF_DEVICES: comma list of device indices (an index may repeat: that many contexts on that GPU), or "all"."""
-    spec = os.getenv('METERELF_DEVICES', 'all').strip()
-    if spec in ('', 'all'):
+    """METERELF_DEVICES: comma list of device indices (an index may repeat: that many contexts on that GPU), or "all".
+    Unset or empty: one device -- LOCAL_RANK's (torchrun: one process per GPU), else device 0."""
+    spec = os.getenv('METERELF_DEVICES', '').strip()
+    if spec == '':
+        rank = os.getenv('LOCAL_RANK', '').strip()
+        return [int(rank) % max(1, _hip.device_count())] if rank.isdigit() else [0]
+    if spec == 'all':
         return list(range(max(1, _hip.device_count())))
     return [int(x) for x in spec.split(',') if x.strip() != ''] or [0]
 
@@ -274,6 +280,36 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
 
 _STOP = object()
 
+# The interpreter's thread switch interval is process-wide: overlapping fan-outs share ONE override, counted under a lock,
+# and the value found by the first one is put back when the last one ends (METERELF_SWITCH_INTERVAL=0: never touched).
+_switch_lock = threading.Lock()
+_switch_users = 0
+_switch_saved = 0.0
+
+
+def _switch_interval_enter() -> bool:
+    global _switch_users, _switch_saved
+    import sys
+    want = float(os.getenv('METERELF_SWITCH_INTERVAL', '0.0005'))
+    if want <= 0:
+        return False
+    with _switch_lock:
+        if _switch_users == 0:
+            _switch_saved = sys.getswitchinterval()
+            if want < _switch_saved:
+                sys.setswitchinterval(want)
+        _switch_users += 1
+    return True
+
+
+def _switch_interval_exit() -> None:
+    global _switch_users
+    import sys
+    with _switch_lock:
+        _switch_users -= 1
+        if _switch_users == 0 and sys.getswitchinterval() != _switch_saved:
+            sys.setswitchinterval(_switch_saved)
+
 
 def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode: bool, batch: int) -> Iterator[MeterImageData]:
     """Chunk k goes to worker k mod D (one per entry of `devices`: its own thread, MeterReader and begin / end pipeline); the
@@ -305,13 +341,9 @@ def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode
     threads = [threading.Thread(target=work, args=(w,), name='meterelf-dev%d-%d' % (devices[w], w), daemon=True) for w in range(nw)]
     # The workers and this thread hand the interpreter lock to each other once per chunk (a worker converts a chunk's records,
     # this thread yields them); a thread that wants the lock while another runs Python code waits up to one switch interval --
-    # 5 ms by default, several chunks' worth.  A shorter interval for as long as the fan-out runs (restored afterwards;
-    # METERELF_SWITCH_INTERVAL=seconds, 0 = leave the interpreter's setting alone).
-    import sys
-    switch_before = sys.getswitchinterval()
-    want = float(os.getenv('METERELF_SWITCH_INTERVAL', '0.0005'))
-    if want > 0 and want < switch_before:
-        sys.setswitchinterval(want)
+    # 5 ms by default, several chunks' worth.  A shorter interval for as long as any fan-out runs (counted: overlapping
+    # generators share one override, the last one out restores; METERELF_SWITCH_INTERVAL=seconds, 0 = leave it alone).
+    switched = _switch_interval_enter()
     for t in threads:
         t.start()
     dealt = 0        # chunks handed out
@@ -350,5 +382,5 @@ def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode
         # _process_chunks' own clean-up) and end; nothing of theirs is yielded any more
         for t in threads:
             t.join()
-        if sys.getswitchinterval() != switch_before:
-            sys.setswitchinterval(switch_before)
+        if switched:
+            _switch_interval_exit()

@@ -18,14 +18,14 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MELF_LIB_PATH') or os.path.join(_PKG, 'libmeterelf_hip.so')  # override: A/B builds
 
 MAX_DIALS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FRAME_OK = 0
 FRAME_DIALS_NOT_FOUND = 1
 FRAME_NEEDLE_CONTOURS_NOT_FOUND = 2
 FRAME_ANGLE_UNDETERMINED = 3
 
-K_LPLANE, K_MATCH, K_DIALS, K_FUSED_MASK, K_HLS, K_JPEG_HUFF, K_JPEG_IDCT, K_JPEG_COLOR, K_COUNT = range(9)
+K_LPLANE, K_MATCH, K_DIALS, K_FUSED_MASK, K_HLS, K_JPEG_HUFF, K_JPEG_IDCT, K_JPEG_COLOR, K_STREAM_PROBE, K_COUNT = range(10)
 JPEG_OK, JPEG_UNSUPPORTED, JPEG_CORRUPT, JPEG_SIZE_MISMATCH, JPEG_UNREADABLE = 0, 1, 2, 3, 4
 FILES_IN_FLIGHT_MAX = 3   # MELF_FILES_IN_FLIGHT_MAX (include/meterelf_hip.h); tests compare with melf_jpeg_files_in_flight_max()
 
@@ -77,7 +77,7 @@ EXPORTS = [
     'melf_last_error', 'melf_abi_version', 'melf_device_count', 'melf_build_dial_masks',
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_sync', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
-    'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
+    'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_stream_probe_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_match_gen_plan_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
     'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end', 'melf_jpeg_files_in_flight_max',
@@ -118,6 +118,7 @@ def lib():
     L.melf_bgr2hls.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp]
     L.melf_hls_inrange_close.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.melf_hls_inrange_close_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.melf_stream_probe_dev.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
     L.melf_match_ccoeff.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.melf_read_dials.argtypes = [vp, vp, C.c_int, vp]
     L.melf_aligned_average.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_int, vp]
@@ -209,10 +210,8 @@ def _path_table(paths):
         blob = b'\0'.join(os.fsencode(p) for p in paths) + b'\0'
     buf = np.frombuffer(blob, np.uint8)
     ends = np.flatnonzero(buf == 0)
-    if len(ends) != n:   # a name with an embedded NUL: the per-name route refuses it with a proper error
-        enc = [os.fsencode(p) for p in paths]
-        arr = (C.c_char_p * n)(*enc)
-        return np.frombuffer(arr, np.uint64), (arr, enc)
+    if len(ends) != n:   # a name with an embedded NUL: a C string would silently end there ('good.jpg\0x' would open good.jpg)
+        raise ValueError('embedded null byte')   # what open() raises for such a name
     addr = np.empty(n, np.uint64)
     addr[0] = 0
     addr[1:] = ends[:-1] + 1
@@ -358,6 +357,11 @@ class Context:
     def hls_inrange_close_dev(self, d_frames_ptr, n, H, W, d_masks_ptr, stream=None):
         check(self._L.melf_hls_inrange_close_dev(self._h, C.c_void_p(d_frames_ptr), n, H, W,
                                                   C.c_void_p(d_masks_ptr), C.c_void_p(stream) if stream else None))
+
+    def stream_probe_dev(self, d_in_ptr, in_bytes, d_out_ptr, chunks_per_block=0, stream=None):
+        """Measurement aid: one bare 3:1 stream launch over device buffers (include/meterelf_hip.h); d_out is overwritten."""
+        check(self._L.melf_stream_probe_dev(self._h, C.c_void_p(d_in_ptr), C.c_size_t(in_bytes), C.c_void_p(d_out_ptr),
+                                             int(chunks_per_block), C.c_void_p(stream) if stream else None))
 
     def match_ccoeff(self, images, want_map=False):
         images = np.ascontiguousarray(images, dtype=np.uint8)

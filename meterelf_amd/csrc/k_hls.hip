@@ -13,6 +13,9 @@
 // pass 4 expands bits to bytes, one dword store per 4 pixels.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <atomic>
+
 #include "melf_device.h"
 #include <hip/hip_ext.h>
 
@@ -278,7 +281,7 @@ void launch_build_fused_tables(int hue_shift, const int lo[3], const int hi[3], 
 {
     Bounds B;
     for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
-    (void)hipMemsetAsync(d_tables, 0, FUSED_TABLE_DWORDS * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(d_tables, 0, FUSED_BUF_DWORDS * sizeof(uint32_t), stream);   // tables and work queues
     hipLaunchKernelGGL(k_build_fused_tables, dim3(65536), dim3(256), 0, stream, hue_shift, B, d_tables);
     hipLaunchKernelGGL(k_finish_fused_tables, dim3(HUE1_DWORDS / 256), dim3(256), 0, stream, d_tables);
     hipLaunchKernelGGL(k_interval_tables, dim3((3 * (LSI_ROWS + HI_ROWS) + 255) / 256), dim3(256), 0, stream, d_tables);
@@ -422,10 +425,14 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_fused_stamps(ui
 #define FSTAMP(k) do { } while (0)
 #endif
 
-template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */>
+template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */,
+          bool DYN = false /* segments from the launch's work queue (PD == 1 only) instead of the static split */>
 __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const uint8_t* __restrict__ frames, int n, int H, int W, int hue_shift, Bounds B,
-    const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB, int plain_store, int rc_dma)
+    const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB, int plain_store, int rc_dma,
+    uint32_t* __restrict__ wq /* work queue of this launch {next segment, workgroups done}, or NULL: static split */,
+    int big_segs, int big_rows /* DYN: a frame's first big_segs x big_rows rows are "big" segments (ids 0 .. n big_segs - 1: every workgroup's
+                                  first one), the rest segs_per_frame small ones of seg_rows rows, handed out behind them */)
 {
     constexpr bool PREFETCH = PD > 0;
     // PD < 0 (round 4, experiment MELF_FUSED_CONFIG=6): the pixel rows of a pass arrive by LDS-DMA with the non-temporal policy
@@ -454,14 +461,22 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     if (threadIdx.x == 0 && blockIdx.x < 4096) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_fused_stamps[8 * blockIdx.x + 4] = xcc & 15u; uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_fused_stamps[8 * blockIdx.x + 5] = hw; }
     int fstamp_passes = 0;
 #endif
-    // Table fill, run once per workgroup AFTER the first frame loads have been issued (see below).
+    // Table fill, run once per workgroup AFTER the first frame loads have been issued (see below).  Interval tables: the two
+    // table words of a thread's row are requested here, BEFORE the first frame loads (round 5): loads return in order, so
+    // behind 48 bytes per thread of pixel rows the tables reached LDS only when the whole chip's first pass had landed.
+    static_assert(!IV || THREADS >= 256, "one interval-table row per thread");
+    uint32_t pre_vh = 0, pre_vl = 0;
+    if (IV && DYN && tid < 256) {   // (the static launch has no two registers to spare at 8 waves per SIMD: it loads them in fill_tables)
+        pre_vh = g_tables[OFF_HI + (VAR - 6) * HI_ROWS + 256 + tid];   // hI rows diff = 0..255 (table rows diff + 256)
+        pre_vl = g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + tid];       // lsI row P
+    }
     auto fill_tables = [&]() {
         if (IV) {
-            // each (lo, count) row replicated so that lane L of a 32-lane group always reads bank L:
-            // one global load per row, then 16-byte LDS stores
-            for (int r = tid; r < 256; r += THREADS) {  // hI rows diff = 0..255 (table rows diff + 256), lsI rows P
-                const uint32_t vh = g_tables[OFF_HI + (VAR - 6) * HI_ROWS + 256 + r];
-                const uint32_t vl = g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + r];
+            // each (lo, count) row replicated so that lane L of a 32-lane group always reads bank L: 16-byte LDS stores
+            if (tid < 256) {
+                const int r = tid;
+                const uint32_t vh = DYN ? pre_vh : g_tables[OFF_HI + (VAR - 6) * HI_ROWS + 256 + r];
+                const uint32_t vl = DYN ? pre_vl : g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + r];
                 const u32x4 h4 = {vh, vh, vh, vh}, l4 = {vl, vl, vl, vl};
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -496,22 +511,44 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const uint32_t lastmask = (W & 31) ? ((1u << (W & 31)) - 1u) : 0xffffffffu;
     const int nbm = NB - 1;
 
-    for (int seg = blockIdx.x; seg < n * segs_per_frame; seg += gridDim.x) {
-        const int f = seg / segs_per_frame, sidx = seg - f * segs_per_frame;
-        const int r0 = sidx * seg_rows, r1 = min(H, r0 + seg_rows);
-        const uint8_t* frame = frames + (size_t)f * H * W * 3;
-        uint8_t* out = masks + (size_t)f * H * W;
+    // the segment being processed: (frame, rows [r0, r1)); the lambdas below see it by reference
+    __shared__ int q_ids[2];         // work queue: the workgroup's next two segments
+    bool dq_first = false;           // this pass is the first of a queue-fed segment
+    int dq_slot = 0;
+    int r0 = 0, r1 = 0;
+    const uint8_t* frame = frames;
+    uint8_t* out = masks;
+    auto seg_decode = [&](int seg, int& f, int& q0, int& q1) {
+        if (DYN && seg < n * big_segs) {
+            f = seg / big_segs;
+            q0 = (seg - f * big_segs) * big_rows;
+            q1 = q0 + big_rows;
+        } else {
+            if (DYN) seg -= n * big_segs;
+            f = seg / segs_per_frame;
+            q0 = (DYN ? big_segs * big_rows : 0) + (seg - f * segs_per_frame) * seg_rows;
+            q1 = min(H, q0 + seg_rows);
+        }
+    };
+    auto set_segment = [&](int seg) {
+        int f;
+        seg_decode(seg, f, r0, r1);
+        frame = frames + (size_t)f * H * W * 3;
+        out = masks + (size_t)f * H * W;
+    };
+    {
         // Unconditional, address-clamped loads: keeping them out of divergent control flow lets the
         // compiler wait with an exact vmcnt(N) instead of vmcnt(0).
-        auto load = [&](int a, Px16& dst) {
+        auto load_from = [&](const uint8_t* fr, int a, int ylast /* last row worth fetching */, Px16& dst) {
             int y = a + trow;
-            y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            y = y < 0 ? 0 : (y > ylast ? ylast : y);
             // plain (cached) loads: each 128-byte line is touched by three dwordx4 instructions of the
             // wave (48-byte lane stride); non-temporal loads refetch it and measured 25 % slower
             // 32-bit offsets from a uniform base (full-rate 24-bit multiplies; a frame is < 4 GiB)
-            const u32x4* p = (const u32x4*)(frame + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tgc) * 3u);
+            const u32x4* p = (const u32x4*)(fr + (__umul24((uint32_t)y, (uint32_t)W) + 16u * (uint32_t)tgc) * 3u);
             dst.q0 = p[0]; dst.q1 = p[1]; dst.q2 = p[2];
         };
+        auto load = [&](int a, Px16& dst) { load_from(frame, a, H - 1, dst); };
         // DMA mode: request the rows [a, a + RC) of the frame into staging buffer `slot` (wave w takes pieces w, w + 16, ...)
         auto issue = [&](int a, int slot) {
             const long row0 = (long)a * W * 3;
@@ -555,6 +592,11 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                     ((uint16_t*)raw)[((y + 4 * NB) & nbm) * wpr * 2 + tg] = (uint16_t)bits;
                 }
             }
+            // work queue (round 5, see below): in a segment's first pass thread 0 requests the segment after next HERE -- behind
+            // the in-range test, where the register pressure peaks -- and hands it on behind the wait in front of the store,
+            // two barriers later: by then the atomic has long returned, and its register is live only over the two light steps
+            uint32_t dq_pend = 0;
+            if (DYN && dq_first && tid == 0) dq_pend = __hip_atomic_fetch_add(wq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lds_barrier();
             // ---- (2) rows [a-1, a+RC-2]: 3x3 dilation, then the horizontal part of the erosion.
             //      Pixels outside the image are neutral (never win): 0 for the dilation, 1 for the erosion.
@@ -592,6 +634,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             // before the store is issued, costs nothing: the only store in flight is one pass old.
             if (PD > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (PD - 1)));  // vmcnt(3*(PD-1)), others untouched
             if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next pass's rows have landed (this wave's pieces); the store below is younger
+            if (DYN && dq_first && tid == 0) q_ids[dq_slot] = (int)(dq_pend + gridDim.x);   // every thread read this slot at least two barriers ago
             {
                 const int y = a - 2 + trow;
                 if (active && y >= r0 && y < r1) {
@@ -614,6 +657,84 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             // any wave reads the staging buffer
             if (DMA) { asm volatile("s_barrier" ::: "memory"); dma_slot ^= 1; }
         };
+        // ---- round 5 (experiment, MELF_FUSED_DYN=N; off by default): the launch's segments come from a work queue (wq) ----
+        // Under the static split the two workgroups of a CU finish 25 % apart (oldest-first arbitration; profiles/r04/
+        // fused_workgroup_clock.txt) and the launch's last quarter runs with half its workgroups; a bare stream of this traffic
+        // mix WITHOUT prefetch gains 9 % from a dynamic split at 1080p sizes (tools/ubench/stream_dyn.hip) -- this kernel does
+        // not (see launch_lut_t): its lone workgroups keep two passes in flight.  Here: the first segment of a workgroup is its
+        // block index (no round trip before the first loads), every further one comes from an atomic counter, requested a
+        // whole segment before it is needed (thread 0, result handed on through LDS behind the passes' barriers), and the
+        // register prefetch runs ACROSS segment boundaries: the first rows of the next segment are in flight while the last
+        // pass of this one is processed (more, smaller segments under the static split lost exactly there: every segment start
+        // refilled the pipeline).  PD == 1: the load cursor is one pass ahead, i.e. in this segment or the next.
+        static_assert(!DYN || PD == 1, "the work-queue loop is written for one pass of register prefetch");
+        if constexpr (DYN) {
+            {
+                const int total = n * (big_segs + segs_per_frame);
+                uint32_t pend = 0;
+                if (tid == 0) pend = __hip_atomic_fetch_add(wq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                set_segment(blockIdx.x);
+                int a = r0 - 2, nxt = total;
+                // The load cursor is exactly one pass ahead of (frame, a): the same segment's next rows, or the first rows of
+                // segment `nxt` (no state of its own: scalar registers are what this launch shape is short of)
+                auto load_ahead = [&](Px16& dst) {
+                    const int na = a + RC;
+                    // rows beyond the segment's last halo row are not fetched again (the clamp makes them repeats of that row)
+                    if (na < r1 + 2) {
+                        load_from(frame, na, min(r1 + 1, H - 1), dst);
+                    } else if (nxt < total) {   // uniform
+                        int f2, q0, q1;
+                        seg_decode(nxt, f2, q0, q1);
+                        load_from(frames + (size_t)f2 * H * W * 3, q0 - 2, min(q1 + 1, H - 1), dst);
+                    }
+                };
+                Px16 pbuf[2];
+                load_from(frame, a, min(r1 + 1, H - 1), pbuf[0]);
+                fill_tables();
+                if (tid == 0) q_ids[1] = (int)(pend + gridDim.x);
+                __syncthreads();
+                FSTAMP(1);
+                nxt = q_ids[1];
+                dq_first = true;     // segment k's first pass requests segment k + 2 into q_ids[k & 1] (pass())
+                dq_slot = 0;
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first pass's rows (see pass())
+                for (;;) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        load_ahead(pbuf[q ^ 1]);
+                        pass(a, pbuf[q]);
+#ifdef MELF_FUSED_STAMP
+                        if (fstamp_passes++ == 0) FSTAMP(2);
+#endif
+                        dq_first = false;
+                        a += RC;
+                        if (a >= r1 + 2) {   // next segment
+                            lds_barrier();
+                            if (nxt >= total) goto queue_empty;
+                            set_segment(nxt);
+                            dq_slot ^= 1;
+                            nxt = q_ids[dq_slot ^ 1];
+                            a = r0 - 2;
+                            dq_first = true;
+                        }
+                    }
+                }
+            queue_empty:
+                // the launch's last workgroup leaves the queue zeroed for the launch that gets this slot next
+                if (tid == 0) {
+                    const uint32_t done = __hip_atomic_fetch_add(wq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (done == gridDim.x - 1) {
+                        __hip_atomic_store(wq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(wq + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                FSTAMP(3);
+                return;
+            }
+        }
+    if constexpr (!DYN)
+    for (int seg = blockIdx.x; seg < n * segs_per_frame; seg += gridDim.x) {
+        set_segment(seg);
         int a = r0 - 2;
         const int aend = r1 + 2;
         if constexpr (DMA) {
@@ -684,6 +805,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
         }
         lds_barrier();
     }
+    }
     FSTAMP(3);
 }
 
@@ -706,7 +828,7 @@ void fused_mask_timing_events(hipEvent_t start, hipEvent_t stop) { g_fused_ev_st
 
 template <int V, int T, int PF, int WPS>
 static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
-                         const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
+                         uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
     const int G16 = W >> 4, wpr = (W + 31) >> 5;
     int RC = T / G16 < FUSED_MAX_RC ? T / G16 : FUSED_MAX_RC;
@@ -730,8 +852,47 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     int seg_rows = (H + segs - 1) / segs;
     if (seg_rows < 32) seg_rows = H < 32 ? H : 32;
     segs = (H + seg_rows - 1) / seg_rows;
-    const long total = (long)n * segs;
-    const int grid = (int)(total < target ? total : target);
+    // Work queue (PD == 1 launches; MELF_FUSED_DYN = segments per workgroup aimed at, 0 = the static split; MELF_FUSED_GRID =
+    // workgroups, for tests that want many segments per workgroup on small inputs): segments of P whole passes including the
+    // 4 halo rows a segment loads beyond its own, so that no pass is half empty; used when it gives some workgroup a second
+    // segment, otherwise the static split above (one segment or none per workgroup either way)
+    // Measured (profiles/r05/fused_work_queue_ab.txt): no gain.  Config 2 0.0643-0.0668 ms against 0.0657-0.0662 for the static
+    // split, config 5 0.769-0.828 against 0.740-0.748: with one pass of register prefetch a workgroup that is alone on its CU
+    // still saturates its share of HBM, so the early finishers cost nothing, and the queue's segments pay their halo rows.
+    // The default stays the static split; MELF_FUSED_DYN=N switches the queue on (tests keep it honest).
+    const int dyn = PF == 1 ? (getenv("MELF_FUSED_DYN") ? atoi(getenv("MELF_FUSED_DYN")) : 0) : 0;
+    const int grid_cap = getenv("MELF_FUSED_GRID") ? std::max(1, atoi(getenv("MELF_FUSED_GRID"))) : target;
+    const int wgs = std::min(target, grid_cap);
+    // MELF_FUSED_BIG = percent of a frame's rows dealt as one big first segment per workgroup (the queue then hands out the rest
+    // in small ones: the halo rows of small segments are paid only where balancing needs them); 0 = small segments only
+    const int big_pct = getenv("MELF_FUSED_BIG") ? std::min(95, std::max(0, atoi(getenv("MELF_FUSED_BIG")))) : 0;
+    uint32_t* wq = nullptr;
+    int big_segs = 0, big_rows = 0;
+    if (dyn > 0) {
+        int Hs = H;   // rows dealt as small segments
+        if (big_pct > 0 && n > 0) {
+            big_segs = (wgs + n - 1) / n;                                      // every workgroup's first segment is a big one
+            int Pb = (int)(((double)H * big_pct / 100.0 / big_segs + 4.0) / RC + 0.5);
+            big_rows = Pb * RC - 4;
+            if (big_rows < RC || big_segs * big_rows > H - RC) { big_segs = 0; big_rows = 0; }
+            else Hs = H - big_segs * big_rows;
+        }
+        const double rows_aimed = (double)n * Hs / ((double)wgs * dyn);
+        int P = (int)((rows_aimed + 4.0) / RC + 0.5);
+        if (P * RC - 4 < RC) P = (2 * RC + 3) / RC;                           // at least RC rows of its own
+        const int dr0 = std::min(P * RC - 4, Hs), ds = (Hs + dr0 - 1) / dr0;
+        const int dr = (Hs + ds - 1) / ds;                                     // evenly: no short last segment
+        if ((long)n * (ds + big_segs) > wgs) {
+            seg_rows = dr;
+            segs = ds;
+            static std::atomic<unsigned> slot{0};
+            wq = d_tables + FUSED_TABLE_DWORDS + 16 * (slot.fetch_add(1) % FUSED_QUEUE_SLOTS);
+        } else {
+            big_segs = big_rows = 0;
+        }
+    }
+    const long total = (long)n * (segs + big_segs);
+    const int grid = (int)std::min<long>(total, wgs);
     const size_t shmem = (size_t)(2 * NB * wpr) * sizeof(uint32_t) + dma_bytes;
     static bool attr_set[64] = {false};  // per device (several contexts on several GPUs may live in one process)
     int dev = 0;
@@ -747,15 +908,28 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     }
     // timing events (optional, set by the caller through fused_mask_timing_events): the dispatch's own start / stop stamps,
     // no event-record packets in the queue around the kernel
+    const int ps = plain_store | ((getenv("MELF_FUSED_PRIO") ? atoi(getenv("MELF_FUSED_PRIO")) : 0) << 8);
+    if constexpr (PF == 1) {
+        if (wq) {
+            static bool dyn_attr_set[64] = {false};
+            if (dev >= 0 && dev < 64 && !dyn_attr_set[dev]) {
+                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+                dyn_attr_set[dev] = true;
+            }
+            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, true>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+                                  n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, wq, big_segs, big_rows);
+            g_fused_ev_start = g_fused_ev_stop = nullptr;
+            return;
+        }
+    }
     hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
-                          n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB,
-                          plain_store | ((getenv("MELF_FUSED_PRIO") ? atoi(getenv("MELF_FUSED_PRIO")) : 0) << 8), RC);
+                          n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
     g_fused_ev_start = g_fused_ev_stop = nullptr;
 }
 
 template <int V>
 static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
-                         const uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
+                         uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
     if constexpr (V >= 5) {  // interval tables (64 KiB per workgroup); 5: timing-only twin of the same launch shapes
         switch (g_fused_config) {
@@ -788,7 +962,7 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
 // variant: 0/1/2 single sector r/g/b (bit tables), 3 generic, 4 generic with tie re-evaluation, 5 timing-only,
 //          6/7/8 single sector r/g/b with interval tables
 void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3],
-                           const int hi[3], const uint32_t* d_tables, int variant, uint8_t* d_masks,
+                           const int hi[3], uint32_t* d_tables, int variant, uint8_t* d_masks,
                            hipStream_t stream)
 {
     Bounds B;
@@ -808,6 +982,98 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
         case 8: launch_lut_v<8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         default: launch_lut_v<4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Measurement aid (bench.py's `stream_ceiling`; no pixel arithmetic, no caller in the product path): a BARE persistent stream
+// of the fused kernel's traffic mix over the caller's buffers -- 48 bytes in, 16 bytes out per thread and step, lane-contiguous
+// 16-byte loads, non-temporal stores, 1024-thread workgroups, two per CU like the kernel -- so that "what this part streams
+// for this mix" is measured in the same run, on the same buffers, as the kernel's own figure.  Two ways of dealing the
+// chunks (a chunk = one step of a workgroup = 48 KiB in, 16 KiB out): the static grid-stride split, and blocks of CH chunks
+// from a work queue (the first two blocks of a workgroup are static, every further one is requested a block ahead).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void stream_step(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t c, int tid)
+{
+    const u32x4* p = in + c * 3072 + tid;
+    const u32x4 a = p[0], b = p[1024], d = p[2048];
+    u32x4 o;
+    o.x = a.x ^ b.x ^ d.x; o.y = a.y ^ b.y ^ d.y; o.z = a.z ^ b.z ^ d.z; o.w = a.w ^ b.w ^ d.w;
+    __builtin_nontemporal_store(o, out + c * 1024 + tid);
+}
+
+// static split with the kernel's register prefetch: the next chunk's 48 bytes are requested before this chunk is stored
+__global__ __launch_bounds__(1024) void k_stream_probe_prefetch(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t nchunks)
+{
+    const int tid = threadIdx.x;
+    size_t c = blockIdx.x;
+    if (c >= nchunks) return;
+    const u32x4* p = in + c * 3072 + tid;
+    u32x4 a = p[0], b = p[1024], d = p[2048];
+    for (;;) {
+        const size_t cn = c + gridDim.x;
+        const bool more = cn < nchunks;
+        const u32x4* pn = in + (more ? cn : c) * 3072 + tid;   // unconditional (address-clamped) loads: exact vmcnt waits
+        const u32x4 a2 = pn[0], b2 = pn[1024], d2 = pn[2048];
+        u32x4 o;
+        o.x = a.x ^ b.x ^ d.x; o.y = a.y ^ b.y ^ d.y; o.z = a.z ^ b.z ^ d.z; o.w = a.w ^ b.w ^ d.w;
+        __builtin_nontemporal_store(o, out + c * 1024 + tid);
+        if (!more) break;
+        a = a2; b = b2; d = d2;
+        c = cn;
+    }
+}
+
+template <bool DYN>
+__global__ __launch_bounds__(1024) void k_stream_probe(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t nchunks, uint32_t CH,
+                                                       uint32_t* __restrict__ wq)
+{
+    const int tid = threadIdx.x;
+    if (!DYN) {
+        for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) stream_step(in, out, c, tid);
+        return;
+    }
+    __shared__ uint32_t nxt[2];
+    const uint32_t nblocks = (nchunks + CH - 1) / CH;
+    if (tid == 0) { nxt[0] = blockIdx.x; nxt[1] = blockIdx.x + gridDim.x; }
+    __syncthreads();
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t b = nxt[it & 1];
+        if (b >= nblocks) break;
+        __syncthreads();   // every thread has read nxt[it & 1]
+        uint32_t v = 0;
+        if (tid == 0) v = __hip_atomic_fetch_add(wq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the block after next
+        const size_t c0 = (size_t)b * CH, c1 = c0 + CH < nchunks ? c0 + CH : nchunks;
+        for (size_t c = c0; c < c1; ++c) stream_step(in, out, c, tid);
+        if (tid == 0) nxt[it & 1] = v + 2u * gridDim.x;   // read two iterations on, behind the next iteration's barrier
+    }
+    if (tid == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(wq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(wq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(wq + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// chunks_per_block = 0: static split; < 0: static split with one chunk of register prefetch; > 0: work queue.  Streams floor(in_bytes / 48 KiB) chunks; returns the bytes moved (in + out).
+size_t launch_stream_probe(const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, uint32_t* d_tables, hipStream_t stream,
+                           hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const uint32_t nchunks = (uint32_t)std::min<size_t>(in_bytes / (48 * 1024), 0x7fffffffu);
+    if (!nchunks) return 0;
+    const int grid = (int)std::min<uint32_t>(512u, nchunks);
+    if (chunks_per_block < 0) {
+        hipExtLaunchKernelGGL(k_stream_probe_prefetch, dim3(grid), dim3(1024), 0, stream, ev_start, ev_stop, 0, (const u32x4*)d_in, (u32x4*)d_out, nchunks);
+    } else if (chunks_per_block > 0) {
+        static std::atomic<unsigned> slot{0};
+        uint32_t* wq = d_tables + FUSED_TABLE_DWORDS + 16 * (slot.fetch_add(1) % FUSED_QUEUE_SLOTS);
+        hipExtLaunchKernelGGL((k_stream_probe<true>), dim3(grid), dim3(1024), 0, stream, ev_start, ev_stop, 0, (const u32x4*)d_in, (u32x4*)d_out, nchunks,
+                              (uint32_t)chunks_per_block, wq);
+    } else {
+        hipExtLaunchKernelGGL((k_stream_probe<false>), dim3(grid), dim3(1024), 0, stream, ev_start, ev_stop, 0, (const u32x4*)d_in, (u32x4*)d_out, nchunks, 0u,
+                              (uint32_t*)nullptr);
+    }
+    return (size_t)nchunks * 64 * 1024;
 }
 
 void launch_fused_mask(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3], const int hi[3],

@@ -1494,7 +1494,13 @@ template <class T>
 static hipError_t grow_dev(T** p, size_t* cap, size_t need)
 {
     if (need <= *cap) return hipSuccess;
-    if (*p) (void)hipFree(*p);
+    if (*p) {
+        // With several chunks (and up to three calls) in flight the kernels of an older chunk may still read this workspace:
+        // the caller has only waited for the slot's UPLOAD event.  hipFree happens to synchronise, but nothing promises it
+        // (melf_api.hip's grow() does the same); growth is rare.
+        (void)hipDeviceSynchronize();
+        (void)hipFree(*p);
+    }
     *p = nullptr; *cap = 0;
     const size_t want = need + need / 4;
     hipError_t e = hipMalloc((void**)p, want * sizeof(T));

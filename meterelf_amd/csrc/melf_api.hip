@@ -55,7 +55,7 @@ extern "C" int melf_device_count(int* count)
 extern "C" const char* melf_kernel_name(int k)
 {
     static const char* names[MELF_K_COUNT] = {"k_lplane", "k_match", "k_dials", "k_fused_mask", "k_bgr2hls",
-                                               "k_jpeg_huff", "k_jpeg_idct", "k_jpeg_color"};
+                                               "k_jpeg_huff", "k_jpeg_idct", "k_jpeg_color", "k_stream_probe"};
     return (k >= 0 && k < MELF_K_COUNT) ? names[k] : "?";
 }
 
@@ -528,7 +528,7 @@ static int ensure_fused_tables(melf_ctx* c)
     if (c->d_fused_tables) return MELF_SUCCESS;
     const melf_params& P = c->P;
     uint32_t* tables = nullptr;
-    HIP_TRY(hipMalloc((void**)&tables, (size_t)FUSED_TABLE_DWORDS * 4));
+    HIP_TRY(hipMalloc((void**)&tables, (size_t)FUSED_BUF_DWORDS * 4));
     launch_build_fused_tables(P.hue_shift, P.needle_lo, P.needle_hi, tables, c->stream);
     uint32_t namb = 0, active = 0, noniv[3] = {1, 1, 1};
     hipError_t e = hipGetLastError();
@@ -564,7 +564,7 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
         return fail(MELF_ERR_NO_DEVICE, "no HIP device: libmeterelf_hip has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(MELF_ERR_INVALID, "bad device index");
     HIP_TRY(hipSetDevice(device));
-    pool_set_devices(ndev);   // the host pools share the cores out over the visible devices
+    pool_note_device(device);   // the host pools share the cores out over the devices this process has contexts on
     std::vector<uint8_t> host;
     if (blob_on_device) {
         if (!blob || blob_bytes < sizeof(BlobHeader)) return fail(MELF_ERR_INVALID, "blob too small");
@@ -1270,6 +1270,25 @@ extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int
             launch_fused_mask(fin, m, H, W, c->P.hue_shift, c->P.needle_lo, c->P.needle_hi, fout, st);
         }
     }
+    HIP_TRY(hipGetLastError());
+    return MELF_SUCCESS;
+}
+
+extern "C" int melf_stream_probe_dev(melf_ctx* c, const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, void* stream_)
+{
+    if (!c || !d_in || !d_out) return fail(MELF_ERR_INVALID, "bad argument");
+    if ((((size_t)d_in | (size_t)d_out) & 15) != 0) return fail(MELF_ERR_INVALID, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = ensure_fused_tables(c)) return rc;   // the work queues live behind the tables
+    TimedEvent ev;
+    ev.kernel = MELF_K_STREAM_PROBE;
+    ev.start = ev.stop = nullptr;
+    if (c->profiling == 1) {
+        HIP_TRY(hipEventCreateWithFlags(&ev.start, hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&ev.stop, hipEventDisableSystemFence));
+    }
+    launch_stream_probe(d_in, in_bytes, d_out, chunks_per_block, c->d_fused_tables, (hipStream_t)stream_, ev.start, ev.stop);
+    if (ev.start) c->events.push_back(ev);
     HIP_TRY(hipGetLastError());
     return MELF_SUCCESS;
 }

@@ -120,6 +120,11 @@ void launch_fused_mask(const uint8_t* d_frames, int n, int H, int W, int hue_shi
                        const int hi[3], uint8_t* d_masks, hipStream_t stream);
 // table-driven fast path of K1b (W % 16 == 0, 16-byte aligned buffers)
 constexpr int FUSED_TABLE_DWORDS = 3 * 65536 * 2 / 32 + 65536 / 32 + 3 * 65536 / 32 + 3 * (512 * 512 / 32) + 3 * (256 + 512) + 16;
+// behind the tables: the work queues of the launches in flight (round 5: a launch's persistent workgroups take their segments
+// from a counter), FUSED_QUEUE_SLOTS of them in rotation, one 64-byte line each: {next segment, workgroups done}; a launch's
+// last workgroup leaves its slot zeroed
+constexpr int FUSED_QUEUE_SLOTS = 64, FUSED_QUEUE_DWORDS = FUSED_QUEUE_SLOTS * 16;
+constexpr int FUSED_BUF_DWORDS = FUSED_TABLE_DWORDS + FUSED_QUEUE_DWORDS;
 int fused_tables_count_offset();
 int fused_tables_active_offset();
 int fused_tables_noniv_offset();
@@ -128,8 +133,12 @@ bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W);
 // the next launch_fused_mask_lut of this thread carries these events as its dispatch's own start / stop stamps
 void fused_mask_timing_events(hipEvent_t start, hipEvent_t stop);
 void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3],
-                           const int hi[3], const uint32_t* d_tables, int variant, uint8_t* d_masks,
+                           const int hi[3], uint32_t* d_tables /* FUSED_BUF_DWORDS: tables + work queues */, int variant, uint8_t* d_masks,
                            hipStream_t stream);
+
+// measurement aid: bare 3:1 stream over the caller's buffers (bench.py's stream_ceiling); returns the bytes moved
+size_t launch_stream_probe(const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, uint32_t* d_tables, hipStream_t stream,
+                           hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // ---- calibration stage kernels ------------------------------------------------
 void launch_aligned_average(const uint8_t* d_frames, int n, size_t frame_stride, int row_stride, int x0, int y0, int rows,

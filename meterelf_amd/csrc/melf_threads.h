@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <sched.h>
 #include <thread>
 #include <unistd.h>
 #include <vector>
@@ -14,9 +15,9 @@ namespace melf {
 
 class WorkerPool {
 public:
-    explicit WorkerPool(int nthreads) : pid_(getpid())
+    explicit WorkerPool(int nthreads) : pid_(getpid()), active_(nthreads)
     {
-        for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this]() { loop(); });
+        for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this, t]() { loop(t); });
     }
     ~WorkerPool()
     {
@@ -28,7 +29,10 @@ public:
         cv_.notify_all();
         for (auto& w : workers_) w.join();
     }
-    int size() const { return (int)workers_.size(); }
+    // workers that take part in a loop (the others sleep through it): the pool is created with the most threads a device's
+    // share of the cores can ever be and uses as many of them as that share is NOW (pool_of)
+    int size() const { return active_.load(); }
+    void set_active(int n) { active_.store(n < 0 ? 0 : (n > (int)workers_.size() ? (int)workers_.size() : n)); }
 
     // fn(i) for i in [0, n): indices are handed out in small blocks; the caller works too and returns when all are done.
     // fn must not throw: an exception on a worker would terminate the process, one on the caller would unwind past
@@ -37,14 +41,16 @@ public:
     {
         if (n <= 0) return;
         // sequential when the loop is short, and in a forked child (the worker threads exist in the parent only)
-        if (workers_.empty() || n < 32 || getpid() != pid_) { for (int i = 0; i < n; ++i) fn(i); return; }
+        const int act = active_.load();
+        if (act <= 0 || n < 32 || getpid() != pid_) { for (int i = 0; i < n; ++i) fn(i); return; }
         std::lock_guard<std::mutex> one_caller(run_m_);  // contexts on different host threads share the pool
         {
             std::lock_guard<std::mutex> lk(m_);
             fn_ = &fn;
             n_ = n;
             next_.store(0);
-            pending_ = (int)workers_.size();
+            pending_ = act;
+            run_active_ = act;
             ++generation_;
         }
         cv_.notify_all();
@@ -65,7 +71,7 @@ private:
             for (int i = i0; i < i1; ++i) (*fn_)(i);
         }
     }
-    void loop()
+    void loop(int idx)
     {
         uint64_t seen = 0;
         for (;;) {
@@ -74,6 +80,7 @@ private:
                 cv_.wait(lk, [&]() { return generation_ != seen; });
                 seen = generation_;
                 if (stop_) return;
+                if (idx >= run_active_) continue;   // not this loop's worker
             }
             drain();
             {
@@ -87,7 +94,8 @@ private:
     const pid_t pid_;
     std::condition_variable cv_, done_;
     const std::function<void(int)>* fn_ = nullptr;
-    int n_ = 0, pending_ = 0;
+    int n_ = 0, pending_ = 0, run_active_ = 0;
+    std::atomic<int> active_;
     std::atomic<int> next_{0};
     uint64_t generation_ = 0;
     bool stop_ = false;
@@ -97,29 +105,35 @@ private:
 // with one pool per process the devices' parallel loops would queue behind each other), created on first use and
 // deliberately never destroyed: a destructor that joins the workers would hang exit() in a forked child (the threads exist
 // in the parent only), and at process exit the threads go away with the process anyway.  The entry points set the calling
-// thread's device (pool_use_device) before their first parallel loop; the host's cores are shared out over the visible
-// devices (pool_set_devices, called by melf_ctx_create).
+// thread's device (pool_use_device) before their first parallel loop.  The cores this process may run on (its affinity
+// mask, not the machine's core count) are shared out over the devices the process has CONTEXTS on (pool_note_device, called
+// by melf_ctx_create) -- not over the visible devices: a one-GPU rank on an eight-GPU node keeps its whole share (round 4
+// divided by the visible devices: 2 I/O threads instead of 12 there).  The share is re-read at every loop, so a process
+// that opens its second device later narrows the first device's loops from then on.
 inline thread_local int tl_pool_device = 0;
-inline std::atomic<int> g_pool_devices{1};
+inline std::atomic<uint64_t> g_pool_device_mask{0};
 inline void pool_use_device(int device) { tl_pool_device = device >= 0 ? device & 63 : 0; }
-inline void pool_set_devices(int ndev)
+inline void pool_note_device(int device) { g_pool_device_mask.fetch_or(1ull << (device & 63)); }
+inline int pool_devices() { const int n = __builtin_popcountll(g_pool_device_mask.load()); return n < 1 ? 1 : n; }
+inline unsigned pool_cores()
 {
-    int cur = g_pool_devices.load();
-    while (ndev > cur && !g_pool_devices.compare_exchange_weak(cur, ndev)) {}
+    static const unsigned n = []() -> unsigned {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (unsigned)CPU_COUNT(&set);
+        return std::max<unsigned>(std::thread::hardware_concurrency(), 2u);
+    }();
+    return n;
 }
-inline WorkerPool& pool_of(WorkerPool** pools, std::mutex& m, const char* env, unsigned divisor, unsigned lo, unsigned hi)
+inline WorkerPool& pool_of(WorkerPool** pools, std::mutex& m, const char* env, unsigned lo, unsigned hi)
 {
     std::lock_guard<std::mutex> lk(m);
     WorkerPool*& p = pools[tl_pool_device];
-    if (!p) {
-        int n;
-        if (getenv(env)) {
-            n = std::max(0, atoi(getenv(env)) - 1);
-        } else {
-            const unsigned share = std::max<unsigned>(std::thread::hardware_concurrency(), 2u) / (divisor * (unsigned)std::max(1, g_pool_devices.load()));
-            n = (int)std::min<unsigned>(std::max<unsigned>(share, lo + 1u) - 1u, hi);
-        }
-        p = new WorkerPool(n);
+    const bool fixed = getenv(env) != nullptr;
+    if (!p) p = new WorkerPool(fixed ? std::max(0, atoi(getenv(env)) - 1) : (int)hi);
+    if (!fixed) {
+        const unsigned share = std::max<unsigned>(pool_cores(), 2u) / (unsigned)pool_devices();
+        p->set_active((int)std::min<unsigned>(std::max<unsigned>(share, lo + 1u) - 1u, hi));
     }
     return *p;
 }
@@ -127,7 +141,7 @@ inline WorkerPool& host_pool()
 {
     static WorkerPool* pools[64] = {};
     static std::mutex m;
-    return pool_of(pools, m, "MELF_HOST_THREADS", 1, 3, 15);   // the device's share of the cores, 4 .. 16 threads with the caller
+    return pool_of(pools, m, "MELF_HOST_THREADS", 3, 15);   // the device's share of the cores, 4 .. 16 threads with the caller
 }
 
 // A second pool for the read stage of melf_jpeg_process_files: with several calls in flight the next call's files are read
@@ -140,7 +154,7 @@ inline WorkerPool& io_pool()
 {
     static WorkerPool* pools[64] = {};
     static std::mutex m;
-    return pool_of(pools, m, "MELF_IO_THREADS", 1, 1, 11);
+    return pool_of(pools, m, "MELF_IO_THREADS", 1, 11);
 }
 
 }  // namespace melf

@@ -207,6 +207,33 @@ def test_fused_mask_other_bounds(env, tmp_path, needle):
         reader.close()
 
 
+@pytest.mark.parametrize('grid,dyn,big', [(1, 3, 0), (2, 1, 60), (3, 7, 0), (5, 2, 70), (16, 4, 50), (4, 3, 30)])
+def test_fused_mask_work_queue(env, monkeypatch, grid, dyn, big):
+    """Round 5: the fused launch's persistent workgroups take their segments from a work queue (k_fused_mask_lut<.., DYN>), with
+    the register prefetch running across segment boundaries.  Production shapes reach it with 512 workgroups; here
+    MELF_FUSED_GRID leaves a few workgroups for small inputs, so that every one of them walks through many segments
+    (whole-frame segments, several segments per frame, a short last segment, more workgroups than segments' first round;
+    MELF_FUSED_BIG: one big first segment per workgroup, the rest of the rows in small ones behind them):
+    masks equal to the oracle's AND to the static split's (MELF_FUSED_DYN=0), twice in a row (the queue slot is left zeroed)."""
+    from oracle import pyoracle as po
+    ctx = env['sample-images1']['reader'].ctx
+    p = ctx.params
+    rng = np.random.default_rng(100 * grid + dyn)
+    for (n, H, W) in ((6, 200, 160), (3, 640, 480), (2, 333, 1920), (9, 37, 64), (5, 101, 48), (2, 1080, 1920)):
+        frames = _blobby(rng, n, H, W)
+        monkeypatch.setenv('MELF_FUSED_DYN', '0')
+        monkeypatch.delenv('MELF_FUSED_GRID', raising=False)
+        static = ctx.hls_inrange_close(frames)
+        monkeypatch.setenv('MELF_FUSED_DYN', str(dyn))
+        monkeypatch.setenv('MELF_FUSED_GRID', str(grid))
+        monkeypatch.setenv('MELF_FUSED_BIG', str(big))
+        for rep in range(2):
+            got = ctx.hls_inrange_close(frames)
+            assert np.array_equal(got, static), (n, H, W, rep, np.argwhere(got != static)[:5])
+        for f in range(n):
+            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
+
+
 def test_fused_mask_lds_dma_launch_shape(env, monkeypatch):
     """MELF_FUSED_CONFIG=6 (round 4's experiment: pixel rows through LDS-DMA into two staging buffers, one workgroup per CU)
     must stay what it is measured as: the same masks as the oracle's, on an aligned and on a narrow shape and at 1080p."""

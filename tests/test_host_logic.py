@@ -456,9 +456,28 @@ def test_context_cache_key_and_fork_hook(monkeypatch):
     monkeypatch.setitem(_api._idle_readers, b'x', r)
     _api._forget_contexts_in_child()
     assert not _api._idle_readers and r.ctx._h is None and r._crop_ctx[(1, 1)]._h is None
+    # unset: ONE device (LOCAL_RANK's under torchrun, else 0) -- a rank of a process-per-GPU job never opens its neighbours' GPUs
+    monkeypatch.delenv('METERELF_DEVICES', raising=False)
+    monkeypatch.delenv('LOCAL_RANK', raising=False)
+    assert _api._device_list() == [0]
+    monkeypatch.setenv('LOCAL_RANK', '5')
+    assert _api._device_list() == [5 % max(1, _hip.device_count())]
+    monkeypatch.setenv('METERELF_DEVICES', 'all')
     assert _api._device_list() == list(range(max(1, _hip.device_count())))
     monkeypatch.setenv('METERELF_DEVICES', '2, 0,0')
     assert _api._device_list() == [2, 0, 0]
+    # the switch-interval override is counted: overlapping fan-outs share it, the last one out restores
+    import sys
+    before = sys.getswitchinterval()
+    monkeypatch.setenv('METERELF_SWITCH_INTERVAL', '0.0004')
+    assert _api._switch_interval_enter() and _api._switch_interval_enter()
+    assert abs(sys.getswitchinterval() - 0.0004) < 1e-9
+    _api._switch_interval_exit()
+    assert abs(sys.getswitchinterval() - 0.0004) < 1e-9      # one generator still running
+    _api._switch_interval_exit()
+    assert sys.getswitchinterval() == before
+    monkeypatch.setenv('METERELF_SWITCH_INTERVAL', '0')
+    assert not _api._switch_interval_enter() and sys.getswitchinterval() == before
 
 
 def test_no_gpu_means_loud_failure():
@@ -626,3 +645,16 @@ def test_import_only_and_run_as_script():
     with patch.object(_main, 'main') as main_func_mock:
         runpy.run_module(meterelf_amd.__name__, run_name='__main__')
         main_func_mock.assert_called_with()
+
+
+def test_path_table_addresses_and_embedded_nul():
+    """The file-name table the C entry points get: one NUL-terminated string per name; a name with an embedded NUL is refused
+    the way open() refuses it (a C string would end there and silently name another file)."""
+    import ctypes as C
+    names = ['a.jpg', 'dir/b c.jpg', 'ü.jpg']
+    (addr, keep) = _hip._path_table(names)
+    assert [C.string_at(int(a)) for a in addr] == [os.fsencode(n) for n in names]
+    (addr, keep) = _hip._path_table([b'x.jpg', 'y.jpg'])
+    assert [C.string_at(int(a)) for a in addr] == [b'x.jpg', b'y.jpg']
+    with pytest.raises(ValueError, match='embedded null byte'):
+        _hip._path_table(['good.jpg\0x', 'other.jpg'])
