@@ -763,19 +763,54 @@ def jpeg_block(ctx, sample_dir, H, W):
     names = [jfiles[i % len(jfiles)] for i in range(64 * 1024)]  # a long list: the per-call costs (params, calibration blob) stop mattering
     dev = os.environ.get('METERELF_DEVICES')
     os.environ['METERELF_DEVICES'] = '%d' % ctx.device   # ONE context on this rank's GPU, whatever the caller's environment says
+    from meterelf_amd import _api
+
+    def host_block(stats, seconds):
+        """Per-chunk host times of a get_meter_values run: the library's stages (read / turn / enqueue / GPU wait, per device
+        pipeline) and the Python side (begin, blocked in end, record conversion), plus what the pools were sized from."""
+        chunks = max(stats['chunks'], 1)
+        lib = stats['library']
+        out = {'os_cpu_count': os.cpu_count(), 'affinity_cores': len(os.sched_getaffinity(0)), 'chunks': stats['chunks'],
+               'python_ms_per_chunk': {'begin_marshal': round(stats['s_begin'] / chunks * 1e3, 3), 'blocked_in_end': round(stats['s_end_wait'] / chunks * 1e3, 3),
+                                       'records_to_objects': round(stats['s_convert'] / chunks * 1e3, 3)},
+               'wall_ms_per_chunk': round(seconds / chunks * 1e3, 3)}
+        if lib:
+            calls = max(sum(x['calls'] for x in lib), 1.0)
+            out['library_ms_per_chunk'] = {k[3:]: round(sum(x[k] for x in lib) / calls, 3) for k in ('ms_read', 'ms_turn_wait', 'ms_enqueue', 'ms_gpu_wait')}
+            out['io_threads'] = int(lib[0]['io_threads'])
+            out['host_threads'] = int(lib[0]['host_threads'])
+            out['pool_cores'] = int(lib[0]['cores'])
+            out['devices_in_process'] = int(lib[0]['devices_in_process'])
+            out['pipelines'] = len(lib)
+        return out
+
+    # what the file system allows the read stage: open() + close() alone, on the library's I/O pool (best of 5)
+    probe = min(_hip.files_open_probe(names[:1024], ctx.device) for _ in range(5))
+    open_probe = {'ms_per_1024_files': round(probe[0], 3), 'threads': probe[1],
+                  'what': 'open() + close() of 1024 of the files on the I/O pool, nothing read: the file system\'s floor under the read stage'}
     sum(1 for _ in get_meter_values(pfile, names[:2048]))  # warm-up: the context the API keeps between calls
+    _api.api_stats(reset=True)
     tg0 = time.perf_counter()
     n_api = sum(1 for r in get_meter_values(pfile, names) if r.error is None)
     tg = time.perf_counter() - tg0
+    host1 = host_block(_api.api_stats(reset=True), tg)
+    host1['open_close_probe'] = open_probe
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fp:
+            host1['cgroup_cpu_max'] = fp.read().strip()
+    except OSError:
+        pass
     release_cached_contexts()
     # the same over TWO contexts on this GPU (METERELF_DEVICES=0,0: the multi-device fan-out of the API -- one reader, one host
     # thread, one begin / end pipeline per entry -- exercised on the one GPU a rank has; on a node the entries are the node's GPUs)
     os.environ['METERELF_DEVICES'] = '%d,%d' % (ctx.device, ctx.device)
     try:
         sum(1 for _ in get_meter_values(pfile, names[:4096]))
+        _api.api_stats(reset=True)
         tg20 = time.perf_counter()
         n_api2 = sum(1 for r in get_meter_values(pfile, names) if r.error is None)
         tg2 = time.perf_counter() - tg20
+        host2 = host_block(_api.api_stats(reset=True), tg2)
     finally:
         if dev is None:
             os.environ.pop('METERELF_DEVICES', None)
@@ -785,10 +820,10 @@ def jpeg_block(ctx, sample_dir, H, W):
     return {'workload': '%d JPEG files (%d distinct %s fixtures, %.1f KB average) -> decode + full reading path, '
                         'file bytes in host memory to result records (melf_jpeg_process_batch, mean of 20 calls; the pointer table built once)' % (JB, len(blobs), sample_dir, sum(map(len, blobs)) / len(blobs) / 1024),
             'files_per_s': round(JB / tj, 1), 'ms_per_call': round(tj * 1e3, 3),
-            'get_meter_values': {'files_per_s': round(len(names) / tg, 1), 'files': len(names), 'values_read': n_api, 'devices': 1,
+            'get_meter_values': {'files_per_s': round(len(names) / tg, 1), 'files': len(names), 'values_read': n_api, 'devices': 1, 'host': host1,
                                  'what': 'meterelf_amd.get_meter_values(params.yml, file names): the reference API, files read '
                                          'from the page cache inside the library, MeterImageData objects out',
-                                 'two_contexts_on_this_gpu': {'files_per_s': round(len(names) / tg2, 1), 'values_read': n_api2,
+                                 'two_contexts_on_this_gpu': {'files_per_s': round(len(names) / tg2, 1), 'values_read': n_api2, 'host': host2,
                                                               'what': 'METERELF_DEVICES=d,d: the API\'s multi-device fan-out with both entries on this GPU '
                                                                       '(same host cores, same GPU: a functional figure, not a scaling one)'}},
             'kernel_ms_per_call': {k: round(ms, 4) for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},

@@ -252,6 +252,17 @@ int melf_jpeg_files_in_flight_max(void); /* the value the library was built with
 int melf_jpeg_process_files_begin(melf_ctx* ctx, const char* const* paths, int n, int32_t* H_used, int32_t* W_used,
                                   melf_result* out_host, int32_t* status);
 int melf_jpeg_process_files_end(melf_ctx* ctx);
+/* Where the _begin calls of this context spent their host time since the last reset (sums, milliseconds): out[0] calls,
+ * [1] files, [2] read stage (open / fstat / read / close / header parse on the I/O pool), [3] waiting for the call's turn at the
+ * context, [4] enqueueing (chunk layout, uploads, launches) until the context is handed to the next call, [5] waiting for the
+ * call's kernels and records; [6] threads of the read stage, [7] of the other host loops (the caller included), [8] cores the
+ * process may run on (affinity mask), [9] devices the process has contexts on (what the pools divide the cores by).
+ * Not while a _begin call is in flight. */
+/* Measurement aid: open() + close() of every path on the I/O pool of `device` (no context needed, nothing is read):
+ * milliseconds for the n files and the threads that took part -- what the file system allows the read stage. */
+int melf_files_open_probe(const char* const* paths, int n, int device, double* ms, int* threads);
+#define MELF_FILES_STATS_COUNT 10
+int melf_ctx_files_stats(melf_ctx* ctx, double out[MELF_FILES_STATS_COUNT], int reset);
 
 /* Promise that the frames handed to melf_process_batch_dev are complete in device memory at the time of each call (they
  * do not depend on work still pending on the call's stream -- e.g. frames that were uploaded or decoded earlier and

@@ -26,6 +26,7 @@ import os
 import queue
 import threading
 from concurrent.futures import ThreadPoolExecutor
+from time import perf_counter
 from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional
 
 from . import _debug, _hip, _params
@@ -137,6 +138,22 @@ def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
 
 _REAL_READER = MeterReader   # tests substitute MeterReader with a CPU stand-in: such readers are never cached
 
+# Where the Python side of get_meter_values spends its time, per device pipeline (bench.py's jpeg_decode.get_meter_values.host):
+# seconds summed over the chunks since the last api_stats(reset=True).  A few perf_counter() calls per 1024-file chunk.
+_stats_lock = threading.Lock()
+_stats = {'chunks': 0, 'files': 0, 's_begin': 0.0, 's_end_wait': 0.0, 's_convert': 0.0, 'library': []}
+
+
+def api_stats(reset: bool = True) -> dict:
+    """{'chunks', 'files', 's_begin' (marshalling + melf_jpeg_process_files_begin), 's_end_wait' (blocked in _end: the library
+    had not finished the chunk), 's_convert' (records -> MeterImageData objects), 'library': [melf_ctx_files_stats of every
+    context released since the last reset]}."""
+    with _stats_lock:
+        out = dict(_stats, library=list(_stats['library']))
+        if reset:
+            _stats.update({'chunks': 0, 'files': 0, 's_begin': 0.0, 's_end_wait': 0.0, 's_convert': 0.0, 'library': []})
+    return out
+
 
 def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode: bool, batch: int) -> Iterator[List[MeterImageData]]:
     """One device's pipeline: chunk lists in, one list of MeterImageData per chunk out, in order."""
@@ -155,6 +172,7 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
     # thread turns chunk k's records into Python objects and the consumer handles them.
     clean = False  # the generator ran to its end (or was closed between chunks with nothing in flight)
     DEPTH = _hip.FILES_IN_FLIGHT_MAX
+    local = {'chunks': 0, 'files': 0, 's_begin': 0.0, 's_end_wait': 0.0, 's_convert': 0.0}
 
     def _gpu_read(chunk: List[str]):
         if hasattr(reader, 'read_jpeg_paths_batch'):
@@ -171,7 +189,9 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
                 nxt = next(chunks, None)
                 if nxt is None:
                     return
+                t0 = perf_counter()
                 reader.read_jpeg_paths_begin(nxt)
+                local['s_begin'] += perf_counter() - t0
                 begun.append(nxt)
 
         chunk = next(chunks, None)
@@ -188,7 +208,9 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
                 if begun:
                     assert begun[0] is chunk
                     begun.pop(0)
+                    t0 = perf_counter()
                     raw = reader.read_jpeg_paths_end()
+                    local['s_end_wait'] += perf_counter() - t0
                     raw = (raw[0], raw[1].tolist())
                 else:
                     raw = _gpu_read(chunk)
@@ -198,6 +220,7 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
             else:
                 following = next(chunks, None)
             items = None  # the chunk's result objects, when every file went through the GPU decoder
+            t0 = perf_counter()
             if isinstance(raw, tuple):
                 if not _debug.DEBUG and all(raw[1]):
                     items = records_to_items(raw[0], raw[1], reader.dial_names, chunk, MeterImageData)
@@ -205,6 +228,9 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
                     converted = records_to_python(raw[0], raw[1], reader.dial_names, chunk)
             elif raw is not None:
                 converted = raw
+            local['s_convert'] += perf_counter() - t0
+            local['chunks'] += 1
+            local['files'] += len(chunk)
             if items is not None:
                 yield items
                 chunk = following
@@ -253,6 +279,17 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
                 clean = False
         if pool is not None:
             pool.shutdown(wait=False)
+        lib_stats = None
+        if reader is not None and clean and hasattr(getattr(reader, 'ctx', None), 'files_stats'):
+            try:
+                lib_stats = reader.ctx.files_stats(reset=True)
+            except Exception:
+                lib_stats = None
+        with _stats_lock:
+            for k in ('chunks', 'files', 's_begin', 's_end_wait', 's_convert'):
+                _stats[k] += local[k]
+            if lib_stats is not None and lib_stats.get('calls'):
+                _stats['library'].append(lib_stats)
         if reader is not None:
             if clean and MeterReader is _REAL_READER:
                 _release_reader(reader)   # idle and in a known state: the next call with this calibration takes it over

@@ -80,7 +80,7 @@ EXPORTS = [
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_stream_probe_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_match_gen_plan_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
     'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
-    'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end', 'melf_jpeg_files_in_flight_max',
+    'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end', 'melf_jpeg_files_in_flight_max', 'melf_ctx_files_stats', 'melf_files_open_probe',
 ]
 
 _lib = None
@@ -140,6 +140,8 @@ def lib():
     L.melf_jpeg_process_files_begin.argtypes = [vp, vp, C.c_int, i32p, i32p, vp, vp]
     L.melf_jpeg_process_files_end.argtypes = [vp]
     L.melf_jpeg_files_in_flight_max.argtypes = []
+    L.melf_ctx_files_stats.argtypes = [vp, vp, C.c_int]
+    L.melf_files_open_probe.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     if L.melf_abi_version() != ABI_VERSION:
         raise HipError('libmeterelf_hip.so ABI version mismatch')
     _lib = L
@@ -217,6 +219,16 @@ def _path_table(paths):
     addr[1:] = ends[:-1] + 1
     addr += np.uint64(buf.ctypes.data)
     return addr, (blob, buf)
+
+
+def files_open_probe(paths, device=0):
+    """open() + close() of every path on the library's I/O pool: (milliseconds, threads).  Measurement aid."""
+    (addr, keep) = _path_table(paths)
+    ms = C.c_double(0.0)
+    th = C.c_int(0)
+    check(lib().melf_files_open_probe(C.c_void_p(addr.ctypes.data), len(paths), device, C.byref(ms), C.byref(th)))
+    del keep
+    return ms.value, th.value
 
 
 def pack_blob(cparams, template):
@@ -497,6 +509,13 @@ class Context:
 
     def set_profiling(self, on):
         check(self._L.melf_ctx_set_profiling(self._h, int(on)))  # False/0 off, True/1 every kernel, 2 only k_match
+
+    def files_stats(self, reset=True):
+        """Host-time breakdown of the file-name calls since the last reset (include/meterelf_hip.h: melf_ctx_files_stats)."""
+        out = np.zeros(10, np.float64)
+        check(self._L.melf_ctx_files_stats(self._h, _ptr(out), 1 if reset else 0))
+        keys = ('calls', 'files', 'ms_read', 'ms_turn_wait', 'ms_enqueue', 'ms_gpu_wait', 'io_threads', 'host_threads', 'cores', 'devices_in_process')
+        return dict(zip(keys, (float(v) for v in out)))
 
     def timings(self):
         ms = np.zeros(K_COUNT, np.float64)

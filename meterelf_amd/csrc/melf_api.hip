@@ -312,6 +312,11 @@ struct melf_ctx {
     uint64_t files_decode_turn = 0;        // the ticket whose decode stage may run
     std::mutex files_m;
     std::condition_variable files_cv;
+    // where the file-name calls spend their host time (melf_ctx_files_stats; bench.py's jpeg_decode.get_meter_values.host):
+    // sums over the _begin calls since the last reset, milliseconds, under files_m
+    struct FilesStats {
+        double calls = 0, files = 0, ms_read = 0, ms_turn_wait = 0, ms_enqueue = 0, ms_gpu_wait = 0;
+    } files_stats;
     // profiling
     bool force_generic_mask = false;  // MELF_FORCE_GENERIC_MASK=1: float path for every shape (tests)
     int profiling = 0;                // 0 off, 1 every kernel, 2 only the dominant kernel (k_match)
@@ -2026,15 +2031,18 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
                 std::unique_lock<std::mutex> lk(c->files_m);
                 c->files_cv.wait(lk, [&]() { return c->files_decode_turn == ticket; });
             }
+            const auto tb2 = std::chrono::steady_clock::now();
             if (trace)
                 fprintf(stderr, "[melf jpeg] call %llu: thread up at %.2f, files read by %.2f, its turn at %.2f (process clock, ms)\n",
-                        (unsigned long long)ticket, trace_clock_ms(tb0), trace_clock_ms(tb1), trace_clock_ms(std::chrono::steady_clock::now()));
+                        (unsigned long long)ticket, trace_clock_ms(tb0), trace_clock_ms(tb1), trace_clock_ms(tb2));
             // the turn goes on as soon as this call has ENQUEUED all its GPU work (the next call then prepares and enqueues
             // while this one's kernels run), at the latest when the call is over
             bool released = false;
+            auto tb3 = tb2;
             std::function<void()> release = [&]() {
                 if (released) return;
                 released = true;
+                tb3 = std::chrono::steady_clock::now();
                 {
                     std::lock_guard<std::mutex> lk(c->files_m);
                     ++c->files_decode_turn;
@@ -2052,6 +2060,16 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
             job->rc = rc;
             if (rc) job->err = g_err;  // this thread's message, for the thread that calls _end
             release();
+            {
+                const auto tb4 = std::chrono::steady_clock::now();
+                const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                    return std::chrono::duration<double, std::milli>(b - a).count();
+                };
+                std::lock_guard<std::mutex> lk(c->files_m);
+                auto& st = c->files_stats;
+                st.calls += 1; st.files += n;
+                st.ms_read += ms(tb0, tb1); st.ms_turn_wait += ms(tb1, tb2); st.ms_enqueue += ms(tb2, tb3); st.ms_gpu_wait += ms(tb3, tb4);
+            }
         });
     } catch (const std::exception& e) {
         delete job;
@@ -2063,6 +2081,44 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
 }
 
 extern "C" int melf_jpeg_files_in_flight_max(void) { return MELF_FILES_IN_FLIGHT_MAX; }
+
+// What the file system gives the read stage: open() + close() of every path on the device's I/O pool, nothing else.  (On the
+// pool's boxes an open() costs 1.4-1.8 ms per 1024 files whether 6 or 48 threads issue them -- the container's file system
+// serialises it -- which is the floor of every file-name figure there: profiles/r05/file_reads_open_close.txt.)
+extern "C" int melf_files_open_probe(const char* const* paths, int n, int device, double* ms, int* threads)
+{
+    if (!paths || n < 0 || !ms) return fail(MELF_ERR_INVALID, "bad argument");
+    pool_use_device(device);
+    WorkerPool& pool = io_pool();
+    std::atomic<int> failed{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    pool.run(n, [&](int i) {
+        const int fd = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+        if (fd < 0) { failed.fetch_add(1, std::memory_order_relaxed); return; }
+        close(fd);
+    });
+    *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (threads) *threads = pool.size() + 1;
+    return failed.load() ? fail(MELF_ERR_INVALID, "melf_files_open_probe: a file could not be opened") : MELF_SUCCESS;
+}
+
+extern "C" int melf_ctx_files_stats(melf_ctx* c, double out[MELF_FILES_STATS_COUNT], int reset)
+{
+    if (!c || !out) return fail(MELF_ERR_INVALID, "NULL argument");
+    if (!c->files_jobs.empty()) return fail(MELF_ERR_INVALID, "melf_ctx_files_stats while a melf_jpeg_process_files_begin call is in flight");
+    pool_use_device(c->device);
+    {
+        std::lock_guard<std::mutex> lk(c->files_m);
+        const auto& st = c->files_stats;
+        out[0] = st.calls; out[1] = st.files; out[2] = st.ms_read; out[3] = st.ms_turn_wait; out[4] = st.ms_enqueue; out[5] = st.ms_gpu_wait;
+        if (reset) c->files_stats = melf_ctx::FilesStats();
+    }
+    out[6] = io_pool().size() + 1;      // threads of the read stage, the calling thread included
+    out[7] = host_pool().size() + 1;    // threads of the other parallel host loops
+    out[8] = pool_cores();              // cores this process may run on (affinity mask)
+    out[9] = pool_devices();            // devices this process has contexts on (the pools' divisor)
+    return MELF_SUCCESS;
+}
 
 extern "C" int melf_jpeg_process_files_end(melf_ctx* c)
 {
