@@ -263,12 +263,12 @@ GEN_TASK_DTYPE = np.dtype([(k, '<i4') for k in ('y0', 'rows', 'rows_computed', '
 def _match_info_dict(mi, gen_plan=False):
     d = {k: getattr(mi, k) for (k, _t) in MelfMatchInfo._fields_ if k != 'reserved'}
     d['kernel'] = MATCH_KERNEL_NAMES[mi.kernel]
-    d['layout'] = ('rb%d%s' % (mi.rows_per_wave, '+pairs' if mi.pair_waves else '')) if mi.kernel == 1 and not gen_plan else None
+    d['layout'] = ('rb%d%s%s' % (mi.rows_per_wave, '+pairs' if mi.pair_waves else '', '/k%d' % mi.reserved[2] if mi.reserved[2] > 1 else '')) if mi.kernel == 1 and not gen_plan else None
     if mi.kernel == 2 or gen_plan:   # the general kernel's plan: tile shape, slices, remainder columns
         (d['nd'], d['rows_pad'], d['blocks_per_tile'], d['slices'], d['v_columns'], d['v_blocks']) = tuple(mi.reserved)
         d['layout'] = 'r%dx%d/%d%s' % (mi.rows_per_wave, d['blocks_per_tile'], d['slices'], '+v%d' % d['v_columns'] if d['v_columns'] else '')
     else:
-        d['th_pad'], d['rows_pad'] = mi.reserved[0], mi.reserved[1]
+        d['th_pad'], d['rows_pad'], d['k_slices'] = mi.reserved[0], mi.reserved[1], max(1, mi.reserved[2])
     return d
 
 

@@ -11,6 +11,7 @@
 // bit-packed LDS image (1 bit per pixel, 2 halo rows above and below); passes 2
 // and 3 do the closing on 32-pixel words with carries between neighbouring words;
 // pass 4 expands bits to bytes, one dword store per 4 pixels.
+#include <limits.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -426,7 +427,11 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_fused_stamps(ui
 #endif
 
 template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */,
-          bool DYN = false /* segments from the launch's work queue (PD == 1 only) instead of the static split */>
+          int MODE = 0 /* PD == 1 only.  1: segments from the launch's work queue instead of the static split (experiment, no gain);
+                          2: static split, EARLY refill: the rows of pass p + 2 are requested as soon as pass p's in-range test has
+                          consumed its register set (into that set), not at the start of pass p + 1 -- 1.7 passes of lead for the
+                          loads instead of 1.0 with the same two register sets, two passes requested before anything is computed,
+                          and nothing fetched beyond a segment's end */>
 __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     const uint8_t* __restrict__ frames, int n, int H, int W, int hue_shift, Bounds B,
     const uint32_t* __restrict__ g_tables, uint8_t* __restrict__ masks, int segs_per_frame, int seg_rows, int NB, int plain_store, int rc_dma,
@@ -434,6 +439,8 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     int big_segs, int big_rows /* DYN: a frame's first big_segs x big_rows rows are "big" segments (ids 0 .. n big_segs - 1: every workgroup's
                                   first one), the rest segs_per_frame small ones of seg_rows rows, handed out behind them */)
 {
+    constexpr bool DYN = MODE == 1, EARLY = MODE == 2;
+    static_assert(MODE == 0 || PD == 1, "the queue loop and the early refill are written for two register sets");
     constexpr bool PREFETCH = PD > 0;
     // PD < 0 (round 4, experiment MELF_FUSED_CONFIG=6): the pixel rows of a pass arrive by LDS-DMA with the non-temporal policy
     // (global_load_lds_dwordx4 ... nt: 1 KiB lane-contiguous pieces straight into a staging buffer in LDS, two buffers: the
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             }
         };
         int dma_slot = 0;
-        auto pass = [&](int a, const Px16& cur) {
+        auto pass = [&](int a, Px16& cur, int refill_a = INT_MIN /* EARLY: first row of the pass whose rows go into `cur` next */) {
             // ---- (1) in-range bits of input rows [a, a+RC) ----
             if (DMA) {
                 const int y = a + trow;
@@ -576,6 +583,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             } else if (PREFETCH) {
                 const int y = a + trow;
                 uint32_t bits = inrange16<VAR>(cur, hue, ls, hue_shift, B);
+                if (EARLY && refill_a != INT_MIN) load_from(frame, refill_a, min(r1 + 1, H - 1), cur);   // (uniform) the set is free: pass p + 2's rows
                 bits = (y >= 0 && y < H) ? bits : 0u;
                 if (active && y < r1 + 2) ((uint16_t*)raw)[__umul24((y + 4 * NB) & nbm, wpr * 2) + tg] = (uint16_t)bits;
             } else {
@@ -632,7 +640,13 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
             // out of order, so a wait for the prefetched pixels issued AFTER this pass's store would also
             // wait for the store's write-ack (a full memory round trip per pass).  Waiting here, just
             // before the store is issued, costs nothing: the only store in flight is one pass old.
-            if (PD > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (PD - 1)));  // vmcnt(3*(PD-1)), others untouched
+            if (EARLY) {
+                // the next pass's rows (requested one pass ago) must be in; the three loads just issued for the pass after it may stay in
+                // flight.  Loads return in order, so "at most three outstanding" cannot leave one of the older three out, whenever the
+                // previous pass's store is acknowledged.
+                if (refill_a != INT_MIN) __builtin_amdgcn_s_waitcnt(0x0F70 | 3);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            } else if (PD > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (PD - 1)));  // vmcnt(3*(PD-1)), others untouched
             if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next pass's rows have landed (this wave's pieces); the store below is younger
             if (DYN && dq_first && tid == 0) q_ids[dq_slot] = (int)(dq_pend + gridDim.x);   // every thread read this slot at least two barriers ago
             {
@@ -745,10 +759,36 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                 tables_ready = true;
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const Px16 unused = {};
+            Px16 unused = {};
             for (; a < aend; a += RC) {
                 if (a + RC < aend) issue(a + RC, dma_slot ^ 1);
                 pass(a, unused);
+            }
+        } else if constexpr (EARLY) {
+            Px16 pbuf[2];
+            const int ylast = min(r1 + 1, H - 1);
+            const bool two = a + RC < aend;          // uniform
+            load_from(frame, a, ylast, pbuf[0]);
+            if (two) load_from(frame, a + RC, ylast, pbuf[1]);
+            if (!tables_ready) {  // the frame loads above are already in flight while LDS is filled
+                fill_tables();
+                tables_ready = true;
+                __syncthreads();
+                FSTAMP(1);
+            }
+            if (two) __builtin_amdgcn_s_waitcnt(0x0F70 | 3);   // the first pass's rows
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            for (bool more = true; more;) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ra = a + 2 * RC;
+                    pass(a, pbuf[q], ra < aend ? ra : INT_MIN);
+#ifdef MELF_FUSED_STAMP
+                    if (fstamp_passes++ == 0) FSTAMP(2);
+#endif
+                    a += RC;
+                    if (a >= aend) { more = false; break; }
+                }
             }
         } else if constexpr (PREFETCH) {
             // PD + 1 rotating register sets: the loads of the next PD passes are in flight while the
@@ -800,7 +840,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                 tables_ready = true;
                 __syncthreads();
             }
-            const Px16 unused = {};
+            Px16 unused = {};
             for (; a < aend; a += RC) pass(a, unused);
         }
         lds_barrier();
@@ -910,13 +950,28 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // no event-record packets in the queue around the kernel
     const int ps = plain_store | ((getenv("MELF_FUSED_PRIO") ? atoi(getenv("MELF_FUSED_PRIO")) : 0) << 8);
     if constexpr (PF == 1) {
+        // early refill (round 5 experiment, MELF_FUSED_EARLY=1): measured no different from the refill at the start of the next
+        // pass (config 2 0.0668 / 0.0681 against 0.0664 ms, config 5 0.782 / 0.824 against 0.781 / 0.820: profiles/r05/
+        // fused_early_refill_ab.txt) -- the launch is not short of requests in flight.  Off by default.
+        const bool early = !wq && getenv("MELF_FUSED_EARLY") && atoi(getenv("MELF_FUSED_EARLY")) == 1;
+        if (early) {
+            static bool early_attr_set[64] = {false};
+            if (dev >= 0 && dev < 64 && !early_attr_set[dev]) {
+                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+                early_attr_set[dev] = true;
+            }
+            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, 2>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+                                  n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
+            g_fused_ev_start = g_fused_ev_stop = nullptr;
+            return;
+        }
         if (wq) {
             static bool dyn_attr_set[64] = {false};
             if (dev >= 0 && dev < 64 && !dyn_attr_set[dev]) {
-                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
                 dyn_attr_set[dev] = true;
             }
-            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, true>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, 1>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
                                   n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, wq, big_segs, big_rows);
             g_fused_ev_start = g_fused_ev_stop = nullptr;
             return;

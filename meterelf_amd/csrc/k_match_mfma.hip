@@ -188,6 +188,7 @@ struct MfmaGeom {
                          // middle row (one 32-column block of it each): 2 RB + 1 map rows per pair
     int k1;              // 128 * (sum T - 128 * th * tw)
     int rows, th;        // searched image rows, template rows (fused window sums)
+    int ntiles;          // row blocks per frame group (nparts = ntiles x K slices)
     double tmean;
 };
 
@@ -219,11 +220,21 @@ __device__ inline bool better_m(float v, int i, float bv, int bi)
 // up itself -- one 4 KiB row per template row, requested a step ahead like every other operand, the 64
 // additions spread over the step's MFMA sub-blocks (the vector ALU is idle there) -- into the window sums of its first
 // map row; the following rows slide (minus the row that leaves, plus the row that enters) in the epilogue.
-template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST>
+// K slices (round 5, KS = 2 or 4): the workgroup's KS waves each run the whole tile over 1 / KS of the template rows; the slices'
+// accumulators and window sums add up in the workgroup's LDS (ds_add_u32, lane-contiguous: conflict-free) and the tile's map
+// rows are dealt out to the waves for the epilogue.  A 512-frame launch then runs 1024 waves of 8 or 9 half-row units x 60
+// template rows (the 1024-frame layout's operand reuse) instead of 4 or 5 units x 120 rows, a 256-frame launch 8 or 9 x 30.
+template <int R, int NXB, int KS>
+struct SliceLds {
+    uint32_t acc[R * NXB][16][64];   // tile (r, xb), accumulator register e, lane
+    uint32_t wsa[32][64];            // window sums of the tile's first map row
+};
+
+template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST, int KS = 1>
 __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                            const uint32_t* __restrict__ ws, const MfmaGeom& g,
                                            float* __restrict__ result_map, MatchPartial* __restrict__ partials,
-                                           int grp, int rblk, int y0)
+                                           int grp, int rblk, int y0, void* lds_raw = nullptr)
 {
     auto on = [](int r, int xb) -> bool {
         return r == 0 ? ((MFIRST >> xb) & 1) : (r == R - 1 ? ((MLAST >> xb) & 1) : true);
@@ -231,7 +242,17 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     constexpr int NKB = ND + NXB - 1;
     constexpr int NBUF = R + PD;   // image-row register buffers: R live + PD in flight
     static_assert(PD == 1, "the template fragments are single-buffered: the next row's fragment d is requested right after this row's last use of fragment d");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int ks = KS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // this wave's K slice
+    const int SL = g.th_pad / KS, i_lo = ks * SL, i_hi = i_lo + SL;                           // its template rows
+    // the map row r of the tile whose epilogue this wave runs (KS > 1: rows dealt out evenly)
+    auto mine = [&](int r) -> bool { return KS == 1 || (r * KS) / R == ks; };
+    SliceLds<R, NXB, KS>* const X = (SliceLds<R, NXB, KS>*)lds_raw;
+    if (KS > 1) {   // zero the workgroup's tile; the barrier is long past when the first wave adds to it
+        uint32_t* z = (uint32_t*)X;
+        for (int i = threadIdx.x; i < (int)(sizeof(SliceLds<R, NXB, KS>) / 4); i += 64 * KS) z[i] = 0;
+        __syncthreads();
+    }
 
     const i32x4* Lrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + y0) * (size_t)NKB * 1024) + lane;
     const i32x4* Ap = (const i32x4*)Atab + lane;
@@ -256,9 +277,9 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // start so that image row y0 + i is roughly the same for every block at any moment (rounded to the
     // rotation period)
 #if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 32)
-    const int istart = 0;  // diagnostic: no rotation of the template-row order (one priming phase)
+    const int istart = i_lo;  // diagnostic: no rotation of the template-row order (one priming phase)
 #else
-    const int istart = (((g.th_pad - y0 % g.th_pad) % g.th_pad) / PERIOD) * PERIOD;
+    const int istart = i_lo + (((SL - y0 % SL) % SL) / PERIOD) * PERIOD;   // inside the wave's slice [i_lo, i_hi)
 #endif
     i32x4 buf[NBUF][NKB];
     // ONE set of template fragments (28 registers instead of 56): the request for the next template row's fragment d
@@ -277,7 +298,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #pragma unroll
     for (int j = 0; j < 32; ++j) wsa[j] = 0;
     for (int phase = 0; phase < 2; ++phase) {
-        const int ibeg = phase == 0 ? istart : 0, iend = phase == 0 ? g.th_pad : istart;
+        const int ibeg = phase == 0 ? istart : i_lo, iend = phase == 0 ? i_hi : istart;
         if (ibeg >= iend) continue;
         // (re-)prime: image rows y0+ibeg .. y0+ibeg+R+PD-2 and template row ibeg
 #pragma unroll
@@ -360,6 +381,36 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #ifdef MELF_MATCH_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_match_loop_end[blockIdx.x] = __builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (KS > 1) {
+        // the slices add up: window sums of the first map row (every wave needs the total: the following rows slide from it),
+        // and every (row, column block) tile into the LDS copy its epilogue wave reads back
+#pragma unroll
+        for (int j = 0; j < 32; ++j) __hip_atomic_fetch_add(&X->wsa[j][lane], wsa[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb) {
+                if (!on(r, xb)) continue;
+                if (!mine(r)) {   // wave-uniform
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        __hip_atomic_fetch_add(&X->acc[r * NXB + xb][e][lane], (uint32_t)acc[r][xb][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wsa[j] = X->wsa[j][lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int xb = 0; xb < NXB; ++xb) {
+                if (!on(r, xb)) continue;
+                if (mine(r)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][xb][e] += (int)X->acc[r * NXB + xb][e][lane];
+                }
+            }
+    }
     // ---- epilogue: exact u8 correlation, OpenCV's float post-pass, first-max reduction ----
     const int n = lane & 31, hh = lane >> 5;
     const int f = grp * 32 + n;
@@ -407,6 +458,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
         for (int rr = 0; rr < RB; ++rr) {
             const int r = r0 + rr;
             if (r >= R) continue;
+            if (!mine(r)) continue;   // (wave-uniform) another slice's wave runs this row; the window sums above slide on regardless
             const int y = y0 + r;
             const bool row_ok = lane_ok && y < g.rh;
 #pragma unroll
@@ -437,7 +489,7 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
         MatchPartial p;
         p.val = bestv;
         p.idx = besti;
-        partials[(size_t)f * g.nparts + rblk] = p;
+        partials[(size_t)f * g.nparts + rblk * KS + ks] = p;
     }
 }
 
@@ -451,10 +503,10 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 // 32-column blocks) or, in a pair, 2 RB + 1 (RB + 1 rows of which the shared middle row counts half) -- so that
 // na + 2 pairs waves per frame group fill the chip's 1024 SIMDs in ONE round whatever the batch size: RB = 4 with pairs
 // at 1024 frames (8 or 9 units instead of 10), RB = 2 with pairs at 512 (4 or 5 instead of 8), RB = 3 at 640-900 ...
-template <int ND, int NXB, int RB, int PD>
+template <int ND, int NXB, int RB, int PD, int KS>
 __device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                             const uint32_t* __restrict__ ws, const MfmaGeom& g,
-                                            float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+                                            float* __restrict__ result_map, MatchPartial* __restrict__ partials, void* lds)
 {
     // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so
     // ids with equal (id % 8) share an L2.  Give each XCD whole frame groups (they share Lg rows).
@@ -465,14 +517,14 @@ __device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const
 #endif
     const int per = nblk / 8, rem = nblk % 8, xcd = id & 7, sub = id >> 3;
     const int vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + sub;
-    const int grp = vid / g.nparts, rblk = vid - grp * g.nparts;
+    const int grp = vid / g.ntiles, rblk = vid - grp * g.ntiles;   // one workgroup (KS waves) per tile
     if (NXB == 2 && RB < 5 && rblk >= g.na) {
         // a pair: two (RB + 1)-row waves, the first owns column block 0 of the shared middle row, the second block 1
         const int q = rblk - g.na, base = RB * g.na + (2 * RB + 1) * (q >> 1);
-        if ((q & 1) == 0) match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 3, 1>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base);
-        else match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 2, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + RB);
+        if ((q & 1) == 0) match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 3, 1, KS>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base, lds);
+        else match_wave<ND, 2, (RB < 5 ? RB + 1 : RB), PD, 2, 3, KS>(Lg, Atab, ws, g, result_map, partials, grp, rblk, base + RB, lds);
     } else {
-        match_wave<ND, NXB, RB, PD, 3, 3>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * RB);
+        match_wave<ND, NXB, RB, PD, 3, 3, KS>(Lg, Atab, ws, g, result_map, partials, grp, rblk, rblk * RB, lds);
     }
 #ifdef MELF_MATCH_STAMP
     if (threadIdx.x == 0 && id < 8192) {
@@ -482,12 +534,18 @@ __device__ __forceinline__ void match_block(const int8_t* __restrict__ Lg, const
 #endif
 }
 
-template <int ND, int NXB, int RB, int PD>
-__global__ __launch_bounds__(64, 1) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
-                                                      const uint32_t* __restrict__ ws, MfmaGeom g,
-                                                      float* __restrict__ result_map, MatchPartial* __restrict__ partials)
+template <int ND, int NXB, int RB, int PD, int KS = 1>
+__global__ __launch_bounds__(64 * KS, 1) void k_match_mfma(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
+                                                           const uint32_t* __restrict__ ws, MfmaGeom g,
+                                                           float* __restrict__ result_map, MatchPartial* __restrict__ partials)
 {
-    match_block<ND, NXB, RB, PD>(Lg, Atab, ws, g, result_map, partials);   // ws = row-window sums R in epilogue order
+    if constexpr (KS > 1) {
+        // room for the largest tile of the launch: (RB + 1)-row pair waves
+        __shared__ __attribute__((aligned(16))) SliceLds<(NXB == 2 && RB < 5 ? RB + 1 : RB), NXB, KS> lds;
+        match_block<ND, NXB, RB, PD, KS>(Lg, Atab, ws, g, result_map, partials, &lds);
+    } else {
+        match_block<ND, NXB, RB, PD, 1>(Lg, Atab, ws, g, result_map, partials, nullptr);   // ws = row-window sums R in epilogue order
+    }
 }
 // ---------------------------------------------------------------------------
 // host side
@@ -497,12 +555,13 @@ constexpr int MM_ND = 7, MM_PD = 1;
 // buffers): a launch with RB-row waves and pairs of (RB + 1)-row waves needs lcm(RB + 1, RB + 2), without pairs
 // RB + 1.  The fragment table carries the largest padding any layout can ask for (60 = lcm(3, 4, 5, 6)).
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
-static int mm_th_pad_max(int th) { return round_up(th, 60); }
-static int mm_th_pad(int th, int rb, bool pairs)
+// K slices (ks = 2, 4; rb = 4 only): every slice is a multiple of the period(s)
+static int mm_th_pad(int th, int rb, bool pairs, int ks = 1)
 {
     static const int lcm2[6] = {0, 0, 12, 20, 30, 6};  // lcm(rb + 1, rb + 2); rb = 5 has no pairs
-    return round_up(th, pairs ? lcm2[rb] : rb + 1);
+    return ks * round_up((th + ks - 1) / ks, pairs ? lcm2[rb] : rb + 1);
 }
+static int mm_th_pad_max(int th) { return std::max(round_up(th, 60), std::max(mm_th_pad(th, 4, true, 2), mm_th_pad(th, 4, true, 4))); }
 
 bool mfma_match_ok(int th, int tw, int rows, int cols)
 {
@@ -517,10 +576,13 @@ bool mfma_match_ok(int th, int tw, int rows, int cols)
 // loop, ~11 cycles of matrix-pipe idle per 1 KiB fragment load issued between the MFMA groups, the epilogue
 // (double-precision post-pass, arg-max) ~2 400 cycles per half-row unit + ~1 200 per map row (its window sums slide in:
 // eight loads, 64 additions), priming ~4 000.
-static double mm_wave_cycles(int R, int units, int nxb, int th_pad)
+// K slices (ks > 1): a wave runs th_pad / ks template rows of the whole tile and the epilogue of 1 / ks of its units; the exchange
+// through LDS (zeroing, ~150 ds_add + as many reads, two barriers -- one of them waits for the tile's slowest slice) ~6 000.
+static double mm_wave_cycles(int R, int units, int nxb, int th_pad, int ks = 1)
 {
     const int nkb = MM_ND + nxb - 1;   // image-row fragments per step; + MM_ND template fragments + 4 pieces of the R row
-    return (double)th_pad * ((double)units * MM_ND * 33.0 + (double)(nkb + MM_ND + 4) * 11.0) + units * 2400.0 + 4000.0 + R * 1200.0;
+    return (double)(th_pad / ks) * ((double)units * MM_ND * 33.0 + (double)(nkb + MM_ND + 4) * 11.0) + (double)((units + ks - 1) / ks) * 2400.0 + 4000.0 + R * 1200.0 +
+           (ks > 1 ? 6000.0 : 0.0);
 }
 
 MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
@@ -534,32 +596,40 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
     // Layout search: RB full rows per wave (2..5), np pairs of (RB + 1)-row waves sharing their middle row.  The
     // launch's time is (rounds of waves over the 1024 SIMDs) x (its longest wave); among equals the fewest pairs.
     const int simds = 1024;
-    int force_rb = 0, force_np = -1;
-    if (const char* e = getenv("MELF_MATCH_LAYOUT")) {  // experiments / tests: "rb,np"; anything outside the family is ignored
-        if (sscanf(e, "%d,%d", &force_rb, &force_np) < 1 || force_rb < 2 || force_rb > 5) { force_rb = 0; force_np = -1; }
+    int force_rb = 0, force_np = -1, force_ks = 0;
+    if (const char* e = getenv("MELF_MATCH_LAYOUT")) {  // experiments / tests: "rb,np[,ks]"; anything outside the family is ignored
+        if (sscanf(e, "%d,%d,%d", &force_rb, &force_np, &force_ks) < 1 || force_rb < 2 || force_rb > 5) { force_rb = 0; force_np = -1; force_ks = 0; }
+        if (force_ks != 1 && force_ks != 2 && force_ks != 4) force_ks = force_rb ? 1 : 0;   // "rb,np" alone: no slices (as before round 5)
+        if (force_ks > 1 && force_rb != 4) force_ks = 1;
     }
     double best = 0;
     p.rb = 0;
-    for (int rb = 2; rb <= 5; ++rb) {
-        if (force_rb && rb != force_rb) continue;
-        const int np_max = (p.nxb == 2 && rb < 5) ? (p.rh + 2 * rb) / (2 * rb + 1) : 0;
-        for (int np = 0; np <= np_max; ++np) {
-            if (force_np >= 0 && np != std::min(force_np, np_max)) continue;
-            const int rest = p.rh - (2 * rb + 1) * np;
-            const int na = rest > 0 ? (rest + rb - 1) / rb : 0;
-            const long waves = (long)(na + 2 * np) * p.groups;
-            const long rounds = (waves + simds - 1) / simds;
-            const int th_pad = mm_th_pad(th, rb, np > 0);
-            const int upr = p.nxb;  // units per full row
-            const double longest = np > 0 ? mm_wave_cycles(rb + 1, upr * rb + 1, p.nxb, th_pad) : mm_wave_cycles(rb, upr * rb, p.nxb, th_pad);
-            const double cost = (double)rounds * longest;
-            if (!p.rb || cost < best * 0.995) {
-                best = cost;
-                p.rb = rb; p.na = na; p.np = np; p.th_pad = th_pad;
+    p.ks = 1;
+    for (int ks = 1; ks <= 4; ks *= 2) {
+        if (force_ks && ks != force_ks) continue;
+        for (int rb = 2; rb <= 5; ++rb) {
+            if (force_rb && rb != force_rb) continue;
+            if (ks > 1 && rb != 4) continue;   // K slices are instantiated for the 4-row tiles (the 1024-frame layout's operand reuse)
+            const int np_max = (p.nxb == 2 && rb < 5) ? (p.rh + 2 * rb) / (2 * rb + 1) : 0;
+            for (int np = 0; np <= np_max; ++np) {
+                if (force_np >= 0 && np != std::min(force_np, np_max)) continue;
+                const int rest = p.rh - (2 * rb + 1) * np;
+                const int na = rest > 0 ? (rest + rb - 1) / rb : 0;
+                const long waves = (long)(na + 2 * np) * p.groups * ks;
+                const long rounds = (waves + simds - 1) / simds;
+                const int th_pad = mm_th_pad(th, rb, np > 0, ks);
+                const int upr = p.nxb;  // units per full row
+                const double longest = np > 0 ? mm_wave_cycles(rb + 1, upr * rb + 1, p.nxb, th_pad, ks) : mm_wave_cycles(rb, upr * rb, p.nxb, th_pad, ks);
+                const double cost = (double)rounds * longest;
+                if (!p.rb || cost < best * 0.995) {
+                    best = cost;
+                    p.rb = rb; p.na = na; p.np = np; p.th_pad = th_pad; p.ks = ks;
+                }
             }
         }
     }
-    p.nparts = p.na + 2 * p.np;
+    p.ntiles = p.na + 2 * p.np;
+    p.nparts = p.ntiles * p.ks;
     const int rows_cov = p.rb * p.na + (2 * p.rb + 1) * p.np;
     p.rows_pad = rows_cov + p.th_pad + MM_PD + 1;   // last row touched: y0 + (th_pad - 1) + R + PD - 1 (prefetched, unused)
     p.lg_bytes = (size_t)p.groups * p.rows_pad * p.nkb * 1024;
@@ -611,13 +681,13 @@ void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan&
     launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, tw, d_lg, d_r, stream);
 }
 
-template <int NXB, int RB>
+template <int NXB, int RB, int KS>
 static void launch_mm(dim3 grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const int8_t* d_lg,
                       const int8_t* d_atab, const uint32_t* d_ws, const MfmaGeom& g, float* d_result_map, MatchPartial* d_partials)
 {
     // ev_start / ev_stop (optional): time stamps taken by the dispatch itself (hipExtLaunchKernelGGL) -- no
     // hipEventRecord barrier packets in the queue around the kernel
-    hipExtLaunchKernelGGL((k_match_mfma<MM_ND, NXB, RB, MM_PD>), grid, dim3(64), 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
+    hipExtLaunchKernelGGL((k_match_mfma<MM_ND, NXB, RB, MM_PD, KS>), grid, dim3(64 * KS), 0, stream, ev_start, ev_stop, 0, d_lg, d_atab, d_ws, g,
                               d_result_map, d_partials);
 }
 
@@ -627,25 +697,29 @@ void launch_mfma_match(int n, const MfmaPlan& p, int th, int tw, long tsum, doub
 {
     MfmaGeom g;
     g.rh = p.rh; g.rw = p.rw; g.rows_pad = p.rows_pad; g.th_pad = p.th_pad; g.nframes = n; g.nparts = p.nparts;
-    g.na = p.na;
+    g.na = p.na; g.ntiles = p.ntiles;
     g.k1 = (int)(128 * (tsum - 128L * th * tw));
     g.rows = p.rh + th - 1; g.th = th;
     g.tmean = tmean;
-    dim3 grid(p.nparts * p.groups);
+    dim3 grid(p.ntiles * p.groups);
 #define MM_CASE(NXB_, RB_) \
-    case NXB_ * 8 + RB_: launch_mm<NXB_, RB_>(grid, stream, ev_start, ev_stop, d_lg, d_atab, d_ws, g, d_result_map, d_partials); break;
-    switch (p.nxb * 8 + p.rb) {
+    case NXB_ * 8 + RB_: launch_mm<NXB_, RB_, 1>(grid, stream, ev_start, ev_stop, d_lg, d_atab, d_ws, g, d_result_map, d_partials); break;
+#define MM_CASE_KS(NXB_, KS_) \
+    case 64 * KS_ + NXB_ * 8 + 4: launch_mm<NXB_, 4, KS_>(grid, stream, ev_start, ev_stop, d_lg, d_atab, d_ws, g, d_result_map, d_partials); break;
+    switch ((p.ks > 1 ? 64 * p.ks : 0) + p.nxb * 8 + p.rb) {
 #ifdef MELF_MATCH_ONLY_RB4   // experiments: one instantiation (fast compile)
         MM_CASE(2, 4)
 #else
         MM_CASE(1, 2) MM_CASE(1, 3) MM_CASE(1, 4) MM_CASE(1, 5)
         MM_CASE(2, 2) MM_CASE(2, 3) MM_CASE(2, 4) MM_CASE(2, 5)
+        MM_CASE_KS(1, 2) MM_CASE_KS(2, 2) MM_CASE_KS(1, 4) MM_CASE_KS(2, 4)
 #endif
         default:   // a plan outside the instantiated family must never pass silently: the records would come from stale partials
-            fprintf(stderr, "[melf] k_match_mfma: no instantiation for %d column blocks x %d rows per wave\n", p.nxb, p.rb);
+            fprintf(stderr, "[melf] k_match_mfma: no instantiation for %d column blocks x %d rows per wave x %d K slices\n", p.nxb, p.rb, p.ks);
             abort();
     }
 #undef MM_CASE
+#undef MM_CASE_KS
 }
 
 }  // namespace melf

@@ -725,11 +725,14 @@ static int default_match_kind(int th, int tw, int rows, int cols, int n)
     if (fast_ok) {
         // measured on MI355X, map 132 x 63 (tools/gpu_check_gen.sh): tuned / general kernel 175 / 246 us at 1024 frames,
         // 128 / 161 at 512, 72 / 87 at 256, 62 / 33 at 64; map 17 x 33 at 1024 frames: 67 / 42 us
+        // round 5 (K slices: 4-row tiles, 2 or 4 waves per tile; tools/match_sweep.py, profiles/r05/match_sweep_k_slices.txt):
+        // tuned / general 42 / 40 us at 128 frames, 44 / 51 at 192, 56 / 66 at 256, 73 / 70 at 320, 86 / 93 at 448, 98 / 153 at 512
         const int rh = rows - th + 1, rw = cols - tw + 1, groups = (n + 31) / 32;
-        const bool few_frames = groups <= 4;                               // the tuned kernel cannot slice its K loop
-        const bool small_map = (long)((rh + 4) / 5) * groups * 2 <= 512;   // ... nor fill the chip with a small map
+        const MfmaPlan pl = mfma_plan(th, tw, rows, cols, n);
+        const bool few_waves = (long)pl.nparts * pl.groups < 700;          // even in four K slices the tuned kernel leaves a third of the chip idle
+        const bool small_map = rh < 64 && (long)((rh + 4) / 5) * groups * 2 <= 512;   // a few rows: the general kernel's tile shapes fit them better
         const bool odd_cols = rw > 32 && rw % 32 >= 1 && rw % 32 <= 4;     // a whole column block for <= 4 columns
-        if (!gen_ok || !(few_frames || small_map || odd_cols)) return MK_FAST;
+        if (!gen_ok || !(few_waves || small_map || odd_cols)) return MK_FAST;
     }
     return gen_ok ? MK_GEN : MK_DOT4;
 }
@@ -774,8 +777,8 @@ extern "C" int melf_match_layout_query(int th, int tw, int rows, int cols, int n
     out->kernel = MK_FAST;
     out->rows_per_wave = pl.rb; out->full_waves = pl.na; out->pair_waves = 2 * pl.np;
     out->waves = pl.nparts * pl.groups;
-    out->tiles = pl.nparts;
-    out->reserved[0] = pl.th_pad; out->reserved[1] = pl.rows_pad;
+    out->tiles = pl.ntiles;
+    out->reserved[0] = pl.th_pad; out->reserved[1] = pl.rows_pad; out->reserved[2] = pl.ks;
     return MELF_SUCCESS;
 }
 
@@ -933,8 +936,8 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
             launch_mfma_prep(ms, from_bgr, m, pl, P.th, P.tw, c->d_lg[bl], c->d_rsum[bl], ls);
         }
         info.rows_per_wave = pl.rb; info.full_waves = pl.na; info.pair_waves = 2 * pl.np;
-        info.waves = pl.nparts * pl.groups; info.tiles = pl.nparts;
-        info.reserved[0] = pl.th_pad; info.reserved[1] = pl.rows_pad;
+        info.waves = pl.nparts * pl.groups; info.tiles = pl.ntiles;
+        info.reserved[0] = pl.th_pad; info.reserved[1] = pl.rows_pad; info.reserved[2] = pl.ks;
         launch_mfma_match(m, pl, P.th, P.tw, c->tsum, c->mg.tmean, c->d_atab, c->d_lg[bl], (const uint32_t*)c->d_rsum[bl], d_map, *parts, ls,
                           ev.start, ev.stop);
     } else if (kind == MK_GEN) {

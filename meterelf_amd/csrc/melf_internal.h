@@ -48,6 +48,7 @@ int match_parts(const MatchGeom& g, int rows, int cols);
 struct MfmaPlan {
     int rh, rw, nxb, nkb, th_pad, nparts, rows_pad, groups;
     int rb, na, np;   // layout: na waves of rb full map rows + np pairs of (rb + 1)-row waves sharing their middle row
+    int ks, ntiles;   // K slices per tile (waves of a tile's workgroup; nparts = ntiles x ks), tiles per frame group = na + 2 np
     size_t lg_bytes, r_bytes;
 };
 bool mfma_match_ok(int th, int tw, int rows, int cols);

@@ -234,6 +234,30 @@ def test_fused_mask_work_queue(env, monkeypatch, grid, dyn, big):
             assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
 
 
+@pytest.mark.parametrize('grid', [0, 3])
+def test_fused_mask_early_refill(env, monkeypatch, grid):
+    """MELF_FUSED_EARLY=1 (round 5 experiment, k_fused_mask_lut<.., 2>): the rows of pass p + 2 requested as soon as pass p's in-range
+    test has consumed its register set, nothing fetched beyond a segment's end.  Same masks as the default launch and the oracle:
+    one-pass, two-pass and many-pass segments, several segments per workgroup (MELF_FUSED_GRID), a full-size batch."""
+    from oracle import pyoracle as po
+    ctx = env['sample-images1']['reader'].ctx
+    p = ctx.params
+    rng = np.random.default_rng(77 + grid)
+    for (n, H, W) in ((6, 200, 160), (3, 640, 480), (2, 333, 1920), (9, 37, 64), (5, 101, 48), (40, 480, 640)):
+        frames = _blobby(rng, n, H, W)
+        monkeypatch.delenv('MELF_FUSED_EARLY', raising=False)
+        monkeypatch.delenv('MELF_FUSED_GRID', raising=False)
+        ref = ctx.hls_inrange_close(frames)
+        monkeypatch.setenv('MELF_FUSED_EARLY', '1')
+        if grid:
+            monkeypatch.setenv('MELF_FUSED_GRID', str(grid))
+        for rep in range(2):
+            got = ctx.hls_inrange_close(frames)
+            assert np.array_equal(got, ref), (n, H, W, rep, np.argwhere(got != ref)[:5])
+        for f in range(min(n, 3)):
+            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
+
+
 def test_fused_mask_lds_dma_launch_shape(env, monkeypatch):
     """MELF_FUSED_CONFIG=6 (round 4's experiment: pixel rows through LDS-DMA into two staging buffers, one workgroup per CU)
     must stay what it is measured as: the same masks as the oracle's, on an aligned and on a narrow shape and at 1080p."""

@@ -22,10 +22,13 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 REJECTED = ('20180814021309-01-e01.jpg', '20180814021310-00-e02.jpg')
 
 # batch size -> layout the planner must pick for the sample-images1 shape (crop 250 x 250, template 119 x 188, map
-# 132 x 63) on 1024 SIMDs.  320: default dispatch's first tuned-kernel size class; 512 / 700: mid-size batches (an
+# 132 x 63) on 1024 SIMDs.  256 (the host-fed chunk size) / 384: the tuned kernel's smallest size classes at default dispatch
+# (four / two K slices; 288 ... 352 frames go to the general kernel); 512 / 700: mid-size batches (an
 # 8-GPU shard of config 5); 1024: the BENCH headline launch and get_meter_values' default chunk; 1056: 33 groups;
 # 2048: two rounds of waves.
-EXPECTED_LAYOUT = {320: 'rb2', 512: 'rb2+pairs', 700: 'rb3', 800: 'rb3+pairs', 900: 'rb4', 1024: 'rb4+pairs',
+# "/kN" (round 5): N waves per tile, each over 1 / N of the template rows, adding up in the workgroup's LDS -- the 4-row tiles of
+# the 1024-frame layout for batches that would otherwise run 2-row waves (320, 512: config 5's per-GPU share).
+EXPECTED_LAYOUT = {256: 'rb4+pairs/k4', 384: 'rb4/k2', 512: 'rb4+pairs/k2', 600: 'rb2+pairs', 700: 'rb3', 800: 'rb3+pairs', 900: 'rb4', 1024: 'rb4+pairs',
                    1056: 'rb4+pairs', 1100: 'rb5', 2048: 'rb4+pairs'}
 
 # sample-images2 shape (BASELINE config 4: crop 135 x 220, map 17 x 33): default dispatch is the GENERAL matrix-core kernel
@@ -45,15 +48,19 @@ def test_planner_invariants_every_batch_size():
     for n in range(1, 4301):
         d = _hip.match_layout_query(th, tw, rows, cols, n)
         assert d['kernel'] == 'mfma' and d['groups'] == (n + 31) // 32
-        (rb, na, npairs) = (d['rows_per_wave'], d['full_waves'], d['pair_waves'] // 2)
+        (rb, na, npairs, ks) = (d['rows_per_wave'], d['full_waves'], d['pair_waves'] // 2, d['k_slices'])
         assert 2 <= rb <= 5 and (npairs == 0 or rb < 5)
+        assert ks in (1, 2, 4) and (ks == 1 or rb == 4)           # K slices are instantiated for the 4-row tiles
         covered = rb * na + (2 * rb + 1) * npairs
         assert rh <= covered < rh + 2 * rb + 1, (n, rb, na, npairs)
-        assert d['waves'] == (na + 2 * npairs) * d['groups']
-        assert d['th_pad'] >= th and d['th_pad'] % (rb + 1) == 0 and (npairs == 0 or d['th_pad'] % (rb + 2) == 0)
+        assert d['waves'] == (na + 2 * npairs) * d['groups'] * ks and d['tiles'] == na + 2 * npairs
+        # every slice's share of the (padded) template rows is a whole number of rotation periods of every wave type
+        sl = d['th_pad'] // ks
+        assert d['th_pad'] >= th and d['th_pad'] == sl * ks and sl % (rb + 1) == 0 and (npairs == 0 or sl % (rb + 2) == 0)
         assert d['rows_pad'] >= covered + d['th_pad'] + 1
-        if 16 <= d['groups'] <= 34:     # 16 x 64 ... 34 x 30 waves: a one-round layout exists
+        if 8 <= d['groups'] <= 34:      # 8 x 32 x 4 ... 34 x 30 waves: a one-round layout exists
             assert d['waves'] <= 1024, (n, d)
+        if 16 <= d['groups'] <= 34 or d['groups'] == 8:
             assert d['waves'] >= 880, (n, d)   # and it uses (nearly) every SIMD
     for (n, want) in EXPECTED_LAYOUT.items():
         assert _hip.match_layout_query(th, tw, rows, cols, n)['layout'] == want, n
@@ -286,16 +293,17 @@ def test_tuned_kernel_whole_map(lay, n):
         assert (float(mv[i]), int(mx[i]), int(my[i])) == (ev, ex, ey), i
 
 
-ALL_LAYOUTS = [(rb, pairs, cols) for rb in (2, 3, 4, 5) for (pairs, cols) in ((0, 250), (3, 250), (0, 215))
-               if not (pairs and rb == 5)]
+ALL_LAYOUTS = [(rb, pairs, cols, 1) for rb in (2, 3, 4, 5) for (pairs, cols) in ((0, 250), (3, 250), (0, 215))
+               if not (pairs and rb == 5)] + [(4, pairs, cols, ks) for ks in (2, 4) for (pairs, cols) in ((0, 250), (3, 250), (0, 215))]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('rb,pairs,cols', ALL_LAYOUTS, ids=lambda v: str(v))
-def test_every_instantiation_forced(lay, monkeypatch, rb, pairs, cols):
-    """Every instantiation of the tuned kernel (RB = 2..5, with pairs, one or two column blocks) forced at a small batch
-    (MELF_MATCH=fast, MELF_MATCH_LAYOUT=rb,np): whole maps bit-equal to the VALU kernel's, twice in a row (work buffers
-    reused).  The layouts are the planner's choices at other batch sizes; forcing them keeps the check cheap."""
+@pytest.mark.parametrize('rb,pairs,cols,ks', ALL_LAYOUTS, ids=lambda v: str(v))
+def test_every_instantiation_forced(lay, monkeypatch, rb, pairs, cols, ks):
+    """Every instantiation of the tuned kernel (RB = 2..5, with pairs, one or two column blocks; 4-row tiles in 2 and 4 K
+    slices) forced at a small batch (MELF_MATCH=fast, MELF_MATCH_LAYOUT=rb,np,ks): whole maps bit-equal to the VALU kernel's,
+    twice in a row (work buffers reused).  The layouts are the planner's choices at other batch sizes; forcing them keeps the
+    check cheap."""
     from meterelf_amd import MeterReader
     (frames, where) = _batch(lay, 70, 3000 + rb * 10 + pairs)
     p = lay['params']
@@ -303,13 +311,13 @@ def test_every_instantiation_forced(lay, monkeypatch, rb, pairs, cols):
     imgs = np.ascontiguousarray(frames[:, y0:y1, x0:x0 + cols, 2])
     (mvd, mxd, myd, rmapd) = lay['readers']['dot4'].ctx.match_ccoeff(imgs, want_map=True)
     monkeypatch.setenv('MELF_MATCH', 'fast')
-    monkeypatch.setenv('MELF_MATCH_LAYOUT', '%d,%d' % (rb, pairs))
+    monkeypatch.setenv('MELF_MATCH_LAYOUT', '%d,%d,%d' % (rb, pairs, ks))
     r = MeterReader(p)
     try:
         for rep in range(2):
             (mv, mx, my, rmap) = r.ctx.match_ccoeff(imgs, want_map=True)
             info = r.ctx.last_match()
-            assert info['kernel'] == 'mfma' and info['rows_per_wave'] == rb, info
+            assert info['kernel'] == 'mfma' and info['rows_per_wave'] == rb and info['k_slices'] == ks, info
             assert (info['pair_waves'] > 0) == (pairs > 0 and cols == 250), info
             assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32)), (rb, pairs, cols, rep)
             assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mvd.tobytes(), mxd.tobytes(), myd.tobytes())
@@ -512,7 +520,7 @@ def test_general_kernel_whole_map_config4(lay2):
 def test_config5_resident_full_size(lay):
     """BASELINE config 5, one GPU's share, as bench.py's config5_block launches it: 512 frames of 1920 x 1080 resident in HBM
     (6 220 800-byte frame stride, 3.2 GB), the six-dial params of bench.config5_params_dir, ONE melf_process_batch_dev call
-    (tuned kernel, 'rb2+pairs').  The oracle on 32 sampled frames (six positions; the reference cannot combine != 4 dials,
+    (tuned kernel, 4-row tiles in two K slices since round 5).  The oracle on 32 sampled frames (six positions; the reference cannot combine != 4 dials,
     meterelf/_reading.py:166), and what cannot depend on the batch: the same frames in ragged pieces and in permuted order."""
     import shutil
     from bench import config5_params_dir
@@ -542,7 +550,7 @@ def test_config5_resident_full_size(lay):
             buf.upload(frames)
             whole = reader.ctx.process_batch_dev(buf.p.value, n, H, W)
             info = reader.ctx.last_match()
-            assert (info['kernel'], info['layout'], info['n']) == ('mfma', 'rb2+pairs', n), info
+            assert (info['kernel'], info['layout'], info['n']) == ('mfma', EXPECTED_LAYOUT[512], n), info
             # ragged pieces of the same device buffer: 200 (general kernel) + 33 + 279 (tuned kernel's small layouts)
             fs = H * W * 3
             cuts = (0, 200, 233, 512)

@@ -80,6 +80,17 @@ for n in sizes:
             os.environ['MELF_MATCH_LAYOUT'] = '%d,%d' % (rb, np_)
             (t, inf) = timed(fast, n)
             row.append('rb%d,%d(%dw)=%.1f' % (rb, np_, inf['waves'], t))
+        # 4-row tiles in 2 / 4 K slices (round 5): the fewest pairs that fit one round
+        for ks in (2, 4):
+            for np_ in range(0, rh // 9 + 2):
+                na = max(0, -(-(rh - 9 * np_) // 4))
+                if (na + 2 * np_) * ((n + 31) // 32) * ks <= 1024 or np_ == rh // 9 + 1:
+                    if ccols - P.tw + 1 <= 32 and np_ > 0:
+                        break
+                    os.environ['MELF_MATCH_LAYOUT'] = '4,%d,%d' % (np_, ks)
+                    (t, inf) = timed(fast, n)
+                    row.append('rb4,%d/k%d(%dw)=%.1f' % (np_, ks, inf['waves'], t))
+                    break
         os.environ.pop('MELF_MATCH_LAYOUT', None)
     (t_gen, inf) = timed(gen, n)
     row.append('gen(%dw)=%.1f' % (inf['waves'], t_gen))
