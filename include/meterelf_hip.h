@@ -118,6 +118,13 @@ int melf_blob_params(const void* blob, size_t blob_bytes, melf_params* out);
 
 /* One context per GPU.  `blob` is a host pointer unless blob_on_device != 0. */
 int melf_ctx_create(int device, const void* blob, size_t blob_bytes, int blob_on_device, melf_ctx** out);
+/* One process, n GPUs (SURVEY 8b's `melf_ctx_bcast`, 8e; the reference has one process and no GPU: meterelf/_api.py:16-33):
+ * the host blob goes to devices[0] and from there to every other listed GPU by ONE ncclBroadcast (ncclUint8, root 0; RCCL
+ * over xGMI, bound with dlopen at the first call), and out[i] is created on devices[i] from that GPU's copy.  A device may
+ * not be listed twice.  All or nothing: on failure every out[i] is NULL.  (One process PER GPU broadcasts the same bytes
+ * through its own communicator -- torch.distributed in meterelf_amd/_dist.py -- and calls melf_ctx_create with
+ * blob_on_device = 1.) */
+int melf_ctx_create_bcast(const int* devices, int n, const void* blob, size_t blob_bytes, melf_ctx** out);
 void melf_ctx_destroy(melf_ctx* ctx);
 int melf_ctx_params(const melf_ctx* ctx, melf_params* out);
 /* Waits for all work the context has enqueued on caller streams and forgets those streams.  Call it before

@@ -77,6 +77,39 @@ def _acquire_reader(params, device: int = 0) -> MeterReader:
     return reader
 
 
+def _acquire_readers_bcast(params, devices: List[int]) -> Dict[int, MeterReader]:
+    """The fan-out's readers, one per DISTINCT device: idle ones from the cache, the others created together -- the calibration
+    blob uploaded to the first missing device and broadcast to the rest by RCCL over xGMI (melf_ctx_create_bcast; north_star:
+    "RCCL broadcast of the template/params").  {} when that is not possible (a device listed twice, no RCCL, an error): the
+    workers then create their contexts one by one from the host blob, which is equivalent."""
+    if len(set(devices)) != len(devices) or len(devices) < 2 or os.getenv('METERELF_BCAST', '1') == '0':
+        return {}
+    blob = make_blob(params)
+    out: Dict[int, MeterReader] = {}
+    missing = []
+    for (w, d) in enumerate(devices):
+        key = _reader_key(params, blob, d)
+        with _idle_lock:
+            r = _idle_readers.pop(key, None)
+        if r is not None:
+            r._cache_key = key
+            out[w] = r
+        else:
+            missing.append(w)
+    if missing:
+        try:
+            ctxs = _hip.Context.create_bcast(blob, [devices[w] for w in missing])
+        except Exception:
+            for r in out.values():
+                _release_reader(r)
+            return {}
+        for (w, ctx) in zip(missing, ctxs):
+            r = MeterReader(params, device=devices[w], blob=blob, ctx=ctx)
+            r._cache_key = _reader_key(params, blob, devices[w])
+            out[w] = r
+    return out
+
+
 def _release_reader(reader: MeterReader) -> None:
     key = getattr(reader, '_cache_key', None)
     limit = int(os.getenv('METERELF_CTX_CACHE_MAX', str(max(_IDLE_MAX, 2 * _devices_used))))
@@ -155,9 +188,10 @@ def api_stats(reset: bool = True) -> dict:
     return out
 
 
-def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode: bool, batch: int) -> Iterator[List[MeterImageData]]:
-    """One device's pipeline: chunk lists in, one list of MeterImageData per chunk out, in order."""
-    reader: Optional[MeterReader] = None
+def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode: bool, batch: int,
+                    reader: Optional[MeterReader] = None) -> Iterator[List[MeterImageData]]:
+    """One device's pipeline: chunk lists in, one list of MeterImageData per chunk out, in order.  `reader`: made by the caller
+    (the fan-out's broadcast-created contexts); handed back to the cache or closed here like one made here."""
     nthreads = max(1, int(os.getenv('METERELF_DECODE_THREADS', str(min(8, os.cpu_count() or 1)))))
     pool = ThreadPoolExecutor(max_workers=nthreads) if (nthreads > 1 and batch > 1) else None
 
@@ -365,7 +399,7 @@ def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode
                 if item is _STOP:
                     return
                 yield item
-        gen = _process_chunks(params, feed(), devices[w], gpu_decode, batch)
+        gen = _process_chunks(params, feed(), devices[w], gpu_decode, batch, reader=pre.get(w))
         try:
             for items in gen:
                 outq[w].put(items)
@@ -375,6 +409,7 @@ def _fan_out(params, chunks: Iterator[List[str]], devices: List[int], gpu_decode
             gen.close()
             outq[w].put(_STOP)
 
+    pre = _acquire_readers_bcast(params, devices) if MeterReader is _REAL_READER else {}
     threads = [threading.Thread(target=work, args=(w,), name='meterelf-dev%d-%d' % (devices[w], w), daemon=True) for w in range(nw)]
     # The workers and this thread hand the interpreter lock to each other once per chunk (a worker converts a chunk's records,
     # this thread yields them); a thread that wants the lock while another runs Python code waits up to one switch interval --

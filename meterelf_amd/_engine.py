@@ -124,12 +124,12 @@ def records_to_items(records: np.ndarray, ok, dial_names: List[str], filenames: 
 
 
 class MeterReader:
-    def __init__(self, params: Params, device: int = 0, blob: Optional[np.ndarray] = None) -> None:
+    def __init__(self, params: Params, device: int = 0, blob: Optional[np.ndarray] = None, ctx: Optional['_hip.Context'] = None) -> None:
         self.params = params
         self.device = device
         self.dial_names = params.dial_names
         self.blob = blob if blob is not None else make_blob(params)
-        self.ctx = _hip.Context(self.blob, device)
+        self.ctx = ctx if ctx is not None else _hip.Context(self.blob, device)   # ctx: created elsewhere from the same blob (broadcast)
         self._crop_ctx: Dict[Tuple[int, int], _hip.Context] = {}
         self._begun: list = []      # read_jpeg_paths_begin: path lists in flight, oldest first
         self._collected: list = []  # their results taken out of the library early (drain_jpeg_paths), oldest first

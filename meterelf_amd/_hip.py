@@ -75,7 +75,7 @@ class HipError(RuntimeError):
 # every symbol include/meterelf_hip.h declares
 EXPORTS = [
     'melf_last_error', 'melf_abi_version', 'melf_device_count', 'melf_build_dial_masks',
-    'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_destroy',
+    'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_create_bcast', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_sync', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
     'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_stream_probe_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_match_gen_plan_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
@@ -107,6 +107,7 @@ def lib():
     L.melf_blob_pack.argtypes = [C.POINTER(MelfParams), vp, vp, C.c_size_t]
     L.melf_blob_params.argtypes = [vp, C.c_size_t, C.POINTER(MelfParams)]
     L.melf_ctx_create.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.melf_ctx_create_bcast.argtypes = [C.POINTER(C.c_int), C.c_int, vp, C.c_size_t, C.POINTER(vp)]
     L.melf_ctx_destroy.argtypes = [vp]
     L.melf_ctx_destroy.restype = None
     L.melf_ctx_params.argtypes = [vp, C.POINTER(MelfParams)]
@@ -307,6 +308,27 @@ class Context:
         self.device = device
         self.params = MelfParams()
         check(L.melf_ctx_params(self._h, C.byref(self.params)))
+
+    @classmethod
+    def create_bcast(cls, blob, devices):
+        """One context per listed GPU of THIS process, the blob sent to devices[0] and broadcast from there by RCCL
+        (melf_ctx_create_bcast).  Devices must be distinct.  Returns the contexts in the order of `devices`."""
+        L = lib()
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        n = len(devices)
+        devs = (C.c_int * n)(*[int(d) for d in devices])
+        handles = (C.c_void_p * n)()
+        check(L.melf_ctx_create_bcast(devs, n, _ptr(blob), blob.nbytes, handles))
+        out = []
+        for (d, h) in zip(devices, handles):
+            c = cls.__new__(cls)
+            c._h = C.c_void_p(h)
+            c._L = L
+            c.device = int(d)
+            c.params = MelfParams()
+            check(L.melf_ctx_params(c._h, C.byref(c.params)))
+            out.append(c)
+        return out
 
     def sync(self):
         """Waits for the context's work on every caller stream and forgets the streams (call before destroying one)."""

