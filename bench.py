@@ -589,7 +589,8 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
     ceiling = None
     if hasattr(ctx, 'stream_probe_dev'):
         in_bytes = FB * H * W * 3
-        variants = [('static', 0), ('static_prefetch', -1), ('queue2', 2), ('queue4', 4)]
+        variants = [('static', 0), ('static_prefetch', -1), ('queue2', 2), ('queue4', 4), ('comb', -2), ('comb_stride48', -3), ('comb_stride48_barriers', -4),
+                    ('comb_stride48_barriers_tables', -5)]
         ctx.set_profiling(1)
         ctx.timings()
         rounds = max(6, min(steps, 24))

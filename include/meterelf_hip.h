@@ -167,8 +167,10 @@ int melf_hls_inrange_close_dev(melf_ctx* ctx, const void* d_frames, int n, int H
  * of a BARE persistent stream with the fused kernel's traffic mix and launch shape -- 48 bytes read and 16 bytes written per
  * thread and step, no pixel arithmetic -- over the caller's device buffers: floor(in_bytes / 48 KiB) chunks of d_in are read,
  * a third as many bytes of d_out are overwritten with garbage (XOR of the input: point it at a mask buffer that is rewritten
- * afterwards).  chunks_per_block = 0: static grid-stride split; < 0: the same with the kernel's register prefetch (the next
- * chunk requested before this one is stored); > 0: blocks of that many chunks from a work queue.  The launch
+ * afterwards).  chunks_per_block = 0: static grid-stride split; -1: the same with the kernel's register prefetch (the next
+ * chunk requested before this one is stored); -2 .. -5: every workgroup walks its own contiguous run of chunks like the kernel's
+ * segments (-3: + the kernel's 48-byte lane stride, -4: + two barriers and an LDS hand-over per step, -5: + 64 KiB of LDS
+ * tables filled first); > 0: blocks of that many chunks from a work queue.  The launch
  * is timed like the fused kernel's (melf_ctx_set_profiling(1), entry MELF_K_STREAM_PROBE of melf_ctx_timings). */
 int melf_stream_probe_dev(melf_ctx* ctx, const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, void* stream);
 

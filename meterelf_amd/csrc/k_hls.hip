@@ -1078,6 +1078,45 @@ __global__ __launch_bounds__(1024) void k_stream_probe_prefetch(const u32x4* __r
     }
 }
 
+// "comb" variants (what the fused kernel's static split does): every workgroup walks its OWN contiguous run of chunks, top to
+// bottom, instead of all workgroups sweeping one moving window; STRIDE48: with the kernel's lane pattern on top (a thread's 48
+// bytes are contiguous: three 16-byte loads at a 48-byte lane stride); BARRIERS: two workgroup barriers per step and the
+// 16-bit-per-thread LDS hand-over of the kernel's passes; TABLES: the kernel's 64 KiB of static LDS, filled before the first step.
+template <bool STRIDE48, bool BARRIERS, bool TABLES>
+__global__ __launch_bounds__(1024) void k_stream_probe_comb(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t nchunks)
+{
+    __shared__ uint32_t ring[BARRIERS ? 2048 : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t tables[TABLES ? 16384 : 4];
+    const int tid = threadIdx.x;
+    const uint32_t per = (nchunks + gridDim.x - 1) / gridDim.x;
+    const size_t c0 = (size_t)blockIdx.x * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    if (c0 >= c1) return;
+    auto src = [&](size_t c, int k) -> const u32x4* { return STRIDE48 ? in + c * 3072 + 3 * tid + k : in + c * 3072 + 1024 * k + tid; };
+    u32x4 a = *src(c0, 0), b = *src(c0, 1), d = *src(c0, 2);
+    if (TABLES) {
+        for (int i = tid; i < 4096; i += 1024) *(u32x4*)(tables + 4 * i) = u32x4{(uint32_t)i, 0u, 0u, 0u};
+        __syncthreads();
+    }
+    uint32_t acc = 0;
+    for (size_t c = c0; c < c1; ++c) {
+        const size_t cn = c + 1 < c1 ? c + 1 : c;   // register prefetch of the next chunk, as the kernel
+        const u32x4 a2 = *src(cn, 0), b2 = *src(cn, 1), d2 = *src(cn, 2);
+        u32x4 o;
+        o.x = a.x ^ b.x ^ d.x; o.y = a.y ^ b.y ^ d.y; o.z = a.z ^ b.z ^ d.z; o.w = a.w ^ b.w ^ d.w;
+        if (TABLES) o.x ^= tables[(o.y & 255u) * 64 + (tid & 31)];
+        if (BARRIERS) {
+            ((uint16_t*)ring)[tid] = (uint16_t)o.x;
+            __syncthreads();
+            acc = ring[(tid >> 1) ^ 1];
+            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            o.w ^= acc;
+        }
+        __builtin_nontemporal_store(o, out + c * 1024 + tid);
+        a = a2; b = b2; d = d2;
+    }
+}
+
 template <bool DYN>
 __global__ __launch_bounds__(1024) void k_stream_probe(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint32_t nchunks, uint32_t CH,
                                                        uint32_t* __restrict__ wq)
@@ -1110,14 +1149,24 @@ __global__ __launch_bounds__(1024) void k_stream_probe(const u32x4* __restrict__
     }
 }
 
-// chunks_per_block = 0: static split; < 0: static split with one chunk of register prefetch; > 0: work queue.  Streams floor(in_bytes / 48 KiB) chunks; returns the bytes moved (in + out).
+// chunks_per_block = 0: static split; -1: static split with one chunk of register prefetch; -2 .. -5: the "comb" variants (own
+// contiguous run per workgroup; + 48-byte lane stride; + barriers and an LDS hand-over; + 64 KiB of LDS tables); > 0: work queue.  Streams floor(in_bytes / 48 KiB) chunks; returns the bytes moved (in + out).
 size_t launch_stream_probe(const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, uint32_t* d_tables, hipStream_t stream,
                            hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const uint32_t nchunks = (uint32_t)std::min<size_t>(in_bytes / (48 * 1024), 0x7fffffffu);
     if (!nchunks) return 0;
     const int grid = (int)std::min<uint32_t>(512u, nchunks);
-    if (chunks_per_block < 0) {
+    if (chunks_per_block <= -2) {
+#define MELF_COMB(S, B, T) hipExtLaunchKernelGGL((k_stream_probe_comb<S, B, T>), dim3(grid), dim3(1024), 0, stream, ev_start, ev_stop, 0, (const u32x4*)d_in, (u32x4*)d_out, nchunks)
+        switch (chunks_per_block) {
+            case -2: MELF_COMB(false, false, false); break;
+            case -3: MELF_COMB(true, false, false); break;
+            case -4: MELF_COMB(true, true, false); break;
+            default: MELF_COMB(true, true, true); break;
+        }
+#undef MELF_COMB
+    } else if (chunks_per_block < 0) {
         hipExtLaunchKernelGGL(k_stream_probe_prefetch, dim3(grid), dim3(1024), 0, stream, ev_start, ev_stop, 0, (const u32x4*)d_in, (u32x4*)d_out, nchunks);
     } else if (chunks_per_block > 0) {
         static std::atomic<unsigned> slot{0};

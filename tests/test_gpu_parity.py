@@ -904,9 +904,10 @@ def test_ctx_create_bcast_one_device(env):
     blob = _engine.make_blob(e['params'])
     (ctx,) = _hip.Context.create_bcast(blob, [0])
     try:
-        frames = e['frames'][:12]
+        from meterelf_amd._image import imread_bgr
+        frames = np.stack([imread_bgr(f) for f in e['files'][2:14]])
         assert ctx.process_batch(frames).tobytes() == e['reader'].ctx.process_batch(frames).tobytes()
-        assert np.array_equal(ctx.get_masks(), e['reader'].ctx.get_masks())
+        assert np.array_equal(ctx.masks(), e['reader'].ctx.masks())
     finally:
         ctx.close()
 
