@@ -299,7 +299,12 @@ struct Px16 {
 };
 
 // 16 pixels -> 16 in-range bits (bit k = pixel k)
-template <int VAR>
+// REP (interval variants): copies of every table row.  32: one per lane of a 32-lane group, conflict-free, 64 KiB -- two
+// 1024-thread workgroups per CU.  8 / 16 (round 5): lanes l and l + REP share a copy (rows r and r' of a copy fall on the same
+// bank when r = r' mod 32 / REP: about two-way conflicts on the two table reads per pixel), 16 / 32 KiB -- eight 256-thread or
+// four 512-thread workgroups per CU: four times / twice as many, shorter passes per workgroup, i.e. less pipeline fill and drain
+// in a launch that gives every workgroup only ten passes (BASELINE config 2).
+template <int VAR, int REP = 32>
 __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __restrict__ hue,
                                               const uint32_t* __restrict__ ls, int hue_shift, const Bounds& B)
 {
@@ -316,10 +321,12 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
     // bank (no LDS conflicts).  A table address is the byte vector {lane * 4 (+128), row, base >> 16, 0}:
     // one v_perm / one SDWA subtract into byte 1 builds it.
     typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
-    const uint32_t ls_lane = (uint32_t)(uintptr_t)ls + (threadIdx.x & 31u) * 4u;
+    const uint32_t ls_lane = (uint32_t)(uintptr_t)ls + (threadIdx.x & (uint32_t)(REP - 1)) * 4u;
+    const uint32_t hue_lane = (uint32_t)(uintptr_t)hue + (threadIdx.x & (uint32_t)(REP - 1)) * 4u;
+    constexpr int ROWSH = REP == 32 ? 8 : (REP == 16 ? 6 : 5);   // log2(bytes per table row): REP < 32 keeps hI and lsI in arrays of their own
     uint32_t haddr[4];  // four hue addresses in flight
 #pragma unroll
-    for (int q = 0; q < 4; ++q) haddr[q] = (uint32_t)(uintptr_t)hue + (threadIdx.x & 31u) * 4u;
+    for (int q = 0; q < 4; ++q) haddr[q] = hue_lane;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int j = (3 * k) >> 2, sh = ((3 * k) & 3) * 8;
@@ -334,9 +341,15 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
             const uint32_t Q = (d[iQ >> 2] >> ((iQ & 3) * 8)) & 255u;
             const uint32_t S = (d[iS >> 2] >> ((iS & 3) * 8)) & 255u;
             const uint32_t mn = min(Q, S);
+            uint32_t lse, hie;
+            if constexpr (REP != 32) {
+                const uint32_t P = (d[iP >> 2] >> ((iP & 3) * 8)) & 255u;
+                lse = *(lds_u32)(uintptr_t)(ls_lane + (P << ROWSH));
+                hie = *(lds_u32)(uintptr_t)(hue_lane + (((P - mn) & 255u) << ROWSH));   // negative differences alias harmlessly (below)
+            } else {
             // lsI row P: address bytes {lane*4, P, base, 0}
             const uint32_t lso = __builtin_amdgcn_perm(d[iP >> 2], ls_lane, 0x0c020000u | ((4u + (iP & 3)) << 8));
-            const uint32_t lse = *(lds_u32)(uintptr_t)lso;
+            lse = *(lds_u32)(uintptr_t)lso;
             // hI row (P - mn) & 255, written into byte 1 of the address register.  Negative differences
             // alias onto real rows, which is harmless: then mn > P and no lsI row P holds a minimum above P.
             switch (iP & 3) {
@@ -345,7 +358,8 @@ __device__ __forceinline__ uint32_t inrange16(const Px16& in, const uint32_t* __
                 case 2: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
                 default: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(haddr[k & 3]) : "v"(d[iP >> 2]), "v"(mn)); break;
             }
-            const uint32_t hie = *(lds_u32)(uintptr_t)haddr[k & 3];
+            hie = *(lds_u32)(uintptr_t)haddr[k & 3];
+            }
             // compares straight into lane masks (v_cmp -> SGPR pair), combined on the scalar unit
             const uint64_t m_ls = __builtin_amdgcn_uicmp((uint32_t)((int)mn - (int)(int16_t)(lse & 0xffffu)), lse >> 16, 36 /* ult */);
             const uint64_t m_h = __builtin_amdgcn_uicmp((uint32_t)((int)Q - ((int)S + (int)(int16_t)(hie & 0xffffu))), hie >> 16, 36);
@@ -427,7 +441,7 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_fused_stamps(ui
 #endif
 
 template <int VAR, int THREADS, int PD /* passes prefetched ahead in registers, 0 = none */, int WPS /* waves per SIMD the register budget must allow */,
-          int MODE = 0 /* PD == 1 only.  1: segments from the launch's work queue instead of the static split (experiment, no gain);
+          int REP /* copies of an interval-table row (inrange16) */, int MODE = 0 /* PD == 1 only.  1: segments from the launch's work queue instead of the static split (experiment, no gain);
                           2: static split, EARLY refill: the rows of pass p + 2 are requested as soon as pass p's in-range test has
                           consumed its register set (into that set), not at the start of pass p + 1 -- 1.7 passes of lead for the
                           loads instead of 1.0 with the same two register sets, two passes requested before anything is computed,
@@ -451,12 +465,14 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
     constexpr bool AMB = VAR == 4;
     constexpr bool IV = VAR >= 6;
     constexpr bool SINGLE = VAR < 3 || VAR == 5;
-    constexpr int HDW = IV ? 256 * 64 /* both interval tables, interleaved by row */ : (AMB ? HUE2_DWORDS : (SINGLE ? HUES_DWORDS : HUE1_DWORDS));
+    static_assert(REP == 32 || (IV && (REP == 8 || REP == 16)), "row copies: 32, or 8 / 16 for the interval tables");
+    constexpr int HDW = IV ? 256 * 2 * REP /* both interval tables: interleaved by row (REP 32), one behind the other (REP < 32) */
+                           : (AMB ? HUE2_DWORDS : (SINGLE ? HUES_DWORDS : HUE1_DWORDS));
     constexpr int LSDW = IV ? 4 /* lives inside hue[] */ : LS_DWORDS;
     // tables in static LDS (their addresses fold into the ds_read offset field), rings in dynamic LDS
-    __shared__ __attribute__((aligned(IV ? 65536 : 16))) uint32_t hue[HDW];
+    __shared__ __attribute__((aligned(IV && REP == 32 ? 65536 : 16))) uint32_t hue[HDW];
     __shared__ __attribute__((aligned(16))) uint32_t ls_own[LSDW];
-    uint32_t* const ls = IV ? hue + 32 : ls_own;
+    uint32_t* const ls = IV ? hue + (REP == 32 ? 32 : 256 * REP) : ls_own;
     __shared__ uint32_t expand4[16];  // 4 mask bits -> 4 mask bytes
     extern __shared__ uint32_t ring[];
     const int wpr = (W + 31) >> 5;
@@ -485,10 +501,18 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                 const uint32_t vh = DYN ? pre_vh : g_tables[OFF_HI + (VAR - 6) * HI_ROWS + 256 + r];
                 const uint32_t vl = DYN ? pre_vl : g_tables[OFF_LSI + (VAR - 6) * LSI_ROWS + r];
                 const u32x4 h4 = {vh, vh, vh, vh}, l4 = {vl, vl, vl, vl};
+                if constexpr (REP == 32) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    *(u32x4*)(hue + r * 64 + q * 4) = h4;
-                    *(u32x4*)(hue + r * 64 + 32 + q * 4) = l4;
+                    for (int q = 0; q < 8; ++q) {
+                        *(u32x4*)(hue + r * 64 + q * 4) = h4;
+                        *(u32x4*)(hue + r * 64 + 32 + q * 4) = l4;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < REP / 4; ++q) {
+                        *(u32x4*)(hue + r * REP + q * 4) = h4;
+                        *(u32x4*)(hue + 256 * REP + r * REP + q * 4) = l4;
+                    }
                 }
             }
         } else {
@@ -576,13 +600,13 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                     const u32x4* sp = (const u32x4*)(stage_base + (size_t)dma_slot * npieces * 1024 + (size_t)tid * 48);
                     Px16 px;
                     px.q0 = sp[0]; px.q1 = sp[1]; px.q2 = sp[2];
-                    bits = inrange16<VAR>(px, hue, ls, hue_shift, B);
+                    bits = inrange16<VAR, REP>(px, hue, ls, hue_shift, B);
                 }
                 bits = (y >= 0 && y < H) ? bits : 0u;
                 if (active && y < r1 + 2) ((uint16_t*)raw)[__umul24((y + 4 * NB) & nbm, wpr * 2) + tg] = (uint16_t)bits;
             } else if (PREFETCH) {
                 const int y = a + trow;
-                uint32_t bits = inrange16<VAR>(cur, hue, ls, hue_shift, B);
+                uint32_t bits = inrange16<VAR, REP>(cur, hue, ls, hue_shift, B);
                 if (EARLY && refill_a != INT_MIN) load_from(frame, refill_a, min(r1 + 1, H - 1), cur);   // (uniform) the set is free: pass p + 2's rows
                 bits = (y >= 0 && y < H) ? bits : 0u;
                 if (active && y < r1 + 2) ((uint16_t*)raw)[__umul24((y + 4 * NB) & nbm, wpr * 2) + tg] = (uint16_t)bits;
@@ -595,7 +619,7 @@ __global__ __launch_bounds__(THREADS, WPS) void k_fused_mask_lut(
                         const u32x4* p = (const u32x4*)(frame + ((size_t)y * W + 16 * tg) * 3);
                         Px16 px;
                         px.q0 = p[0]; px.q1 = p[1]; px.q2 = p[2];
-                        bits = inrange16<VAR>(px, hue, ls, hue_shift, B);
+                        bits = inrange16<VAR, REP>(px, hue, ls, hue_shift, B);
                     }
                     ((uint16_t*)raw)[((y + 4 * NB) & nbm) * wpr * 2 + tg] = (uint16_t)bits;
                 }
@@ -866,7 +890,7 @@ static int g_fused_config = -1;  // -1: per-variant default
 static thread_local hipEvent_t g_fused_ev_start = nullptr, g_fused_ev_stop = nullptr;
 void fused_mask_timing_events(hipEvent_t start, hipEvent_t stop) { g_fused_ev_start = start; g_fused_ev_stop = stop; }
 
-template <int V, int T, int PF, int WPS>
+template <int V, int T, int PF, int WPS, int REP = 32>
 static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
                          uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
@@ -884,7 +908,11 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
             if (RC <= 1 || 65664 + ringb + 2 * sb <= 160 * 1024) break;   // 65 600 bytes of static LDS (tables, expand table)
         }
     }
-    const int per_cu = PF < 0 ? 1 : WPS * 256 / T;          // resident workgroups per CU
+    int per_cu = PF < 0 ? 1 : WPS * 256 / T;                // resident workgroups per CU
+    if (REP != 32) {   // small tables: LDS (tables + this shape's rings) may admit one workgroup fewer than the wave count does
+        const size_t lds_wg = (size_t)256 * 2 * REP * 4 + 128 + (size_t)(2 * NB * wpr) * sizeof(uint32_t);
+        per_cu = std::min<int>(per_cu, (int)(160 * 1024 / lds_wg));
+    }
     const int target = 256 * (per_cu < 1 ? 1 : per_cu);
     static const int seg_mult = getenv("MELF_FUSED_SEGMULT") ? atoi(getenv("MELF_FUSED_SEGMULT")) : 1;  // experiments
     static const int plain_store = getenv("MELF_FUSED_PLAINSTORE") ? atoi(getenv("MELF_FUSED_PLAINSTORE")) : 0;
@@ -900,7 +928,7 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // split, config 5 0.769-0.828 against 0.740-0.748: with one pass of register prefetch a workgroup that is alone on its CU
     // still saturates its share of HBM, so the early finishers cost nothing, and the queue's segments pay their halo rows.
     // The default stays the static split; MELF_FUSED_DYN=N switches the queue on (tests keep it honest).
-    const int dyn = PF == 1 ? (getenv("MELF_FUSED_DYN") ? atoi(getenv("MELF_FUSED_DYN")) : 0) : 0;
+    const int dyn = (PF == 1 && REP == 32 && T == 1024) ? (getenv("MELF_FUSED_DYN") ? atoi(getenv("MELF_FUSED_DYN")) : 0) : 0;
     const int grid_cap = getenv("MELF_FUSED_GRID") ? std::max(1, atoi(getenv("MELF_FUSED_GRID"))) : target;
     const int wgs = std::min(target, grid_cap);
     // MELF_FUSED_BIG = percent of a frame's rows dealt as one big first segment per workgroup (the queue then hands out the rest
@@ -938,10 +966,10 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, PF < 0 ? 160 * 1024 - 65664 : 28 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, REP>, hipFuncAttributeMaxDynamicSharedMemorySize, PF < 0 ? 160 * 1024 - 65664 : 28 * 1024);
         if (getenv("MELF_FUSED_TRACE")) {
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fused_mask_lut<V, T, PF, WPS>, T, shmem);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fused_mask_lut<V, T, PF, WPS, REP>, T, shmem);
             fprintf(stderr, "[melf fused] V=%d T=%d PD=%d WPS=%d grid=%d shmem=%zu resident blocks/CU=%d\n", V, T, PF, WPS, grid, shmem, nb);
         }
         attr_set[dev] = true;
@@ -949,7 +977,7 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // timing events (optional, set by the caller through fused_mask_timing_events): the dispatch's own start / stop stamps,
     // no event-record packets in the queue around the kernel
     const int ps = plain_store | ((getenv("MELF_FUSED_PRIO") ? atoi(getenv("MELF_FUSED_PRIO")) : 0) << 8);
-    if constexpr (PF == 1) {
+    if constexpr (PF == 1 && REP == 32 && T == 1024) {   // the two experiments below are instantiated for the default launch shapes only
         // early refill (round 5 experiment, MELF_FUSED_EARLY=1): measured no different from the refill at the start of the next
         // pass (config 2 0.0668 / 0.0681 against 0.0664 ms, config 5 0.782 / 0.824 against 0.781 / 0.820: profiles/r05/
         // fused_early_refill_ab.txt) -- the launch is not short of requests in flight.  Off by default.
@@ -957,10 +985,10 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
         if (early) {
             static bool early_attr_set[64] = {false};
             if (dev >= 0 && dev < 64 && !early_attr_set[dev]) {
-                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, REP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
                 early_attr_set[dev] = true;
             }
-            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, 2>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, REP, 2>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
                                   n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
             g_fused_ev_start = g_fused_ev_stop = nullptr;
             return;
@@ -968,16 +996,16 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
         if (wq) {
             static bool dyn_attr_set[64] = {false};
             if (dev >= 0 && dev < 64 && !dyn_attr_set[dev]) {
-                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, REP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
                 dyn_attr_set[dev] = true;
             }
-            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, 1>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, REP, 1>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
                                   n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, wq, big_segs, big_rows);
             g_fused_ev_start = g_fused_ev_stop = nullptr;
             return;
         }
     }
-    hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+    hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, REP>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
                           n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
     g_fused_ev_start = g_fused_ev_stop = nullptr;
 }
@@ -995,6 +1023,10 @@ static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_s
             case 5: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
             case 6: launch_lut_t<V, 1024, -1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;   // LDS-DMA staging
             case 0: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            // round 5: smaller tables (8 / 16 copies of a row), more and smaller workgroups per CU
+            case 8: if constexpr (V >= 6) { launch_lut_t<V, 256, 1, 8, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
+            case 9: if constexpr (V >= 6) { launch_lut_t<V, 512, 1, 8, 16>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
+            case 10: if constexpr (V >= 6) { launch_lut_t<V, 512, 1, 8, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
             default: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         }
     } else {
@@ -1024,7 +1056,7 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
     for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
     {   // read at every launch (a getenv is nothing beside a launch): tests and A/B scripts switch it inside one process
         const char* e = getenv("MELF_FUSED_CONFIG");
-        g_fused_config = e ? atoi(e) & 7 : -1;
+        g_fused_config = e ? atoi(e) & 15 : -1;
     }
     switch (variant) {
         case 0: launch_lut_v<0>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;

@@ -258,6 +258,26 @@ def test_fused_mask_early_refill(env, monkeypatch, grid):
             assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
 
 
+@pytest.mark.parametrize('config', [8, 9, 10])
+def test_fused_mask_small_table_launch_shapes(env, monkeypatch, config):
+    """MELF_FUSED_CONFIG=8 / 9 / 10 (round 5): 8 or 16 copies of every interval-table row instead of 32 (16 / 32 KiB of LDS), eight
+    256-thread or four 512-thread workgroups per CU.  Same masks as the oracle and the default launch: aligned, narrow, 1080p and a
+    full-size batch (every workgroup several passes, several segments per workgroup)."""
+    from oracle import pyoracle as po
+    ctx = env['sample-images1']['reader'].ctx
+    p = ctx.params
+    rng = np.random.default_rng(800 + config)
+    for (n, H, W) in ((2, 640, 480), (1, 1080, 1920), (3, 50, 64), (5, 101, 48), (64, 480, 640)):
+        frames = _blobby(rng, n, H, W)
+        monkeypatch.delenv('MELF_FUSED_CONFIG', raising=False)
+        ref = ctx.hls_inrange_close(frames)
+        monkeypatch.setenv('MELF_FUSED_CONFIG', str(config))     # read by the library at every fused launch
+        got = ctx.hls_inrange_close(frames)
+        assert np.array_equal(got, ref), (n, H, W, np.argwhere(got != ref)[:5])
+        for f in range(min(n, 2)):
+            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
+
+
 def test_fused_mask_lds_dma_launch_shape(env, monkeypatch):
     """MELF_FUSED_CONFIG=6 (round 4's experiment: pixel rows through LDS-DMA into two staging buffers, one workgroup per CU)
     must stay what it is measured as: the same masks as the oracle's, on an aligned and on a narrow shape and at 1080p."""
