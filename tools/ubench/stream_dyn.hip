@@ -2,7 +2,7 @@
 // kernel's traffic (48 B in, 16 B out per thread and step, persistent 1024-thread workgroups, two per CU)?
 // Round 4's per-workgroup clocks (profiles/r04/fused_workgroup_clock.txt) show the CU's two workgroups finishing 25 % apart under
 // the static split (oldest-first arbitration): the launch's last quarter runs with one workgroup per CU.
-//   static      : chunk c = blockIdx + k * grid                       (tools/ubench/stream_lds.hip, "3:1 plain")
+//   static      : chunk c = blockIdx + k * grid                       (the "3:1 plain" stream of round 4's stream_lds microbenchmark, profiles/r04/fused_split_and_lds_stream.txt)
 //   dynamic/CH  : blocks of CH consecutive chunks from an atomic counter, the next block's index fetched one block ahead
 // Also prints the spread of the workgroups' end times (100 MHz real-time clock) for both.
 #include <hip/hip_runtime.h>
