@@ -265,7 +265,7 @@ int melf_jpeg_process_files_end(melf_ctx* ctx);
  * [1] files, [2] read stage (open / fstat / read / close / header parse on the I/O pool), [3] waiting for the call's turn at the
  * context, [4] enqueueing (chunk layout, uploads, launches) until the context is handed to the next call, [5] waiting for the
  * call's kernels and records; [6] threads of the read stage, [7] of the other host loops (the caller included), [8] cores the
- * process may run on (affinity mask), [9] devices the process has contexts on (what the pools divide the cores by).
+ * process may use (affinity mask cut down to the cgroup CPU quota), [9] devices the process has contexts on (what the pools divide the cores by).
  * Not while a _begin call is in flight. */
 /* Measurement aid: open() + close() of every path on the I/O pool of `device` (no context needed, nothing is read):
  * milliseconds for the n files and the threads that took part -- what the file system allows the read stage. */

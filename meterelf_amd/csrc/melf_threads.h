@@ -3,6 +3,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <mutex>
@@ -117,11 +118,25 @@ inline void pool_note_device(int device) { g_pool_device_mask.fetch_or(1ull << (
 inline int pool_devices() { const int n = __builtin_popcountll(g_pool_device_mask.load()); return n < 1 ? 1 : n; }
 inline unsigned pool_cores()
 {
+    // the cores this process may USE: its affinity mask, cut down to the container's CPU quota (cgroup v2 cpu.max, v1
+    // cfs_quota_us / cfs_period_us) -- the pool's boxes show 256 cores and allow 16; threads beyond the quota get the whole
+    // process throttled for the rest of the scheduler period
     static const unsigned n = []() -> unsigned {
+        unsigned cores = std::max<unsigned>(std::thread::hardware_concurrency(), 2u);
         cpu_set_t set;
         CPU_ZERO(&set);
-        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (unsigned)CPU_COUNT(&set);
-        return std::max<unsigned>(std::thread::hardware_concurrency(), 2u);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) cores = (unsigned)CPU_COUNT(&set);
+        long long quota = -1, period = 0;
+        if (FILE* fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(fp, "%31s %lld", q, &period) == 2 && q[0] != 'm') quota = atoll(q);
+            fclose(fp);
+        } else {
+            if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+            if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fq, "%lld", &period) != 1) period = 0; fclose(fq); }
+        }
+        if (quota > 0 && period > 0) cores = std::min<unsigned>(cores, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        return std::max(cores, 1u);
     }();
     return n;
 }
