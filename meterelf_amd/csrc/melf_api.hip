@@ -627,9 +627,26 @@ Rccl& rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, []() {
+        // The RCCL that belongs to THIS library's HIP runtime: the one next to the libamdhip64 our HIP calls resolve to (a process
+        // may hold a second runtime and a second RCCL -- torch ships its own and loads them by path -- and device memory of one
+        // runtime is foreign to the other).  RTLD_LOCAL: its symbols must not interpose on another copy loaded later (round 5:
+        // with RTLD_GLOBAL a process that imported torch afterwards died in exit() with a double free).
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so.1");
+                names.push_back(dir + "/librccl.so");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
         void* h = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        for (const std::string& name : names) {
+            h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (h) break;
         }
         if (!h) { r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "?"); return; }
