@@ -308,6 +308,7 @@ struct melf_ctx {
     size_t file_arena_cap[NFJ] = {};
     JpegParsed* files_parsed[NFJ] = {};     // the slot's parsed headers + decode data (re-used call after call)
     size_t file_arena_per_file[NFJ] = {};   // arena bytes per file of the slot's last call: sizes the arena for the next one
+    int file_arena_oversized[NFJ] = {};     // consecutive calls that needed less than a quarter of the slot's arena
     std::deque<FilesJob*> files_jobs;      // oldest first
     uint64_t files_next_ticket = 0;        // of the next _begin
     uint64_t files_decode_turn = 0;        // the ticket whose decode stage may run
@@ -1958,8 +1959,15 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
         const size_t per_file = c->file_arena_per_file[slot] ? c->file_arena_per_file[slot] : (size_t)48 << 10;
         // (grown with room to spare: lists of slightly different sizes must not replace the arena call after call)
         const size_t need = std::min<size_t>((size_t)n * (per_file + per_file / 8) + (1u << 20), (size_t)2 << 30);
-        const size_t want = need > c->file_arena_cap[slot] ? need + need / 2 : 0;
-        if (want > c->file_arena_cap[slot]) {
+        size_t want = need > c->file_arena_cap[slot] ? need + need / 2 : 0;
+        // ... and given back (advisor, round 4: the arenas were grow-only, up to 3 GiB of pinned memory per slot after one list of
+        // large files): a slot whose arena is more than four times what its calls need, sixteen calls in a row, gets a fitting one
+        if (!want && c->file_arena_cap[slot] > ((size_t)64 << 20) && c->file_arena_cap[slot] > 4 * need) {
+            if (++c->file_arena_oversized[slot] >= 16) want = need + need / 2;
+        } else {
+            c->file_arena_oversized[slot] = 0;
+        }
+        if (want && want != c->file_arena_cap[slot]) {
             HIP_TRY(hipSetDevice(c->device));
             if (c->file_arena[slot]) HIP_TRY(hipHostFree(c->file_arena[slot]));
             c->file_arena[slot] = nullptr;

@@ -496,6 +496,15 @@ def test_files_that_outgrow_the_pinned_arena(tmp_path):
             (got, status, hw) = reader.ctx.jpeg_process_files(many)
             assert hw == (640, 480) and (status[:-1] == 0).all() and status[-1] == _hip.JPEG_UNREADABLE, attempt
             assert got[:-1].tobytes() == ref.tobytes(), attempt
+        # an arena grown for one long list (2100 files: 75 MB) is given back after sixteen calls that need less than a quarter of it
+        # (round 5; the advisor's round-4 finding: the pinned arenas were grow-only) -- and grows again when it has to
+        (big, bstatus, _hw) = reader.ctx.jpeg_process_files(many[:-1] * 7)
+        assert (bstatus == 0).all() and big[:300].tobytes() == ref.tobytes() and big[-300:].tobytes() == ref.tobytes()
+        for k in range(18):
+            (r1, s1, _hw) = reader.ctx.jpeg_process_files(tiny)
+            assert (s1 == 0).all() and r1.tobytes() == r0.tobytes(), k
+        (got, status, hw) = reader.ctx.jpeg_process_files(many)
+        assert (status[:-1] == 0).all() and status[-1] == _hip.JPEG_UNREADABLE and got[:-1].tobytes() == ref.tobytes()
         # and through the begin / end pair, every slot's first big call after a small one
         for k in range(_hip.FILES_IN_FLIGHT_MAX):
             reader.ctx.jpeg_process_files_begin(tiny)
