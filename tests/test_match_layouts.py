@@ -376,12 +376,14 @@ def test_wide_crops_pick_a_kernel_that_can_launch(lay, rows, cols, want):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('th,tw,rows,cols', [(100, 170, 160, 220), (91, 190, 130, 230), (61, 163, 200, 190), (120, 188, 250, 250)],
+@pytest.mark.parametrize('th,tw,rows,cols', [(100, 170, 160, 220), (91, 190, 130, 230), (61, 163, 200, 190), (120, 188, 250, 250),
+                                             (121, 180, 200, 240), (133, 175, 170, 210)],
                          ids=lambda v: str(v))
 def test_other_template_heights_in_every_layout(tmp_path, monkeypatch, th, tw, rows, cols):
     """Templates whose height is NOT one short of the padded height (the fixture's 119 -> 120): up to 29 zero template
-    rows, for which the waves must add an all-zero row-window-sum row, in every layout (forced).  Whole maps against the
-    oracle and the VALU kernel."""
+    rows -- with K slices (round 5) a whole slice of a short template can be padding, and 121 / 133 rows in four slices pad to 240 --
+    for which the waves must add an all-zero row-window-sum row, in every layout (forced).  Whole maps against the oracle and the
+    VALU kernel."""
     from oracle import pyoracle as po
     from tests.test_gpu_parity import _reader_with_template
     rng = np.random.default_rng(th * 1000 + tw)
@@ -403,12 +405,13 @@ def test_other_template_heights_in_every_layout(tmp_path, monkeypatch, th, tw, r
     monkeypatch.setenv('MELF_MATCH', 'fast')
     r = _reader_with_template(tmp_path / 'fast', tpl)
     try:
-        for (rb, pairs) in ((2, 0), (2, 3), (3, 0), (3, 2), (4, 0), (4, 1), (5, 0)):
-            monkeypatch.setenv('MELF_MATCH_LAYOUT', '%d,%d' % (rb, pairs))
+        for (rb, pairs, ks) in ((2, 0, 1), (2, 3, 1), (3, 0, 1), (3, 2, 1), (4, 0, 1), (4, 1, 1), (5, 0, 1), (4, 0, 2), (4, 1, 2), (4, 0, 4), (4, 2, 4)):
+            monkeypatch.setenv('MELF_MATCH_LAYOUT', '%d,%d,%d' % (rb, pairs, ks))
             (mv, mx, my, rmap) = r.ctx.match_ccoeff(imgs, want_map=True)
             info = r.ctx.last_match()
-            assert info['kernel'] == 'mfma' and info['rows_per_wave'] == rb, info
-            assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32)), (rb, pairs)
+            assert info['kernel'] == 'mfma' and info['rows_per_wave'] == rb and info['k_slices'] == ks, info
+            assert info['th_pad'] % ks == 0 and info['th_pad'] >= th, info
+            assert np.array_equal(rmap.view(np.uint32), rmapd.view(np.uint32)), (rb, pairs, ks)
             assert (mv.tobytes(), mx.tobytes(), my.tobytes()) == (mvd.tobytes(), mxd.tobytes(), myd.tobytes())
     finally:
         r.close()
