@@ -103,10 +103,18 @@ def _acquire_readers_bcast(params, devices: List[int]) -> Dict[int, MeterReader]
             for r in out.values():
                 _release_reader(r)
             return {}
-        for (w, ctx) in zip(missing, ctxs):
-            r = MeterReader(params, device=devices[w], blob=blob, ctx=ctx)
-            r._cache_key = _reader_key(params, blob, devices[w])
-            out[w] = r
+        try:
+            for (w, ctx) in zip(missing, ctxs):
+                r = MeterReader(params, device=devices[w], blob=blob, ctx=ctx)
+                r._cache_key = _reader_key(params, blob, devices[w])
+                out[w] = r
+        except Exception:     # nothing of a half-made set survives: the workers start from scratch
+            for ctx in ctxs:
+                ctx.close()
+            for r in out.values():
+                if getattr(r, 'ctx', None) not in ctxs:
+                    _release_reader(r)
+            return {}
     return out
 
 
