@@ -43,3 +43,11 @@ for (label, a, b) in (('  pixel phase: candidate prefilter', 2, 6), ('  pixel ph
 for k in range(5):
     dlt = t[:, k + 1] - t[:, k]
     print('  %-34s median %8.0f cycles (%4.1f %%)  p90 %8.0f' % (names[k], np.median(dlt), 100 * np.median(dlt) / np.median(tot), np.sort(dlt)[n * 9 // 10]))
+# per dial (wave w of a workgroup = dial w): which dials are the slow ones
+nd = int(ctx.params.ndials)
+for d in range(nd):
+    sel = np.arange(n) % nd == d
+    ex = t8[sel, 3] - t8[sel, 7]
+    pf = t8[sel, 6] - t8[sel, 2]
+    print('  dial %d: total median %6.0f p90 %6.0f | prefilter median %6.0f | exact test median %6.0f p90 %6.0f max %6.0f' % (
+        d, np.median(tot[sel]), np.sort(tot[sel])[sel.sum() * 9 // 10], np.median(pf), np.median(ex), np.sort(ex)[sel.sum() * 9 // 10], ex.max()))

@@ -110,7 +110,7 @@ stats bench python3 bench.py --skip twostream
 mv $OUT/bench_kernel_stats_bench.csv $OUT/bench_kernel_stats.csv
 mv $OUT/bench_stdout.txt $OUT/bench_under_rocprof.json; mv $OUT/bench_stderr.txt $OUT/bench_under_rocprof.err
 stats config2 python3 tools/run_stage.py fused --iters 60 --hw 640x480 --batch 256 --nbuf 4 --profiling 0
-stats config5 python3 tools/run_stage.py fused --iters 16 --hw 1080x1920 --batch 512 --nbuf 1 --profiling 0
+stats config5 python3 tools/run_stage.py fused --iters 80 --hw 1080x1920 --batch 512 --nbuf 1 --profiling 0   # 90 launches: a 26-launch trace is 5 % slow from its cold start
 stats config4 python3 tools/run_stage.py full --iters 60 --sample-dir sample-images2 --device-records --profiling 0
 stats config3 python3 tools/run_stage.py full --iters 60 --device-records --profiling 0
 rm -f $OUT/*_stderr.txt
