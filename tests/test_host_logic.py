@@ -751,7 +751,7 @@ def test_fan_out_throughput_scales_with_devices(monkeypatch):
         (ok, rate) = measure()
         if ok:
             break
-    assert ok, rate              # at the interpreter's ceiling: eight workers hand the lock round, no gain, a small loss
+    assert ok, rate              # (8 against 4: at the interpreter's ceiling the workers only hand the lock round)
     # order and content survive the fan-out at full speed
     got = list(_api.get_meter_values(pfile, names[:5000]))
     assert [r.filename for r in got] == names[:5000] and got[1234].value == 100.0 + (1234 - 1024) % 800 + 0.125
