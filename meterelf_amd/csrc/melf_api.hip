@@ -673,6 +673,8 @@ extern "C" int melf_ctx_create_bcast(const int* devices, int n, const void* blob
             if (devices[i] == devices[j]) return fail(MELF_ERR_INVALID, "melf_ctx_create_bcast: a device is listed twice (one RCCL rank per GPU)");
     Rccl& R = rccl();
     if (!R.ok) return fail(MELF_ERR_HIP, "melf_ctx_create_bcast: " + R.why);
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);   // put back at the end: the call must not move the calling thread to another GPU
     std::vector<void*> d_blob(n, nullptr);
     std::vector<hipStream_t> st(n, nullptr);
     std::vector<Rccl::comm_t> comm(n, nullptr);
@@ -719,9 +721,9 @@ extern "C" int melf_ctx_create_bcast(const int* devices, int n, const void* blob
     if (rc != MELF_SUCCESS) {
         for (int i = 0; i < n; ++i)
             if (out[i]) { melf_ctx_destroy(out[i]); out[i] = nullptr; }
-        return fail(rc, keep);
     }
-    return MELF_SUCCESS;
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    return rc != MELF_SUCCESS ? fail(rc, keep) : MELF_SUCCESS;
 }
 
 extern "C" void melf_ctx_destroy(melf_ctx* c)
