@@ -2212,9 +2212,9 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
 
 extern "C" int melf_jpeg_files_in_flight_max(void) { return MELF_FILES_IN_FLIGHT_MAX; }
 
-// What the file system gives the read stage: open() + close() of every path on the device's I/O pool, nothing else.  (On the
-// pool's boxes an open() costs 1.4-1.8 ms per 1024 files whether 6 or 48 threads issue them -- the container's file system
-// serialises it -- which is the floor of every file-name figure there: profiles/r05/file_reads_open_close.txt.)
+// What the file system gives the read stage: open() + close() of every path on the device's I/O pool, nothing else (0.5-0.6 ms
+// per 1024 files with 12 threads on the pool's boxes -- about a third of the read stage, the rest being read() into the pinned
+// arena and the header parse: HISTORY.md, round 5; bench.py puts the figure on the line as `open_close_probe`).
 extern "C" int melf_files_open_probe(const char* const* paths, int n, int device, double* ms, int* threads)
 {
     if (!paths || n < 0 || !ms) return fail(MELF_ERR_INVALID, "bad argument");
@@ -2235,10 +2235,10 @@ extern "C" int melf_files_open_probe(const char* const* paths, int n, int device
 extern "C" int melf_ctx_files_stats(melf_ctx* c, double out[MELF_FILES_STATS_COUNT], int reset)
 {
     if (!c || !out) return fail(MELF_ERR_INVALID, "NULL argument");
-    if (!c->files_jobs.empty()) return fail(MELF_ERR_INVALID, "melf_ctx_files_stats while a melf_jpeg_process_files_begin call is in flight");
     pool_use_device(c->device);
     {
         std::lock_guard<std::mutex> lk(c->files_m);
+        if (!c->files_jobs.empty()) return fail(MELF_ERR_INVALID, "melf_ctx_files_stats while a melf_jpeg_process_files_begin call is in flight");
         const auto& st = c->files_stats;
         out[0] = st.calls; out[1] = st.files; out[2] = st.ms_read; out[3] = st.ms_turn_wait; out[4] = st.ms_enqueue; out[5] = st.ms_gpu_wait;
         if (reset) c->files_stats = melf_ctx::FilesStats();
