@@ -50,7 +50,12 @@ __device__ inline bool angle_by_vector(double x, double y, double& out)
         return false;
     }
     const double at = atan(x / y) / (2 * 3.141592653589793);
-    out = py_fmod(-at + (y > 0 ? 0.5 : 0.0), 1.0);
+    // CPython's float % 1.0 without the library's fmod: v - trunc(v) IS fmod(v, 1.0) (the subtraction is exact), sign included
+    // except at the zeros, which float_rem replaces by +0.0 anyway
+    const double v = -at + (y > 0 ? 0.5 : 0.0);
+    double m = v - trunc(v);
+    if (m != 0.0) { if (m < 0) m += 1.0; } else { m = 0.0; }
+    out = m;
     return true;
 }
 
@@ -70,30 +75,24 @@ struct Key {
     double a, d;
 };
 __device__ inline bool key_lt(const Key& p, const Key& q) { return p.a < q.a || (p.a == q.a && p.d < q.d); }
-__device__ inline Key shfl_key(const Key& k, int o)
+// One trimming round: the smallest of the lanes' `lo` keys and the largest of their `hi` keys.  The angle's extreme first (the two
+// scans interleave); the lane that holds it is nearly always alone, and its distance is then a v_readlane away.
+__device__ inline void wave_min_max_key(const Key& lo, const Key& hi, Key& klo, Key& khi)
 {
-    Key r;
-    r.a = __shfl_xor(k.a, o, 64);
-    r.d = __shfl_xor(k.d, o, 64);
-    return r;
-}
-__device__ inline Key wave_min_key(Key k)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const Key q = shfl_key(k, o);
-        if (key_lt(q, k)) k = q;
+    klo.a = wave_min_f64(lo.a);
+    khi.a = wave_max_f64(hi.a);
+    const uint64_t blo = __builtin_amdgcn_ballot_w64(lo.a == klo.a), bhi = __builtin_amdgcn_ballot_w64(hi.a == khi.a);
+    if (__popcll(blo) == 1 && __popcll(bhi) == 1) {
+        const int jl = __builtin_ctzll(blo), jh = __builtin_ctzll(bhi);
+        const uint64_t dl = __double_as_longlong(lo.d), dh = __double_as_longlong(hi.d);
+        klo.d = __longlong_as_double((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dl, jl) |
+                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dl >> 32), jl) << 32));
+        khi.d = __longlong_as_double((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dh, jh) |
+                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dh >> 32), jh) << 32));
+    } else {
+        klo.d = wave_min_f64(lo.a == klo.a ? lo.d : 1e300);
+        khi.d = wave_max_f64(hi.a == khi.a ? hi.d : -1e300);
     }
-    return k;
-}
-__device__ inline Key wave_max_key(Key k)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const Key q = shfl_key(k, o);
-        if (key_lt(k, q)) k = q;
-    }
-    return k;
 }
 
 // Visits the ring points that the reference keeps (meterelf/_reading.py:53-69):
@@ -212,9 +211,27 @@ extern "C" __attribute__((visibility("default"))) int melf_debug_dials_stamps(ui
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dials_stamps), sizeof(uint64_t) * 8 * (size_t)(nwaves < 8192 ? nwaves : 8192)) == hipSuccess ? 0 : -1;
 }
-#define DSTAMP(k) do { if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) g_dials_stamps[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// ... and the 100 MHz real-time counter at four of them (the shader-clock counters of different CUs cannot be compared) + HW_ID
+__device__ uint64_t g_dials_real[8 * 8192];
+extern "C" __attribute__((visibility("default"))) int melf_debug_dials_real(uint64_t* out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dials_real), sizeof(uint64_t) * 8 * (size_t)(nwaves < 8192 ? nwaves : 8192)) == hipSuccess ? 0 : -1;
+}
+// ... and shader-clock stamps inside the closing / labelling and the momentum / angle phases
+__device__ uint64_t g_dials_fine[16 * 8192];
+extern "C" __attribute__((visibility("default"))) int melf_debug_dials_fine(uint64_t* out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dials_fine), sizeof(uint64_t) * 16 * (size_t)(nwaves < 8192 ? nwaves : 8192)) == hipSuccess ? 0 : -1;
+}
+#define FSTAMPD(k) do { if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) g_dials_fine[16 * (blockIdx.x * (blockDim.x >> 6) + wv) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DSTAMP(k) do { if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) { \
+        g_dials_stamps[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + (k)] = __builtin_amdgcn_s_memtime(); \
+        if ((k) < 6) g_dials_real[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if ((k) == 0) { uint32_t hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); uint32_t xc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc_)); \
+                        g_dials_real[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + 6] = hw_; g_dials_real[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + 7] = xc_ & 15u; } } } while (0)
 #else
 #define DSTAMP(k) do { } while (0)
+#define FSTAMPD(k) do { } while (0)
 #endif
 
 // Register budget: 128 of the SIMD's 512 ("amdgpu-num-vgpr" is doubled by the backend for gfx90a+'s unified file): four waves
@@ -243,6 +260,15 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     // with event brackets, profiles/r04/dials_rotate_ab.txt -- the dispatcher already mixes them.)
     const int d = wv;
     DSTAMP(0);
+#if defined(MELF_DIALS_PRIO) && MELF_DIALS_PRIO == 1
+    if (d == 1) __builtin_amdgcn_s_setprio(3);
+#endif
+#if defined(MELF_DIALS_STAGGER)
+    {   // experiment: the k-th workgroup of a CU (dispatch order) requests its pixels k * MELF_DIALS_STAGGER/4 us later
+        const int kth = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < kth * MELF_DIALS_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);   // ~512 cycles = 0.25 us each
+    }
+#endif
     const uint8_t* frame = src.base + (size_t)f * src.frame_stride;
     uint8_t* const lds = s_dyn + (size_t)wv * DIAL_LDS_BYTES;
     uint32_t* const list_px = (uint32_t*)lds;                       // pixel phase
@@ -297,9 +323,13 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     // clamped (always valid) coordinates: a load inside a bounds check makes the compiler wait for each one separately.
     // The colour phase below then runs while the window's rows are still in flight -- one memory round trip for the
     // wave instead of one for the core and one per 16 rows (half of the wave's life was such waits).
+    // Lanes and rows beyond the window request its LAST column / row again (the same cache lines: nothing more leaves HBM).
+    // Round 5: they used to request the 64 x NR pixels around the window's corner whatever its size -- a 49 x 49 window
+    // fetched 12.3 KB of which it used 7.2 (the 1.6x of the traffic counters).
     const int Xl = wx0 + lane;
     const bool colvalid = lane < ws && Xl >= 0 && Xl < P.tw;
-    const int Xc = min(max(Xl, 0), P.tw - 1);
+    const int Xc = min(max(wx0 + min(lane, ws - 1), 0), P.tw - 1);
+    const int ylast = ws - 1;   // wave-uniform
     const bool tail = !FROM_HLS && hls_scalar_tail(mx + Xl, src.crop_cols);
     const size_t rstride = FROM_HLS ? (size_t)P.tw * 3 : (size_t)src.row_stride;
     const uint8_t* const origin = FROM_HLS ? frame : frame + (size_t)(src.y0 + my) * src.row_stride + (size_t)(src.x0 + mx) * 3;
@@ -313,7 +343,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     if (!FROM_HLS) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-            const int Y = min(max(wy0 + k, 0), th1);
+            const int Y = min(max(wy0 + min(k, ylast), 0), th1);
             pxv[k] = load_px3_row(pcol, (size_t)((int64_t)Y * rs_u));
         }
     }
@@ -343,7 +373,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
             uint32_t pxe[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int Y = min(max(wy0 + yc + k, 0), th1);
+                const int Y = min(max(wy0 + min(yc + k, ylast), 0), th1);
                 pxe[k] = load_px3_row(pcol, (size_t)((int64_t)Y * rs_u));
             }
 #pragma unroll
@@ -412,6 +442,12 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         // lane y's row of the window's valid-pixel mask (what the per-row ballots of `valid` used to deliver)
         V = (lane < ws && wy0 + lane >= 0 && wy0 + lane < P.th && lane < NR) ? colb : 0ull;
         DSTAMP(6);
+#if defined(MELF_DIALS_PRIO) && MELF_DIALS_PRIO == 2
+        { const int pr = total >> 7; if (pr >= 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
+#endif
+#ifdef MELF_DIALS_STAMP
+        if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) g_dials_real[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + 6] |= (uint64_t)total << 32;
+#endif
         if (total > DIAL_LIST_CAP) {
             exact_rows();
         } else {
@@ -441,51 +477,75 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     const uint64_t annulus = rowmasks[((size_t)d * 3 + 1) * 64 + lane];
     const uint64_t outside0 = rowmasks[((size_t)d * 3 + 2) * 64 + lane];  // truly outside the disk (no pockets)
     const uint64_t M = mde & disk;
+    FSTAMPD(0);   // closing done, row masks loaded
 
     int status = 0;  // 0 ok, 1 no contours, 2 unreadable
     double pos = 0.0, angle = 0.0;
     if (__builtin_amdgcn_ballot_w64(M != 0) == 0) {
         status = 1;  // NeedleContoursNotFoundError (_reading.py:137-138)
     } else {
-        // pixels of ~M that are 4-connected to the outside of the disk.  The seed is host-computed:
-        // unfilled pockets inside the reference's disk mask (thin rings) are not outside.
-        const uint64_t freeb = ~M;
-        uint64_t o = outside0;
-        for (;;) {
-            const uint64_t n = o | ((((o << 1) | (o >> 1)) | row_up(o, lane, ~0ull) | row_down(o, lane, ~0ull)) & freeb);
-            const bool ch2 = n != o;
-            o = n;
-            if (__builtin_amdgcn_ballot_w64(ch2) == 0) break;
-        }
-        const uint64_t Gf = ~o;  // M plus everything its outer borders enclose
-        // 8-connected components of Gf in raster order of their first pixel =
-        // external contours in cv2's discovery order; keep the largest by
-        // contourArea (stable sort + [-1] with cv2's reversed list => earliest wins ties)
-        uint64_t rem = Gf, bestF = 0;
-        int best2 = -1;
-        for (;;) {
-            const uint64_t rowsb = __builtin_amdgcn_ballot_w64(rem != 0);
-            if (rowsb == 0) break;
-            const int r0 = __builtin_ctzll(rowsb);
-            // row r0 of `rem` for every lane: r0 is wave-uniform, so this is two v_readlane (no LDS permute)
-            const uint64_t rv = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rem, r0) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rem >> 32), r0) << 32);
-            const int b0 = __builtin_ctzll(rv);
-            uint64_t s = (lane == r0) ? (1ull << b0) : 0ull;
+        // 8-connected components of a set in raster order of their first pixel = external contours in cv2's discovery order; keep
+        // the largest by contourArea (stable sort + [-1] with cv2's reversed list => earliest wins ties).  Two propagation steps
+        // per convergence test: the test (compare, ballot, branch) is a third of a lone wave's trip.
+        uint64_t bestF = 0;
+        int best2 = -1, ncomp = 0;
+        auto label = [&](const uint64_t Gs) {
+            uint64_t rem = Gs;
+            bestF = 0; best2 = -1; ncomp = 0;
             for (;;) {
-                const uint64_t h3 = s | (s << 1) | (s >> 1);
-                const uint64_t n = (h3 | row_up(h3, lane, 0) | row_down(h3, lane, 0)) & Gf;
-                const bool ch2 = n != s;
-                s = n;
+                const uint64_t rowsb = __builtin_amdgcn_ballot_w64(rem != 0);
+                if (rowsb == 0) break;
+                const int r0 = __builtin_ctzll(rowsb);
+                // row r0 of `rem` for every lane: r0 is wave-uniform, so this is two v_readlane (no LDS permute)
+                const uint64_t rv = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rem, r0) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rem >> 32), r0) << 32);
+                const int b0 = __builtin_ctzll(rv);
+                uint64_t s = (lane == r0) ? (1ull << b0) : 0ull;
+                for (;;) {
+                    const uint64_t h3 = s | (s << 1) | (s >> 1);
+                    const uint64_t n1 = (h3 | row_up(h3, lane, 0) | row_down(h3, lane, 0)) & Gs;
+                    const uint64_t g3 = n1 | (n1 << 1) | (n1 >> 1);
+                    const uint64_t n2 = (g3 | row_up(g3, lane, 0) | row_down(g3, lane, 0)) & Gs;
+                    const bool ch2 = n2 != n1;
+                    s = n2;
+                    if (__builtin_amdgcn_ballot_w64(ch2) == 0) break;
+                }
+                const uint64_t a = s, b = row_down(s, lane, 0), a1 = a >> 1, b1 = b >> 1;
+                const int c = 2 * __builtin_popcountll(a & a1 & b & b1) + __builtin_popcountll(a & a1 & b & ~b1) +
+                              __builtin_popcountll(a & a1 & ~b & b1) + __builtin_popcountll(a & ~a1 & b & b1) +
+                              __builtin_popcountll(~a & a1 & b & b1);
+                const int area2 = wave_sum_i32(c);  // 2 * cv2.contourArea
+                if (area2 > best2) { best2 = area2; bestF = s; }
+                rem &= ~s;
+                ++ncomp;
+            }
+        };
+        // The reference fills each EXTERNAL contour: a component's holes count as its pixels.  Needle masks rarely have holes, and
+        // whether this one has any follows from its Euler number without a flood (Gray's bit quads: 4 E = Q1 - Q3 - 2 QD for
+        // 8-connected foreground / 4-connected background, E = components - holes; the window's 2-pixel margin makes the all-zero
+        // quads beyond its edges irrelevant): no holes -> the components of M are the filled contours.  Otherwise, as until round 5:
+        // the pixels of ~M that are 4-connected to the outside of the disk (the seed is host-computed: unfilled pockets inside the
+        // reference's disk mask -- thin rings -- are not outside), everything else is M plus what its outer borders enclose.
+        int euler4;
+        {
+            const uint64_t a = M, b = row_down(M, lane, 0), a1 = a >> 1, b1 = b >> 1;
+            const uint64_t odd = a ^ a1 ^ b ^ b1;                          // one or three pixels of the quad
+            const uint64_t three = odd & ((a & a1) | (b & b1));
+            const uint64_t diag = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
+            euler4 = wave_sum_i32(__builtin_popcountll(odd) - 2 * __builtin_popcountll(three) - 2 * __builtin_popcountll(diag));
+        }
+        label(M);
+        FSTAMPD(1);
+        if (4 * ncomp != euler4) {
+            const uint64_t freeb = ~M;
+            uint64_t o = outside0;
+            for (;;) {
+                const uint64_t n = o | ((((o << 1) | (o >> 1)) | row_up(o, lane, ~0ull) | row_down(o, lane, ~0ull)) & freeb);
+                const bool ch2 = n != o;
+                o = n;
                 if (__builtin_amdgcn_ballot_w64(ch2) == 0) break;
             }
-            const uint64_t a = s, b = row_down(s, lane, 0), a1 = a >> 1, b1 = b >> 1;
-            const int c = 2 * __builtin_popcountll(a & a1 & b & b1) + __builtin_popcountll(a & a1 & b & ~b1) +
-                          __builtin_popcountll(a & a1 & ~b & b1) + __builtin_popcountll(a & ~a1 & b & b1) +
-                          __builtin_popcountll(~a & a1 & b & b1);
-            const int area2 = wave_sum_i32(c);  // 2 * cv2.contourArea
-            if (area2 > best2) { best2 = area2; bestF = s; }
-            rem &= ~s;
+            label(~o);   // M plus everything its outer borders enclose
         }
         // contourArea > 100: filled contour, else the whole closed mask (_reading.py:141-148); both are
         // used only through `& dial.mask` / `& dial.circle_mask` (:150, :51) -- the filled contour can
@@ -497,23 +557,27 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         // momentum vector (_reading.py:32-41)
         const double cx = D.cx, cy = D.cy;
         double sx = 0.0, sy = 0.0;
+        FSTAMPD(2);
         {
+            // a row's x term from eight table entries (melf_ctx_create: momx[d][byte of the row mask][its value] = the sum of
+            // sign(dx) dx^2 over the byte's set bits), its y term times its pixel count: no loop over the pixels (a lone wave
+            // spent 3 000-4 000 cycles in the longest row's)
             const double dy = (double)(wy0 + lane) - cy;
             const double ty = (dy < 0 ? -1.0 : 1.0) * (dy * dy);
-            uint64_t bits = N;
-            while (bits) {
-                const int x = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const double dx = (double)(wx0 + x) - cx;
-                sx += (dx < 0 ? -1.0 : 1.0) * (dx * dx);
-                sy += ty;
-            }
+            const double* const mt = (const double*)(rowmasks + (size_t)P.ndials * 3 * 64) + (size_t)d * 2048;
+            double part[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) part[b] = mt[b * 256 + (int)((N >> (8 * b)) & 255)];
+            sx = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            sy = ty * (double)__builtin_popcountll(N);
         }
         sx = wave_sum_f64(sx);
         sy = wave_sum_f64(sy);
+        FSTAMPD(3);   // momentum sums reduced (loop + two reductions)
         const double msign = D.negative_momentum ? -1.0 : 1.0;
         double mom = 0.0;
         const bool have_mom = angle_by_vector(msign * sx, msign * sy, mom);
+        FSTAMPD(4);   // momentum angle
 
         // The ring points (needle pixels inside the annulus, a few dozen) are compacted into a list first: the
         // angle of each -- a double-precision atan -- is then computed once, 64 points at a time, and the three
@@ -535,6 +599,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                     list[at++] = (uint16_t)(lane << 6 | x);
                 }
             }
+            FSTAMPD(5);   // ring list written
             int nk = 0;
             double mina = 1e300;
             for (int t = lane; t < rtotal; t += 64) {
@@ -555,6 +620,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
             if (nk == 0) {
                 status = 2;  // unreadable dial (_reading.py:79-81)
             } else {
+                FSTAMPD(6);   // ring angles cached, count and minimum known
                 const int cut = nk >= 5 ? min(2, (nk - 3) / 2) : 0;
                 const Key PINF = {1e300, 1e300}, NINF = {-1e300, -1e300};
                 Key klo = NINF, khi = PINF;
@@ -570,12 +636,12 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                         if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
                     }
                     for (int c2 = 0; c2 < cut; ++c2) {
-                        klo = wave_min_key(l1);
+                        wave_min_max_key(l1, h1, klo, khi);
                         if (l1.a == klo.a && l1.d == klo.d) { l1 = l2; l2 = PINF; }
-                        khi = wave_max_key(h1);
                         if (h1.a == khi.a && h1.d == khi.d) { h1 = h2; h2 = NINF; }
                     }
                 }
+                FSTAMPD(7);   // trimming keys known
                 double sad = 0.0, sd = 0.0;
                 for (int t = lane; t < rtotal; t += 64) {
                     const double a = ra[t];
@@ -621,9 +687,8 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                         if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
                     });
                     for (int c2 = 0; c2 < cut; ++c2) {
-                        klo = wave_min_key(l1);
+                        wave_min_max_key(l1, h1, klo, khi);
                         if (l1.a == klo.a && l1.d == klo.d) { l1 = l2; l2 = PINF; }
-                        khi = wave_max_key(h1);
                         if (h1.a == khi.a && h1.d == khi.d) { h1 = h2; h2 = NINF; }
                     }
                 }

@@ -521,6 +521,25 @@ static int setup_device_tables(melf_ctx* c)
     }
     HIP_TRY(hipMalloc((void**)&c->d_geom, geom.size() * sizeof(DialGeom)));
     HIP_TRY(hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(DialGeom), hipMemcpyHostToDevice));
+    // behind the masks: the momentum vector's x sums per byte of a row mask (k_dials), momx[d][byte][value] as doubles
+    {
+        const size_t at = rowmasks.size();
+        rowmasks.resize(at + (size_t)P.ndials * 8 * 256, 0);
+        for (int d = 0; d < P.ndials; ++d) {
+            double f[64];
+            for (int x = 0; x < 64; ++x) {
+                const double dx = (double)(geom[d].wx0 + x) - P.dial[d].cx;
+                f[x] = (dx < 0 ? -1.0 : 1.0) * (dx * dx);
+            }
+            for (int b = 0; b < 8; ++b)
+                for (int v = 0; v < 256; ++v) {
+                    double sum = 0.0;
+                    for (int j = 0; j < 8; ++j)
+                        if (v >> j & 1) sum += f[8 * b + j];
+                    memcpy(&rowmasks[at + ((size_t)d * 8 + b) * 256 + v], &sum, 8);
+                }
+        }
+    }
     HIP_TRY(hipMalloc((void**)&c->d_rowmasks, rowmasks.size() * 8));
     HIP_TRY(hipMemcpy(c->d_rowmasks, rowmasks.data(), rowmasks.size() * 8, hipMemcpyHostToDevice));
 

@@ -131,20 +131,37 @@ __device__ inline double readlane63_f64(double v)
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
     return __longlong_as_double(((uint64_t)hi << 32) | lo);
 }
-// 64-bit floating-point reductions stay on the shuffle butterfly: the DPP form needs two moves per step and double, and
-// measured slower in the angle phase of k_dials (23 K against 16 K cycles per wave).
+// 64-bit floating-point reductions, DPP scans too (two moves per step): lane 63 ends with the result, two v_readlane hand it to
+// every lane.  (Until round 5 these were __shfl_xor butterflies -- twelve ds_bpermute round trips each; with four waves per SIMD the
+// LDS latency hides behind the other waves and the DPP form's extra moves had measured slower, but k_dials ends with ONE wave per
+// SIMD running its angle phase alone, and there the round trips are the critical path: tools/dials_clock.py.)
+// Sums: zero fill (bound_ctrl: a lane without a source adds 0.0).  Minimum / maximum: a lane without a source keeps its own value,
+// which an idempotent operation ignores.
+template <int CTRL>
+__device__ __forceinline__ double dpp0_f64(double v)
+{
+    const uint64_t vu = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)vu, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(vu >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((uint64_t)hi << 32) | lo);
+}
 __device__ inline double wave_sum_f64(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp0_f64<0x111>(v); v += dpp0_f64<0x112>(v); v += dpp0_f64<0x114>(v); v += dpp0_f64<0x118>(v);
+    v += dpp0_f64<0x142>(v); v += dpp0_f64<0x143>(v);
+    return readlane63_f64(v);
 }
-__device__ inline double wave_min_f64(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define MELF_DPP_FOLD_F64(OP, v)                       \
+    v = OP(v, dpp_f64<0x111, 0xf, 0xf>(v, v));         \
+    v = OP(v, dpp_f64<0x112, 0xf, 0xf>(v, v));         \
+    v = OP(v, dpp_f64<0x114, 0xf, 0xe>(v, v));         \
+    v = OP(v, dpp_f64<0x118, 0xf, 0xc>(v, v));         \
+    v = OP(v, dpp_f64<0x142, 0xa, 0xf>(v, v));         \
+    v = OP(v, dpp_f64<0x143, 0xc, 0xf>(v, v));
+__device__ inline double wave_min_f64(double v) { MELF_DPP_FOLD_F64(vmin_f64, v) return readlane63_f64(v); }
+__device__ inline double wave_max_f64(double v) { MELF_DPP_FOLD_F64(vmax_f64, v) return readlane63_f64(v); }
 __device__ inline uint64_t shfl_u64(uint64_t v, int src)
 {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
