@@ -163,6 +163,7 @@ __device__ __forceinline__ uint32_t load_px3_row(const PxColumn& c, size_t row_o
 
 // packed 16-bit arithmetic on two values per register (v_pk_*_u16)
 typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2v, a), __builtin_bit_cast(u16x2v, b)));
@@ -260,15 +261,6 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     // with event brackets, profiles/r04/dials_rotate_ab.txt -- the dispatcher already mixes them.)
     const int d = wv;
     DSTAMP(0);
-#if defined(MELF_DIALS_PRIO) && MELF_DIALS_PRIO == 1
-    if (d == 1) __builtin_amdgcn_s_setprio(3);
-#endif
-#if defined(MELF_DIALS_STAGGER)
-    {   // experiment: the k-th workgroup of a CU (dispatch order) requests its pixels k * MELF_DIALS_STAGGER/4 us later
-        const int kth = (blockIdx.x >> 8) & 3;
-        for (int i = 0; i < kth * MELF_DIALS_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);   // ~512 cycles = 0.25 us each
-    }
-#endif
     const uint8_t* frame = src.base + (size_t)f * src.frame_stride;
     uint8_t* const lds = s_dyn + (size_t)wv * DIAL_LDS_BYTES;
     uint32_t* const list_px = (uint32_t*)lds;                       // pixel phase
@@ -317,9 +309,10 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     const melf_dial D = P.dial[d];
     // one dial per wave: its geometry is wave-uniform (tell the compiler, so that row / window tests are scalar)
     const int wx0 = __builtin_amdgcn_readfirstlane(G.wx0), wy0 = __builtin_amdgcn_readfirstlane(G.wy0), ws = __builtin_amdgcn_readfirstlane(G.ws);
+    FSTAMPD(8);    // the dial's geometry has arrived
 
     // Every pixel this wave needs is requested here, before anything waits: the 5x5 colour core (one pixel per lane)
-    // and the lane's column of the window (lane = column, one packed VGPR per window row).  Unconditional loads at
+    // and the window (four pixels of a row per lane and load, below).  Unconditional loads at
     // clamped (always valid) coordinates: a load inside a bounds check makes the compiler wait for each one separately.
     // The colour phase below then runs while the window's rows are still in flight -- one memory round trip for the
     // wave instead of one for the core and one per 16 rows (half of the wave's life was such waits).
@@ -336,18 +329,41 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     const int coreX = G.core_x - 2 + lane % 5, coreY = G.core_y - 2 + (lane < 25 ? lane / 5 : 0);
     const bool corevalid = lane < 25 && coreX >= 0 && coreX < P.tw && coreY >= 0 && coreY < P.th;
     const uint32_t corepx = load_px3(origin + (size_t)min(max(coreY, 0), P.th - 1) * rstride + (size_t)min(max(coreX, 0), P.tw - 1) * 3, src.base);
-    uint32_t pxv[NR];
-    const PxColumn pcol = px_column(origin + (size_t)Xc * 3, src.base);
+    const PxColumn pcol = px_column(origin + (size_t)Xc * 3, src.base);   // (the exact path's loads: one pixel per lane and row)
     const int th1 = __builtin_amdgcn_readfirstlane(P.th - 1);
     const int rs_u = __builtin_amdgcn_readfirstlane((int)rstride);  // uniform: the row offsets below are scalar products
-    if (!FROM_HLS) {
+    // The window for the integer test, round 5: a lane fetches FOUR pixels of a row as one aligned 16-byte load (the 12 bytes and
+    // what the alignment adds), sixteen lanes a row, four rows per instruction -- NR / 4 loads per wave instead of NR.  Until then
+    // a lane fetched its column's pixel of every row as an unaligned dword: the texture addresser took 12 cycles per such
+    // instruction, and the 784 of a CU's sixteen waves were issued over the launch's first 4.6 us with nothing else to do
+    // (tools/dials_clock.py: "pixels requested" 9 700 cycles; 4 200 for a wave alone on its SIMD).
+    constexpr int NG = NR / 4;
+    static_assert(NR % 4 == 0, "window rows come in groups of four");
+    const int rg = lane >> 4, pc = lane & 15;
+    const int npiece = (ws + 3) >> 2;   // wave-uniform: 12-byte pieces of a window row
+    // wave-uniform: every piece lies inside the crop's rows (no column clamping: a lane's four pixels stay four neighbours) and
+    // the last load ends inside the frames' buffer; otherwise every pixel takes the exact path below
+    const uint8_t* const buf_end = src.base + (size_t)gridDim.x * src.frame_stride;
+    const bool quads = !FROM_HLS && ((uintptr_t)src.base & 3) == 0 && wx0 >= 0 && wx0 + 4 * npiece <= P.tw &&
+                       origin + (size_t)th1 * rstride + (size_t)(wx0 + 4 * npiece) * 3 + 4 <= buf_end;
+    u32x4v raw[NG];
+    uint32_t mshift[NG];   // bytes between a load's aligned address and its first pixel (0..3)
+    if (quads) {
+        const uint8_t* const lane0 = origin + (size_t)(wx0 + 4 * min(pc, npiece - 1)) * 3;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int Y = min(max(wy0 + min(k, ylast), 0), th1);
-            pxv[k] = load_px3_row(pcol, (size_t)((int64_t)Y * rs_u));
+        for (int g = 0; g < NG; ++g) {
+            const int Y = min(max(wy0 + min(4 * g + rg, ylast), 0), th1);
+            const uint8_t* const a = lane0 + (size_t)Y * (size_t)rs_u;
+            mshift[g] = (uint32_t)(uintptr_t)a & 3u;
+            raw[g] = *(const u32x4v*)((uintptr_t)a & ~(uintptr_t)3);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    FSTAMPD(9);    // every pixel requested
+#ifdef MELF_DIALS_STAMP
+    asm volatile("; colour core here" :: "v"(corepx) : "memory");
+    FSTAMPD(10);   // the colour core has arrived
+#endif
 
     // get_dial_color (_reading.py:154-160): mean of the 5x5 core, Python round()
     int sh = 0, sl = 0, ss = 0, cnt = 0;
@@ -400,10 +416,11 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         // sum = max + min and diff = max - min, L is sum/2 rounded either way and S is 255*diff/den rounded
         // (den = sum below mid-grey, 510 - sum above), both float paths within 1e-4 of the real value, so a
         // pixel whose L or S misses the bounds by a whole unit cannot be in range.  (2) The candidates --
-        // typically the needle, a tenth of the window -- take the exact float path, 64 at a time: each row's
-        // candidates are appended (position and pixel, by the lane that holds it) to a list in LDS as the row is
-        // tested.  More candidates than the list holds: every pixel takes the exact path.
-        // The test runs on TWO window rows per instruction, as packed 16-bit halves (v_pk_*_u16): 255 * diff and
+        // typically the needle, a tenth of the window -- take the exact float path, 64 at a time: the candidates
+        // are appended (position and pixel, by the lane that holds it) to a list in LDS as they are found (the list's
+        // order does not matter: the exact test ORs bits into the window's row masks).  More candidates than the list
+        // holds: every pixel takes the exact path.
+        // The test runs on TWO pixels of the lane's four per instruction, as packed 16-bit halves (v_pk_*_u16): 255 * diff and
         // den * (bound) stay below 2^16, so the compares  255 diff >= (los - 1) den  and  255 diff <= (his + 1) den  (the
         // inequalities above halved) are exact in 16 bits; "x outside [lo, hi]" is  x != min(max(x, lo), hi).  Grey pixels
         // (diff = 0) pass here when los <= 1 although only los = 0 admits them: a candidate more for the exact test.
@@ -411,40 +428,50 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         const uint64_t colb = __builtin_amdgcn_ballot_w64(colvalid);
         const uint32_t LO2 = (uint32_t)max(2 * lol - 1, 0) * 0x00010001u, HI2 = (uint32_t)(2 * hil + 1) * 0x00010001u;
         const uint32_t SLO = (uint32_t)max(los - 1, 0) * 0x00010001u, SHI = (uint32_t)(his + 1) * 0x00010001u;
+        const int xleft = ws - 4 * pc;   // pixels j < xleft of this lane's four are window columns
+        if (quads) {
 #pragma unroll
-        for (int k2 = 0; k2 < NR; k2 += 2) {
-            const uint32_t p0 = pxv[k2], p1 = pxv[k2 + 1];
-            const uint32_t B2 = __builtin_amdgcn_perm(p1, p0, 0x0c040c00u), G2 = __builtin_amdgcn_perm(p1, p0, 0x0c050c01u),
-                           R2 = __builtin_amdgcn_perm(p1, p0, 0x0c060c02u);
-            const uint32_t vmax = pk_max_u16(pk_max_u16(B2, G2), R2), vmin = pk_min_u16(pk_min_u16(B2, G2), R2);
-            const uint32_t sum = pk_add_u16(vmax, vmin), diff = pk_sub_u16(vmax, vmin);
-            const uint32_t den = pk_min_u16(sum, pk_sub_u16(0x01fe01feu, sum));
-            const uint32_t lbad = pk_min_u16(pk_max_u16(sum, LO2), HI2) ^ sum;
-            const uint32_t a = pk_mul_u16(diff, 0x00ff00ffu);
-            const uint32_t sbad = pk_min_u16(pk_max_u16(a, pk_mul_u16(den, SLO)), pk_mul_u16(den, SHI)) ^ a;
-            const uint32_t bad = lbad | sbad;
+            for (int g = 0; g < NG; ++g) {
+                // the lane's 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(raw[g].y, raw[g].x, mshift[g]);
+                const uint32_t e1 = __builtin_amdgcn_alignbyte(raw[g].z, raw[g].y, mshift[g]);
+                const uint32_t e2 = __builtin_amdgcn_alignbyte(raw[g].w, raw[g].z, mshift[g]);
+                const int y = 4 * g + rg, Y = wy0 + y;
+                const bool rowok = (y < ws) & (Y >= 0) & (Y < P.th);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = k2 + h, y = k, Y = wy0 + y;
-                const bool rowok = (y < ws) & (Y >= 0) & (Y < P.th);                  // wave-uniform
-                const bool cand = (h ? bad < 0x10000u : (bad & 0xffffu) == 0u) & colvalid & rowok;
-                const uint64_t cb = __builtin_amdgcn_ballot_w64(cand);
-                if (cb) {   // wave-uniform: most rows above and below the needle have no candidate at all
-                    const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
-                    if (cand && slot < DIAL_LIST_CAP) {
-                        list_pos[slot] = (uint16_t)(y << 6 | lane);
-                        list_px[slot] = pxv[k];
+                for (int h = 0; h < 2; ++h) {   // pixels (0, 1), then (2, 3): two per instruction, as packed 16-bit halves
+                    const uint32_t B2 = h ? __builtin_amdgcn_perm(e2, e1, 0x0c050c02u) : __builtin_amdgcn_perm(e1, e0, 0x0c030c00u);
+                    const uint32_t G2 = h ? __builtin_amdgcn_perm(e2, e1, 0x0c060c03u) : __builtin_amdgcn_perm(e1, e0, 0x0c040c01u);
+                    const uint32_t R2 = h ? __builtin_amdgcn_perm(e2, e1, 0x0c070c04u) : __builtin_amdgcn_perm(e1, e0, 0x0c050c02u);
+                    const uint32_t vmax = pk_max_u16(pk_max_u16(B2, G2), R2), vmin = pk_min_u16(pk_min_u16(B2, G2), R2);
+                    const uint32_t sum = pk_add_u16(vmax, vmin), diff = pk_sub_u16(vmax, vmin);
+                    const uint32_t den = pk_min_u16(sum, pk_sub_u16(0x01fe01feu, sum));
+                    const uint32_t lbad = pk_min_u16(pk_max_u16(sum, LO2), HI2) ^ sum;
+                    const uint32_t a = pk_mul_u16(diff, 0x00ff00ffu);
+                    const uint32_t sbad = pk_min_u16(pk_max_u16(a, pk_mul_u16(den, SLO)), pk_mul_u16(den, SHI)) ^ a;
+                    const uint32_t bad = lbad | sbad;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int j = 2 * h + q;
+                        const bool cand = (q ? bad < 0x10000u : (bad & 0xffffu) == 0u) & rowok & (j < xleft);
+                        const uint64_t cb = __builtin_amdgcn_ballot_w64(cand);
+                        if (cb) {   // wave-uniform: most rows above and below the needle have no candidate at all
+                            const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+                            if (cand && slot < DIAL_LIST_CAP) {
+                                list_pos[slot] = (uint16_t)(y << 6 | (4 * pc + j));
+                                list_px[slot] = j == 0 ? e0 : (j == 1 ? __builtin_amdgcn_alignbyte(e1, e0, 3) : (j == 2 ? __builtin_amdgcn_alignbyte(e2, e1, 2) : e2 >> 8));
+                            }
+                            total += __popcll(cb);
+                        }
                     }
-                    total += __popcll(cb);
                 }
             }
+        } else {
+            total = DIAL_LIST_CAP + 1;   // a window that leaves the crop: the exact path for every pixel
         }
         // lane y's row of the window's valid-pixel mask (what the per-row ballots of `valid` used to deliver)
         V = (lane < ws && wy0 + lane >= 0 && wy0 + lane < P.th && lane < NR) ? colb : 0ull;
         DSTAMP(6);
-#if defined(MELF_DIALS_PRIO) && MELF_DIALS_PRIO == 2
-        { const int pr = total >> 7; if (pr >= 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
-#endif
 #ifdef MELF_DIALS_STAMP
         if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) g_dials_real[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + 6] |= (uint64_t)total << 32;
 #endif

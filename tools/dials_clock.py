@@ -117,3 +117,6 @@ for (label, a, b) in seq:
     dlt = (b - a)[ok]
     d1 = (b - a)[ok & (wvi == 1)]
     print('    %-34s %7.0f  [%7.0f]  p90 %7.0f' % (label, np.median(dlt), np.median(d1), q(dlt, 0.9)))
+print('  inside the first phases, median shader cycles [p90]: geometry arrived %.0f [%.0f] | pixels requested %.0f [%.0f] | colour core arrived %.0f [%.0f] | colour and bounds %.0f [%.0f]' % (
+    np.median(fz[:, 8] - t8[:, 1]), q(fz[:, 8] - t8[:, 1], 0.9), np.median(fz[:, 9] - fz[:, 8]), q(fz[:, 9] - fz[:, 8], 0.9),
+    np.median(fz[:, 10] - fz[:, 9]), q(fz[:, 10] - fz[:, 9], 0.9), np.median(t8[:, 2] - fz[:, 10]), q(t8[:, 2] - fz[:, 10], 0.9)))
