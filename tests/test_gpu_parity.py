@@ -1125,3 +1125,51 @@ def test_full_size_fused_mask_properties(env):
     for f in rng.choice(256, 6, replace=False):
         assert np.array_equal(whole[f], po.hls_inrange_close(frames[f], p.hue_shift, lo, hi)), f
     assert (whole > 0).any()
+
+
+@pytest.mark.gpu
+def test_dial_window_fetch_edge_paths(env, tmp_path):
+    """k_dials fetches a dial window as aligned 16-byte pieces (four pixels per lane) when the window lies inside the
+    crop's columns and the frames' buffer is 4-byte aligned, and pixel by pixel through the exact path otherwise.
+    (a) the same frames at device addresses 1, 2 and 3 bytes off alignment: the aligned run's records byte for byte, which
+    equal the oracle's; (b) dials whose windows leave the crop on the left and on the right: against the oracle."""
+    import ctypes as C
+    import shutil
+    import yaml
+    from meterelf_amd import MeterReader, _params
+    from oracle import pyoracle as po
+    e = env['sample-images1']
+    frames = synth_frames(_good(e['files']), 96, 5)
+    (n, H, W) = frames.shape[:3]
+    ctx = e['reader'].ctx
+    hip = hip_runtime()
+    d_buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_buf), C.c_size_t(frames.nbytes + 8)) == 0
+    try:
+        ref = None
+        for off in (0, 1, 2, 3):
+            assert hip.hipMemcpy(C.c_void_p(d_buf.value + off), frames.ctypes.data_as(C.c_void_p), C.c_size_t(frames.nbytes), 1) == 0
+            got = ctx.process_batch_dev(d_buf.value + off, n, H, W)
+            if ref is None:
+                ref = got
+                _compare_records(ref, po.process_frames(frames, e['oparams']), tag='aligned')
+                assert sum(int(r['status']) == 0 for r in ref) > 80
+            else:
+                assert got.tobytes() == ref.tobytes(), 'frames %d byte(s) off alignment' % off
+    finally:
+        hip.hipFree(d_buf)
+    # (b)
+    with open(e['pfile']) as fp:
+        data = yaml.safe_load(fp)
+    tw = data['dials_template_size'][0]
+    data['needle_data'][0]['center'][0] = 18.0        # window columns -5 .. 41
+    data['needle_data'][3]['center'][0] = tw - 17.5   # ... and beyond the crop's last column
+    shutil.copy(os.path.join(GOLDEN, 'sample-images1', data['dials_template']), tmp_path / data['dials_template'])
+    with open(tmp_path / 'params.yml', 'w') as fp:
+        yaml.safe_dump(data, fp)
+    reader = MeterReader(_params.load(str(tmp_path / 'params.yml')))
+    try:
+        recs = reader.read_frames(frames[:48])
+        _compare_records(recs, po.process_frames(frames[:48], po.Params(str(tmp_path / 'params.yml'))), tag='windows beyond the crop')
+    finally:
+        reader.close()
