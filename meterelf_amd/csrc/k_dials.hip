@@ -347,14 +347,14 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     const bool quads = !FROM_HLS && ((uintptr_t)src.base & 3) == 0 && wx0 >= 0 && wx0 + 4 * npiece <= P.tw &&
                        origin + (size_t)th1 * rstride + (size_t)(wx0 + 4 * npiece) * 3 + 4 <= buf_end;
     u32x4v raw[NG];
-    uint32_t mshift[NG];   // bytes between a load's aligned address and its first pixel (0..3)
+    uint32_t mshift = 0;   // bytes between a load's aligned address and its first pixel (0..3), two bits per load
     if (quads) {
         const uint8_t* const lane0 = origin + (size_t)(wx0 + 4 * min(pc, npiece - 1)) * 3;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int Y = min(max(wy0 + min(4 * g + rg, ylast), 0), th1);
             const uint8_t* const a = lane0 + (size_t)Y * (size_t)rs_u;
-            mshift[g] = (uint32_t)(uintptr_t)a & 3u;
+            mshift |= ((uint32_t)(uintptr_t)a & 3u) << (2 * g);
             raw[g] = *(const u32x4v*)((uintptr_t)a & ~(uintptr_t)3);
         }
     }
@@ -429,15 +429,19 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         const uint32_t LO2 = (uint32_t)max(2 * lol - 1, 0) * 0x00010001u, HI2 = (uint32_t)(2 * hil + 1) * 0x00010001u;
         const uint32_t SLO = (uint32_t)max(los - 1, 0) * 0x00010001u, SHI = (uint32_t)(his + 1) * 0x00010001u;
         const int xleft = ws - 4 * pc;   // pixels j < xleft of this lane's four are window columns
+        // the lanes whose pixel j is a window column, as wave masks: a pixel's candidacy is then ballot(test) & masks, scalar work
+        const uint64_t xm[4] = {__builtin_amdgcn_ballot_w64(0 < xleft), __builtin_amdgcn_ballot_w64(1 < xleft),
+                                __builtin_amdgcn_ballot_w64(2 < xleft), __builtin_amdgcn_ballot_w64(3 < xleft)};
         if (quads) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 // the lane's 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                const uint32_t e0 = __builtin_amdgcn_alignbyte(raw[g].y, raw[g].x, mshift[g]);
-                const uint32_t e1 = __builtin_amdgcn_alignbyte(raw[g].z, raw[g].y, mshift[g]);
-                const uint32_t e2 = __builtin_amdgcn_alignbyte(raw[g].w, raw[g].z, mshift[g]);
+                const uint32_t ms = (mshift >> (2 * g)) & 3u;
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(raw[g].y, raw[g].x, ms);
+                const uint32_t e1 = __builtin_amdgcn_alignbyte(raw[g].z, raw[g].y, ms);
+                const uint32_t e2 = __builtin_amdgcn_alignbyte(raw[g].w, raw[g].z, ms);
                 const int y = 4 * g + rg, Y = wy0 + y;
-                const bool rowok = (y < ws) & (Y >= 0) & (Y < P.th);
+                const uint64_t rowb = __builtin_amdgcn_ballot_w64((y < ws) & (Y >= 0) & (Y < P.th));
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {   // pixels (0, 1), then (2, 3): two per instruction, as packed 16-bit halves
                     const uint32_t B2 = h ? __builtin_amdgcn_perm(e2, e1, 0x0c050c02u) : __builtin_amdgcn_perm(e1, e0, 0x0c030c00u);
@@ -453,10 +457,10 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int j = 2 * h + q;
-                        const bool cand = (q ? bad < 0x10000u : (bad & 0xffffu) == 0u) & rowok & (j < xleft);
-                        const uint64_t cb = __builtin_amdgcn_ballot_w64(cand);
+                        const uint64_t cb = __builtin_amdgcn_ballot_w64(q ? bad < 0x10000u : (bad & 0xffffu) == 0u) & rowb & xm[j];
                         if (cb) {   // wave-uniform: most rows above and below the needle have no candidate at all
                             const int slot = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+                            const bool cand = (cb >> lane) & 1ull;
                             if (cand && slot < DIAL_LIST_CAP) {
                                 list_pos[slot] = (uint16_t)(y << 6 | (4 * pc + j));
                                 list_px[slot] = j == 0 ? e0 : (j == 1 ? __builtin_amdgcn_alignbyte(e1, e0, 3) : (j == 2 ? __builtin_amdgcn_alignbyte(e2, e1, 2) : e2 >> 8));
