@@ -275,11 +275,12 @@ def match_roofline(P, H, W, kt, frames_total, traffic_entry):
 
 
 def dials_roofline(kernel_ms, traffic, label):
-    """k_dials is bound by vector-instruction issue, not by bytes or matrix FLOPs: its 'roofline' is the share of the vector units'
+    """k_dials is bound by the vector units, not by bytes or matrix FLOPs -- instruction issue while a SIMD's four waves run
+    together, the dependency chains of its last wave afterwards: its 'roofline' is the share of the vector units'
     cycles the launch keeps busy.  The counters come from the PMC pass of tools/profile_round.sh (rocprofv3 cannot run inside
     this process; traffic.json is stamped with the kernel sources it was measured on), the launch time from this run."""
     v = traffic.valu_entry(label + ':k_dials')
-    out = {'kernel': 'k_dials', 'bound': 'valu-issue', 'avg_launch_ms': kernel_ms.get('k_dials'), 'source': traffic.source,
+    out = {'kernel': 'k_dials', 'bound': 'valu', 'avg_launch_ms': kernel_ms.get('k_dials'), 'source': traffic.source,
            'note': 'avg_launch_ms: hipEvents around each launch in the per-kernel pass of this run (a few microseconds more than an '
                    'unbracketed launch); counters per launch from the PMC pass'}
     if v:

@@ -33,7 +33,7 @@ pmc() {  # name, command...
 }
 pmc config3 python3 tools/run_stage.py full --iters 8
 pmc config4 python3 tools/run_stage.py full --iters 8 --sample-dir sample-images2
-# k_dials is VALU-issue bound: issued vector instructions and the cycles the vector units were busy (SQ_ACTIVE_INST_VALU counts
+# k_dials is bound by the vector units (issue, then the last waves' dependency chains): issued vector instructions and the cycles the vector units were busy (SQ_ACTIVE_INST_VALU counts
 # quad-cycles per SIMD, MI355X_MICROARCH.md), the waves' lifetime, and the chip's active cycles (GRBM_GUI_ACTIVE: the sum over
 # the 8 XCDs) for the clock the launch ran at -- one pass, SQ has eight slots and GRBM two
 valu() {  # name, command...
