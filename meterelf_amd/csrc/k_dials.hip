@@ -118,14 +118,17 @@ __device__ inline void for_each_kept(uint64_t outer, int lane, int wx0, int wy0,
 }
 
 constexpr int DIAL_LIST_CAP = 768;   // candidate pixels of a dial window that take the exact float path
-constexpr int RING_CAP = 256;
+// Ring points (needle pixels inside the annulus) whose angles the angle phase caches.  512 since round 5: with 256 the timed
+// workloads had a wave or two per batch just above it (257, 262 points), and the uncached path (an arctangent per point and pass,
+// serially along the rows) cost such a wave 60 000 cycles instead of 14 000 -- and the launch, which ends with its slowest wave,
+// 58 us instead of 38.  The squared distances are recomputed from the positions now (six instructions) instead of cached.
+constexpr int RING_CAP = 512;
 // LDS of one dial (one wave), carved from the kernel's dynamic block: the ring arrays of the angle phase re-use the
-// candidate list of the pixel phase.
-//   [0, 2048) ra, [2048, 4096) rd   (double[RING_CAP] each)      | pixel phase: [0, 3072) list_px u32[CAP], [3072, 4608) list_pos u16[CAP]
-//   [4096, 4608) ring list u16[RING_CAP]
-//   [4608, 5120) exact in-range bits, two dwords per window row
+// candidate list and the in-range bits of the pixel phase (all of them dead by then).
+//   [0, 4096) ra double[RING_CAP]          | pixel phase: [0, 3072) list_px u32[CAP], [3072, 4608) list_pos u16[CAP]
+//   [4096, 5120) ring list u16[RING_CAP]   |              [4608, 5120) exact in-range bits, two dwords per window row
 constexpr int DIAL_LDS_BYTES = 5120;
-static_assert(DIAL_LIST_CAP * 4 + DIAL_LIST_CAP * 2 <= 4608 && RING_CAP * 16 + RING_CAP * 2 <= 4608, "dial LDS layout");
+static_assert(DIAL_LIST_CAP * 4 + DIAL_LIST_CAP * 2 <= 4608 && RING_CAP * 8 + RING_CAP * 2 <= DIAL_LDS_BYTES, "dial LDS layout");
 
 // Three bytes of a packed 3-channel pixel with ONE (unaligned) dword load instead of three byte loads: the
 // dword starts one byte early (so it never runs past the buffer's end) except at the buffer's very first pixel.
@@ -266,7 +269,6 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     uint32_t* const list_px = (uint32_t*)lds;                       // pixel phase
     uint16_t* const list_pos = (uint16_t*)(lds + 3072);             // pixel phase
     double* const s_ra_d = (double*)lds;                            // angle phase
-    double* const s_rd_d = (double*)(lds + 2048);
     uint16_t* const ring_list = (uint16_t*)(lds + 4096);
     uint32_t* const mask_d = (uint32_t*)(lds + 4608);
 
@@ -617,10 +619,12 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         const int rmine = __popcll(outer);
         const int rincl = wave_scan_i32(rmine);
         const int rtotal = __builtin_amdgcn_readlane(rincl, 63);
+#ifdef MELF_DIALS_STAMP
+        if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) g_dials_real[8 * (blockIdx.x * (blockDim.x >> 6) + wv) + 7] |= (uint64_t)rtotal << 32;
+#endif
         if (rtotal <= RING_CAP) {
             uint16_t* list = ring_list;
             double* ra = s_ra_d;
-            double* rd = s_rd_d;
             {
                 int at = rincl - rmine;
                 uint64_t bits = outer;
@@ -631,6 +635,10 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                 }
             }
             FSTAMPD(5);   // ring list written
+            auto ring_d2 = [&](int e) {   // squared distance from the dial's centre of list entry e (row << 6 | column)
+                const double dx = (double)(wx0 + (e & 63)) - cx, dy = (double)(wy0 + (e >> 6)) - cy;
+                return dx * dx + dy * dy;
+            };
             int nk = 0;
             double mina = 1e300;
             for (int t = lane; t < rtotal; t += 64) {
@@ -644,7 +652,6 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                     if (dist < 0.25) { keep = a; ++nk; if (a < mina) mina = a; }
                 }
                 ra[t] = keep;
-                rd[t] = dx * dx + dy * dy;
             }
             nk = wave_sum_i32(nk);
             mina = wave_min_f64(mina);
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                         if (a != a) continue;
                         Key k;
                         k.a = fabs(a - mina) < 0.75 ? a : a - 1;
-                        k.d = rd[t];
+                        k.d = ring_d2(list[t]);
                         if (key_lt(k, l1)) { l2 = l1; l1 = k; } else if (key_lt(k, l2)) { l2 = k; }
                         if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
                     }
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                     if (a != a) continue;
                     Key k;
                     k.a = fabs(a - mina) < 0.75 ? a : a - 1;
-                    k.d = rd[t];
+                    k.d = ring_d2(list[t]);
                     if (cut == 0 || (key_lt(klo, k) && key_lt(k, khi))) {
                         sad += k.a * k.d;
                         sd += k.d;

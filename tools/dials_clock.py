@@ -23,7 +23,9 @@ files = [f for f in sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', sd, '
 imgs = [imread_bgr(f) for f in files]
 base = np.stack([im for im in imgs if im.shape == imgs[-1].shape])
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), B, 2024, dev)
+# optional third argument: which of the four batches tools/run_stage.py and bench.py rotate over (they differ: one slow wave makes a slow launch)
+KB = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), (KB + 1) * B, 2024, dev)[KB * B:]
 (H, W) = base.shape[1:3]
 stream = torch.cuda.current_stream().cuda_stream
 for _ in range(20):
@@ -59,7 +61,8 @@ r = real[:, :6].astype(np.float64) * 0.01   # us
 r -= r[:, 0].min()
 hw = (real[:, 6] & np.uint64(0xffffffff)).astype(np.int64)
 cands = (real[:, 6] >> np.uint64(32)).astype(np.int64)
-xcc = real[:, 7].astype(np.int64)
+xcc = (real[:, 7] & np.uint64(0xffffffff)).astype(np.int64)
+ring = (real[:, 7] >> np.uint64(32)).astype(np.int64)   # points of the needle inside the annulus
 simd = (hw >> 4) & 3
 cu = (hw >> 8) & 15
 se = (hw >> 13) & 7
@@ -120,3 +123,8 @@ for (label, a, b) in seq:
 print('  inside the first phases, median shader cycles [p90]: geometry arrived %.0f [%.0f] | pixels requested %.0f [%.0f] | colour core arrived %.0f [%.0f] | colour and bounds %.0f [%.0f]' % (
     np.median(fz[:, 8] - t8[:, 1]), q(fz[:, 8] - t8[:, 1], 0.9), np.median(fz[:, 9] - fz[:, 8]), q(fz[:, 9] - fz[:, 8], 0.9),
     np.median(fz[:, 10] - fz[:, 9]), q(fz[:, 10] - fz[:, 9], 0.9), np.median(t8[:, 2] - fz[:, 10]), q(t8[:, 2] - fz[:, 10], 0.9)))
+# the slowest waves of the launch
+worst = np.argsort(-r[:, 5])[:6]
+print('  the six waves that end last: ' + '; '.join('frame %d dial %d ends %.1f us, %d candidates, phases %s' % (wgi[i], wvi[i], r[i, 5], cands[i],
+      '/'.join('%.0f' % (t[i, k + 1] - t[i, k]) for k in range(5))) + ', ring points %d' % ring[i] for i in worst))
+print('  ring points per wave: median %d p90 %d p99 %d max %d; waves above 256 (the angle cache): %d, above 512: %d' % (np.median(ring), q(ring, 0.9), q(ring, 0.99), ring.max(), (ring > 256).sum(), (ring > 512).sum()))
