@@ -567,15 +567,21 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
             const uint64_t diag = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
             euler4 = wave_sum_i32(__builtin_popcountll(odd) - 2 * __builtin_popcountll(three) - 2 * __builtin_popcountll(diag));
         }
-        label(M);
+        // E <= 0 means at least as many holes as components, i.e. at least one: no need to label M first to find out
+        bool holes = euler4 <= 0;
+        if (!holes) {
+            label(M);
+            holes = 4 * ncomp != euler4;
+        }
         FSTAMPD(1);
-        if (4 * ncomp != euler4) {
+        if (holes) {
             const uint64_t freeb = ~M;
             uint64_t o = outside0;
-            for (;;) {
-                const uint64_t n = o | ((((o << 1) | (o >> 1)) | row_up(o, lane, ~0ull) | row_down(o, lane, ~0ull)) & freeb);
-                const bool ch2 = n != o;
-                o = n;
+            for (;;) {   // two propagation steps per convergence test, as in the labelling
+                const uint64_t n1 = o | ((((o << 1) | (o >> 1)) | row_up(o, lane, ~0ull) | row_down(o, lane, ~0ull)) & freeb);
+                const uint64_t n2 = n1 | ((((n1 << 1) | (n1 >> 1)) | row_up(n1, lane, ~0ull) | row_down(n1, lane, ~0ull)) & freeb);
+                const bool ch2 = n2 != n1;
+                o = n2;
                 if (__builtin_amdgcn_ballot_w64(ch2) == 0) break;
             }
             label(~o);   // M plus everything its outer borders enclose

@@ -125,6 +125,9 @@ print('  inside the first phases, median shader cycles [p90]: geometry arrived %
     np.median(fz[:, 10] - fz[:, 9]), q(fz[:, 10] - fz[:, 9], 0.9), np.median(t8[:, 2] - fz[:, 10]), q(t8[:, 2] - fz[:, 10], 0.9)))
 # the slowest waves of the launch
 worst = np.argsort(-r[:, 5])[:6]
+print('  their labelling phase (Euler number + labelling of M / holes: outside flood + relabelling): ' + '; '.join('%.0f / %.0f' % (fz[i, 1] - fz[i, 0], t8[i, 4] - fz[i, 1]) for i in worst))
+holes = (t8[:, 4] - fz[:, 1]) > 1000
+print('  waves that took the hole path: %d of %d (per dial %s); of the 5 %% that end last: %d of %d' % (holes.sum(), n, np.bincount(wvi[holes], minlength=nd).tolist(), (holes & late).sum(), late.sum()))
 print('  the six waves that end last: ' + '; '.join('frame %d dial %d ends %.1f us, %d candidates, phases %s' % (wgi[i], wvi[i], r[i, 5], cands[i],
       '/'.join('%.0f' % (t[i, k + 1] - t[i, k]) for k in range(5))) + ', ring points %d' % ring[i] for i in worst))
 print('  ring points per wave: median %d p90 %d p99 %d max %d; waves above 256 (the angle cache): %d, above 512: %d' % (np.median(ring), q(ring, 0.9), q(ring, 0.99), ring.max(), (ring > 256).sum(), (ring > 512).sum()))
