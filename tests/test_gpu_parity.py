@@ -399,6 +399,19 @@ def test_read_dials_stress_random_crops(env):
             c = np.kron(cells, np.ones((6, 6, 1), np.uint8))[:th, :tw]
             c = np.clip(c.astype(np.int64) + rng.integers(-12, 12, size=c.shape), 0, 255).astype(np.uint8)
         crops.append(c)
+    # every dial's disk (or three quarters of it) in the dial's own colour: > 1 000 (> 750) needle pixels inside the annulus -- more
+    # than the angle phase caches (k_dials RING_CAP = 512): the uncached passes
+    for (k, quarter_off) in enumerate((False, True, True)):
+        c = np.empty((th, tw, 3), np.uint8)
+        c[:] = (200, 30, 40)
+        (yy, xx) = np.mgrid[0:th, 0:tw]
+        for d in range(int(ctx.params.ndials)):
+            (cx, cy) = (ctx.params.dial[d].cx, ctx.params.dial[d].cy)
+            inside = (xx - cx) ** 2 + (yy - cy) ** 2 <= 27.0 ** 2
+            if quarter_off:
+                inside &= ~((xx - cx > 2 + k) & (yy - cy > 2))
+            c[inside] = (60 + 20 * d, 120, 150)
+        crops.append(c)
     crops = np.stack(crops)
     recs = ctx.read_dials(crops)
     seen = set()
