@@ -123,6 +123,7 @@ constexpr int DIAL_LIST_CAP = 768;   // candidate pixels of a dial window that t
 // serially along the rows) cost such a wave 60 000 cycles instead of 14 000 -- and the launch, which ends with its slowest wave,
 // 58 us instead of 38.  The squared distances are recomputed from the positions now (six instructions) instead of cached.
 constexpr int RING_CAP = 512;
+constexpr int RING_CAP_REGS = 1024;   // ... beyond the LDS cache: angles in registers, 16 per lane (positions: 2 KiB of the same LDS)
 // LDS of one dial (one wave), carved from the kernel's dynamic block: the ring arrays of the angle phase re-use the
 // candidate list and the in-range bits of the pixel phase (all of them dead by then).
 //   [0, 4096) ra double[RING_CAP]          | pixel phase: [0, 3072) list_px u32[CAP], [3072, 4608) list_pos u16[CAP]
@@ -693,6 +694,93 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
                     Key k;
                     k.a = fabs(a - mina) < 0.75 ? a : a - 1;
                     k.d = ring_d2(list[t]);
+                    if (cut == 0 || (key_lt(klo, k) && key_lt(k, khi))) {
+                        sad += k.a * k.d;
+                        sd += k.d;
+                    }
+                }
+                sad = wave_sum_f64(sad);
+                sd = wave_sum_f64(sd);
+                angle = sad / sd;
+                const double fixed = angle - (D.angle_of_zero / 360.0);
+                pos = py_fmod(10.0 * fixed, 10.0);  // _reading.py:95-96
+            }
+        } else if (rtotal <= RING_CAP_REGS) {
+            // More ring points than the LDS cache holds, up to 1024 (a dial whose disk is mostly "needle": a flare, a wrong match):
+            // the positions go to the list (2 bytes each), the angles stay in REGISTERS, sixteen per lane (point t = lane + 64 j
+            // in ang[j]; the window's pixel registers are dead by now).  One arctangent per point, as in the cached path -- the
+            // passes below this branch compute it once per point AND pass, serially along the rows (60 000 cycles for 260 points).
+            uint16_t* list = (uint16_t*)lds;   // [0, 2048)
+            {
+                int at = rincl - rmine;
+                uint64_t bits = outer;
+                while (bits) {
+                    const int x = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    list[at++] = (uint16_t)(lane << 6 | x);
+                }
+            }
+            auto ring_d2 = [&](int e) {
+                const double dx = (double)(wx0 + (e & 63)) - cx, dy = (double)(wy0 + (e >> 6)) - cy;
+                return dx * dx + dy * dy;
+            };
+            constexpr int NJ = RING_CAP_REGS / 64;
+            double ang[NJ];
+            int nk = 0;
+            double mina = 1e300;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                double keep = __builtin_nan("");
+                if (64 * j < rtotal) {   // wave-uniform
+                    const int t = lane + 64 * j;
+                    if (t < rtotal) {
+                        const int e = list[t];
+                        const double dx = (double)(wx0 + (e & 63)) - cx, dy = (double)(wy0 + (e >> 6)) - cy;
+                        double a;
+                        if (angle_by_vector(dx, dy, a) && have_mom) {
+                            double dist = fabs(a - mom);
+                            const double dist2 = fabs(fabs(a - mom) - 1);
+                            if (dist2 < dist) dist = dist2;
+                            if (dist < 0.25) { keep = a; ++nk; if (a < mina) mina = a; }
+                        }
+                    }
+                }
+                ang[j] = keep;
+            }
+            nk = wave_sum_i32(nk);
+            mina = wave_min_f64(mina);
+            if (nk == 0) {
+                status = 2;  // unreadable dial (_reading.py:79-81)
+            } else {
+                const int cut = nk >= 5 ? min(2, (nk - 3) / 2) : 0;
+                const Key PINF = {1e300, 1e300}, NINF = {-1e300, -1e300};
+                Key klo = NINF, khi = PINF;
+                if (cut > 0) {
+                    Key l1 = PINF, l2 = PINF, h1 = NINF, h2 = NINF;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const double a = ang[j];
+                        if (a != a) continue;
+                        Key k;
+                        k.a = fabs(a - mina) < 0.75 ? a : a - 1;
+                        k.d = ring_d2(list[lane + 64 * j]);
+                        if (key_lt(k, l1)) { l2 = l1; l1 = k; } else if (key_lt(k, l2)) { l2 = k; }
+                        if (key_lt(h1, k)) { h2 = h1; h1 = k; } else if (key_lt(h2, k)) { h2 = k; }
+                    }
+                    for (int c2 = 0; c2 < cut; ++c2) {
+                        wave_min_max_key(l1, h1, klo, khi);
+                        if (l1.a == klo.a && l1.d == klo.d) { l1 = l2; l2 = PINF; }
+                        if (h1.a == khi.a && h1.d == khi.d) { h1 = h2; h2 = NINF; }
+                    }
+                }
+                double sad = 0.0, sd = 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const double a = ang[j];
+                    if (a != a) continue;
+                    Key k;
+                    k.a = fabs(a - mina) < 0.75 ? a : a - 1;
+                    k.d = ring_d2(list[lane + 64 * j]);
                     if (cut == 0 || (key_lt(klo, k) && key_lt(k, khi))) {
                         sad += k.a * k.d;
                         sd += k.d;

@@ -1186,3 +1186,56 @@ def test_dial_window_fetch_edge_paths(env, tmp_path):
         _compare_records(recs, po.process_frames(frames[:48], po.Params(str(tmp_path / 'params.yml'))), tag='windows beyond the crop')
     finally:
         reader.close()
+
+
+@pytest.mark.gpu
+def test_ring_points_beyond_both_angle_caches(env, tmp_path):
+    """k_dials caches the angles of the needle's pixels inside the annulus in LDS (<= 512 points), in registers (<= 1024) or
+    not at all (beyond: an arctangent per point and pass).  A dial with a 20-pixel annulus, its disk wholly / three quarters /
+    one quarter in the dial's colour: ~2 100 / ~1 600 / ~500 ring points -- all three tiers against the oracle."""
+    import shutil
+    import yaml
+    from meterelf_amd import MeterReader, _params
+    from oracle import pyoracle as po
+    e = env['sample-images1']
+    with open(e['pfile']) as fp:
+        data = yaml.safe_load(fp)
+    nd0 = data['needle_data'][0]
+    (nd0['diameter'], nd0['dist_from_center'], nd0['circle_thickness']) = (10, 2, 20)
+    shutil.copy(os.path.join(GOLDEN, 'sample-images1', data['dials_template']), tmp_path / data['dials_template'])
+    with open(tmp_path / 'params.yml', 'w') as fp:
+        yaml.safe_dump(data, fp)
+    reader = MeterReader(_params.load(str(tmp_path / 'params.yml')))
+    oparams = po.Params(str(tmp_path / 'params.yml'))
+    try:
+        ctx = reader.ctx
+        (th, tw) = (ctx.params.th, ctx.params.tw)
+        (yy, xx) = np.mgrid[0:th, 0:tw]
+        crops = []
+        for kind in range(6):
+            c = np.empty((th, tw, 3), np.uint8)
+            c[:] = (200, 30, 40)
+            for d in range(int(ctx.params.ndials)):
+                (cx, cy) = (ctx.params.dial[d].cx, ctx.params.dial[d].cy)
+                inside = (xx - cx) ** 2 + (yy - cy) ** 2 <= 30.0 ** 2
+                if kind % 3 == 1:
+                    inside &= ~((xx - cx > 2) & (yy - cy > 3))
+                if kind % 3 == 2:
+                    inside &= (xx - cx < -1) & (yy - cy > 1 + kind)
+                c[inside] = (60 + 20 * d, 120, 150)
+            if kind >= 3:   # ... and with noise in the lightness, so that the masks are ragged
+                rng = np.random.default_rng(kind)
+                c[..., 1] = np.clip(c[..., 1].astype(np.int64) + rng.integers(-30, 30, size=(th, tw)), 0, 255).astype(np.uint8)
+            crops.append(c)
+        crops = np.stack(crops)
+        recs = ctx.read_dials(crops)
+        for i in range(len(crops)):
+            o = po.read_dials(crops[i], oparams)
+            assert int(recs[i]['status']) == o.status, (i, int(recs[i]['status']), o.status)
+            if o.status == 0:
+                assert np.allclose(recs[i]['pos'][:4], list(o.pos)[:4], rtol=0, atol=POS_TOL), i
+                assert np.allclose(recs[i]['angle'][:4], list(o.angle)[:4], rtol=0, atol=POS_TOL), i
+            elif o.status == 3:
+                assert int(recs[i]['unreadable_mask']) == o.unreadable_mask, i
+    finally:
+        reader.close()
