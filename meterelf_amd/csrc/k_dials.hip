@@ -560,21 +560,33 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
         // quads beyond its edges irrelevant): no holes -> the components of M are the filled contours.  Otherwise, as until round 5:
         // the pixels of ~M that are 4-connected to the outside of the disk (the seed is host-computed: unfilled pockets inside the
         // reference's disk mask -- thin rings -- are not outside), everything else is M plus what its outer borders enclose.
-        int euler4;
+        int euler4, isolated;
         {
             const uint64_t a = M, b = row_down(M, lane, 0), a1 = a >> 1, b1 = b >> 1;
             const uint64_t odd = a ^ a1 ^ b ^ b1;                          // one or three pixels of the quad
             const uint64_t three = odd & ((a & a1) | (b & b1));
             const uint64_t diag = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
             euler4 = wave_sum_i32(__builtin_popcountll(odd) - 2 * __builtin_popcountll(three) - 2 * __builtin_popcountll(diag));
+            // isolated pixels (no 8-neighbour) are components without holes: the rest of the mask has the Euler number E - their count
+            const uint64_t up = row_up(M, lane, 0);
+            const uint64_t nb = (a << 1) | a1 | up | (up << 1) | (up >> 1) | b | (b << 1) | b1;
+            isolated = wave_sum_i32(__builtin_popcountll(a & ~nb));
         }
-        // E <= 0 means at least as many holes as components, i.e. at least one: no need to label M first to find out
-        bool holes = euler4 <= 0;
+        // E <= 0 -- here for the mask without its isolated pixels -- means at least as many holes as components, i.e. at least one
+        // (or nothing but isolated pixels: the flood path is right for any mask, only slower): no need to label M first to find out
+        bool holes = euler4 - 4 * isolated <= 0;
         if (!holes) {
             label(M);
             holes = 4 * ncomp != euler4;
         }
         FSTAMPD(1);
+#ifdef MELF_DIALS_STAMP
+        if (lane == 0 && (int)(blockIdx.x * (blockDim.x >> 6) + wv) < 8192) {
+            g_dials_fine[16 * (blockIdx.x * (blockDim.x >> 6) + wv) + 12] = (uint64_t)(uint32_t)euler4;
+            g_dials_fine[16 * (blockIdx.x * (blockDim.x >> 6) + wv) + 13] = (uint64_t)(uint32_t)ncomp;
+            g_dials_fine[16 * (blockIdx.x * (blockDim.x >> 6) + wv) + 14] = (uint64_t)(uint32_t)isolated;
+        }
+#endif
         if (holes) {
             const uint64_t freeb = ~M;
             uint64_t o = outside0;

@@ -131,3 +131,10 @@ print('  waves that took the hole path: %d of %d (per dial %s); of the 5 %% that
 print('  the six waves that end last: ' + '; '.join('frame %d dial %d ends %.1f us, %d candidates, phases %s' % (wgi[i], wvi[i], r[i, 5], cands[i],
       '/'.join('%.0f' % (t[i, k + 1] - t[i, k]) for k in range(5))) + ', ring points %d' % ring[i] for i in worst))
 print('  ring points per wave: median %d p90 %d p99 %d max %d; waves above 256 (the angle cache): %d, above 512: %d' % (np.median(ring), q(ring, 0.9), q(ring, 0.99), ring.max(), (ring > 256).sum(), (ring > 512).sum()))
+# hole-path waves: Euler number (x 4), components of M (0 = the Euler number alone proved the hole), isolated pixels
+e4 = fine[:, 12].astype(np.int64).astype(np.int32).astype(np.int64)
+nc = fine[:, 13].astype(np.int64)
+iso = fine[:, 14].astype(np.int64)
+from collections import Counter
+print('  hole-path waves by (Euler number, components of M labelled first, isolated pixels): %s' % sorted(Counter(zip((e4[holes] // 4).tolist(), nc[holes].tolist(), iso[holes].tolist())).items()))
+print('  the other waves by components of M: %s' % sorted(Counter(nc[~holes].tolist()).items()))
