@@ -25,7 +25,9 @@
 // (tools/ubench/mfma_i8_layout.hip): A lane l = A[l & 31][16 (l >> 5) + j],
 // B lane l = B[16 (l >> 5) + j][l & 31], D lane l reg r = D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
 #include <limits.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -37,6 +39,7 @@
 namespace melf {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------
@@ -57,8 +60,13 @@ typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 // of a match wave finds the row-window sums of its accumulator elements e = 8 half + q of column block xb, i.e. of map columns
 // x = 32 xb + (e & 3) + 8 (e >> 2) + 4 hh, in one lane-contiguous 16-byte piece.  The match waves add them up over the template
 // rows themselves (k_match_mfma since round 3, k_match_gen since round 4): no column-sum kernel, no window-sum array.
+// pairs (k_match_mfma, round 6; 0 for the general kernel): the first `pairs` image blocks share their registers with blocks
+// 6 .. 6 + pairs - 1 as the B operand of a 2:4-sparse matrix instruction: P_p = blocks (p, p + 6), dword t of lane (n, h) =
+// {L'[32 p + 16 h + 2 t], L'[.. + 1], L'[32 (p + 6) + 16 h + 2 t], L'[.. + 1]}, dwords 0-3 in 1 KiB slot 2 p, dwords 4-7 in slot
+// 2 p + 1; the blocks in between follow in plain fragment order (slots 2 pairs ..).  The two threads of a pair swap the halves the
+// other one needs (lane shuffles) and interleave them with v_perm_b32; the row still leaves in coalesced 16-byte stores.
 template <bool FROM_BGR>
-__global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw, int rwp,
+__global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw, int rwp, int pairs,
                                                      int8_t* __restrict__ Lg, uint16_t* __restrict__ R)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[8 * 2 * 32 * 4];  // [kb][h][n][16 B], one chunk of 8 blocks
@@ -118,10 +126,40 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
         }
         if (kc) __syncthreads();  // the previous chunk's tile has been written out
         // fragment-order image of the row
+        if (pairs == 0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
-            *(u32x4m*)(tile + ((kl * 2 + h) * 32 + n) * 4) = v;
+            for (int h = 0; h < 2; ++h) {
+                u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
+                *(u32x4m*)(tile + ((kl * 2 + h) * 32 + n) * 4) = v;
+            }
+        } else {
+            // (uniform branch; nkb <= 8: one chunk)  role of this thread's block: low member p of a pair, high member p + 6, or plain
+            const bool lo = kl < pairs, hi = kl >= 6 && kl < 6 + pairs;
+            const int partner = lo ? kl + 6 : (hi ? kl - 6 : kl);
+            uint32_t got[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) got[q] = (uint32_t)__shfl((int)(lo ? w[4 + q] : w[q]), partner, 8);   // the low member hands over its h = 1 half, the high member its h = 0 half
+            if (lo || hi) {
+                // low member: lane half h = 0 of P (own columns 0..15 with the partner's); high member: h = 1 (the partner's columns 16..31 with its own)
+                const int h = hi ? 1 : 0, p = lo ? kl : kl - 6;
+                uint32_t o[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const uint32_t mine = w[4 * h + (t >> 1)], other = got[t >> 1];
+                    const uint32_t a = lo ? mine : other, b = lo ? other : mine;   // a = block p's pair of columns, b = block p + 6's
+                    o[t] = __builtin_amdgcn_perm(b, a, (t & 1) ? 0x07060302u : 0x05040100u);
+                }
+                u32x4m v0 = {o[0], o[1], o[2], o[3]}, v1 = {o[4], o[5], o[6], o[7]};
+                *(u32x4m*)(tile + (((2 * p) * 2 + h) * 32 + n) * 4) = v0;
+                *(u32x4m*)(tile + (((2 * p + 1) * 2 + h) * 32 + n) * 4) = v1;
+            } else if (kl < nkb) {
+                const int slot = kl + pairs;   // blocks pairs .. 5 -> slots 2 pairs ..
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
+                    *(u32x4m*)(tile + ((slot * 2 + h) * 32 + n) * 4) = v;
+                }
+            }
         }
         // inclusive prefix sums of L' along the row: 32 local sums, then a scan over the frame's 8 lanes
         int loc[32];
@@ -230,6 +268,7 @@ struct SliceLds {
     uint32_t wsa[32][64];            // window sums of the tile's first map row
 };
 
+constexpr int MM_NF_DEV = 8;   // template fragments per row in Atab (= MM_NF of the host side)
 template <int ND, int NXB, int R, int PD /* prefetch distance in template rows */, int MFIRST, int MLAST, int KS = 1>
 __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const int8_t* __restrict__ Atab,
                                            const uint32_t* __restrict__ ws, const MfmaGeom& g,
@@ -254,9 +293,27 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
         __syncthreads();
     }
 
-    const i32x4* Lrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + y0) * (size_t)NKB * 1024) + lane;
-    const i32x4* Ap = (const i32x4*)Atab + lane;
-    constexpr int ROWV = NKB * 64;  // i32x4 per image row
+    // Every operand is fetched with a buffer load: resource in scalar registers, ONE vector register (16 lane) as the offset of
+    // every load of the kernel, the row / slot part as a 32-bit scalar offset -- no address arithmetic on the vector ALU and no
+    // 64-bit address pairs in the register file the accumulators and row buffers fill.
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Lg + (size_t)grp * g.rows_pad * (size_t)NKB * 1024), 0,
+                                                                         (int)((unsigned)g.rows_pad * (unsigned)NKB * 1024u), 0x27000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Atab + 1024), 0, (int)((unsigned)(g.th_pad + PD) * MM_NF_DEV * 1024u), 0x27000);
+    // row-window sums of the group; an offset at or beyond the end reads zeros (the hardware's range check): that is the "row" of a padding template row
+    const unsigned rsR_bytes = (unsigned)g.rows * 4096u;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ws + (size_t)grp * g.rows * 1024), 0, (int)rsR_bytes, 0x27000);
+    auto LD = [&](__amdgpu_buffer_rsrc_t rs, unsigned rowoff, int slot) -> i32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, l16, rowoff + (unsigned)slot * 1024u, 0);
+    };
+    const unsigned Lrow = (unsigned)y0 * (unsigned)NKB * 1024u;   // image row y0 + r at + r ROWB
+    const int idxP = ((const int*)Atab)[lane];               // 2:4 positions of the (d = 0, d = ND - 1) pair: the same for every template row
+    const int idxLo = 0x44444444, idxHi = (int)0xEEEEEEEEu;  // "positions 0, 1" / "positions 2, 3" of every group of four
+    constexpr unsigned ROWB = (unsigned)NKB * 1024u;  // bytes per image row
+    constexpr unsigned AROWB = (unsigned)MM_NF_DEV * 1024u;   // bytes per template row in Atab
+    constexpr int NP = NXB;         // paired operands per image row: P0 = blocks (0, ND - 1) [, P1 = blocks (1, ND)]
+    constexpr int NKD = NKB - 2 * NP;   // plain fragments per image row: blocks NP .. NP + NKD - 1 (slots 2 NP ..)
+    static_assert(ND == 7 && (NXB == 1 || NXB == 2), "the sub-block schedule below is written out for 7 Toeplitz blocks");
 
     i32x16 acc[R][NXB];
 #pragma unroll
@@ -276,107 +333,180 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // while its output rows are only R lower, so neighbouring blocks are PERIOD - R image rows apart.
     // start so that image row y0 + i is roughly the same for every block at any moment (rounded to the
     // rotation period)
-#if defined(MELF_MATCH_EXPERIMENT) && (MELF_MATCH_EXPERIMENT & 32)
-    const int istart = i_lo;  // diagnostic: no rotation of the template-row order (one priming phase)
-#else
     const int istart = i_lo + (((SL - y0 % SL) % SL) / PERIOD) * PERIOD;   // inside the wave's slice [i_lo, i_hi)
-#endif
-    i32x4 buf[NBUF][NKB];
-    // ONE set of template fragments (28 registers instead of 56): the request for the next template row's fragment d
-    // is placed behind this row's last MFMA that reads fragment d -- a full step (70 MFMAs) ahead of its use, as
-    // before.  (The kernel uses 447-488 of the SIMD's 512 registers, one wave per SIMD; round 2's register cap for a
-    // co-resident wave of another kernel is gone: profiles/r03/match_vgpr_cap_ab.txt.)
-    i32x4 a[ND];
+    // Image-row registers: the paired operands (8 registers each, B operand of the sparse instruction) and the plain fragments.
+    // The incoming row's pieces are requested right after the oldest row's last use of the same piece: the two never live at
+    // once, so the ring costs R rows + a fragment or two instead of R + 1 rows.
+    i32x8 pp[NBUF][NP];
+    i32x4 kd[NBUF][NKD];
+    // ONE set of template fragments: the request for the next template row's fragment is placed behind this row's last
+    // matrix instruction that reads it -- a full step ahead of its use.  a06 = the compressed pair, ad[0..4] = d = 1..5 dense,
+    // a1s / a5s (two column blocks only) = d = 1 / d = 5 laid out for the low / high positions of a paired operand.
+    i32x4 a06, ad[5], a1s, a5s;
     // fused window sums: wsa[16 xb + e] of map row y0 for this lane's (frame, half); rwv = the row in flight
     uint32_t wsa[32];
     i32x4 rwv[4];
-    const i32x4* const Rrows = (const i32x4*)ws + (size_t)grp * g.rows * 256 + lane;                             // row r at + 256 r
-    const i32x4* const Zrow = (const i32x4*)(Lg + ((size_t)grp * g.rows_pad + g.rows) * (size_t)NKB * 1024) + lane;  // an all-zero L' row
-    auto rw_row = [&](int i) -> const i32x4* {   // row-window sums of image row y0 + i; template rows >= th are padding
-        return i < g.th ? Rrows + (size_t)min(y0 + i, g.rows - 1) * 256 : Zrow;
+    auto rw_row = [&](int i) -> unsigned {   // row-window sums of image row y0 + i; template rows >= th are padding (zeros)
+        return i < g.th ? (unsigned)min(y0 + i, g.rows - 1) * 4096u : rsR_bytes;
     };
+    auto load_pp = [&](i32x8& d, unsigned row, int slot) {
+        const i32x4 lo = LD(rsL, row, slot), hi = LD(rsL, row, slot + 1);
+        d = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto SP = [&](int r, int xb, const i32x4& a, const i32x8& b, int idx) {
+        if (on(r, xb)) acc[r][xb] = __builtin_amdgcn_smfmac_i32_32x32x64_i8(a, b, acc[r][xb], idx, 0, 0);
+    };
+    auto DN = [&](int r, int xb, const i32x4& a, const i32x4& b) {
+        if (on(r, xb)) acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[r][xb], 0, 0, 0);
+    };
+    // matrix instructions of a sub-block that covers column block xb only / both
+    constexpr int NM1_0 = R - ((MFIRST & 1) == 0) - ((MLAST & 1) == 0);                       // xb = 0 (a row's block may belong to the neighbour wave)
+    constexpr int NM1_1 = NXB == 2 ? R - ((MFIRST & 2) == 0) - ((MLAST & 2) == 0) : 0;        // xb = 1
+    constexpr int NM2 = NM1_0 + NM1_1;
 #pragma unroll
     for (int j = 0; j < 32; ++j) wsa[j] = 0;
+    // piece p of this template row's R row (requested a step ago) joins the window sums, its additions issued BETWEEN the
+    // sub-block's matrix instructions (a vector instruction that issues while a matrix instruction runs is free; a cluster
+    // of them in front of the sub-block holds the matrix pipe up)
+    auto ws_add = [&](int p) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t v = (uint32_t)rwv[p][c];
+            wsa[8 * p + 2 * c] += v & 0xffffu;
+            wsa[8 * p + 2 * c + 1] += v >> 16;
+            // an empty, zero-instruction asm keeps the optimiser from reasoning through the chain of several
+            // hundred additions per accumulator (InstCombine took minutes per instantiation without it)
+            asm("" : "+v"(wsa[8 * p + 2 * c]));
+            asm("" : "+v"(wsa[8 * p + 2 * c + 1]));
+        }
+    };
+#define MELF_SGB(MFMAS, VALUS) __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALUS, 0);
+#define MELF_SPREAD(NM) \
+    if constexpr ((NM) >= 8) { MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) } \
+    else if constexpr ((NM) >= 4) { MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) } \
+    else { MELF_SGB(1, 4) MELF_SGB(1, 4) }
+#define MELF_FENCE __builtin_amdgcn_sched_barrier(0);
     for (int phase = 0; phase < 2; ++phase) {
         const int ibeg = phase == 0 ? istart : i_lo, iend = phase == 0 ? i_hi : istart;
         if (ibeg >= iend) continue;
         // (re-)prime: image rows y0+ibeg .. y0+ibeg+R+PD-2 and template row ibeg
 #pragma unroll
-        for (int r = 0; r < NBUF - 1; ++r)
+        for (int r = 0; r < NBUF - 1; ++r) {
+            const unsigned row = Lrow + (unsigned)(ibeg + r) * ROWB;
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-                buf[r][kb] = Lrow[(size_t)(ibeg + r) * ROWV + kb * 64];
+            for (int p = 0; p < NP; ++p) load_pp(pp[r][p], row, 2 * p);
 #pragma unroll
-        for (int d = 0; d < ND; ++d) a[d] = Ap[((size_t)ibeg * ND + d) * 64];
+            for (int c = 0; c < NKD; ++c) kd[r][c] = LD(rsL, row, 2 * NP + c);
+        }
         {
-            const i32x4* rp = rw_row(ibeg);
+            const unsigned an = (unsigned)ibeg * AROWB;
+            a06 = LD(rsA, an, 0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rwv[k] = rp[k * 64];
+            for (int d = 0; d < 5; ++d) ad[d] = LD(rsA, an, 1 + d);
+            if constexpr (NXB == 2) { a1s = LD(rsA, an, 6); a5s = LD(rsA, an, 7); }
+            const unsigned rp = rw_row(ibeg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rwv[k] = LD(rsR, rp, k);
         }
         for (int i0 = ibeg; i0 < iend; i0 += PERIOD) {
 #pragma unroll
             for (int s = 0; s < PERIOD; ++s) {
                 const int i = i0 + s;
-                // Loads for later steps are spread over this step's MFMA sub-blocks (one image-row
-                // fragment and one template fragment per ten MFMAs) and pinned there with
-                // sched_barrier: they stay in flight for a whole step while the matrix pipe never
-                // waits for a burst of load issue.  (Left to itself hipcc sinks each load next to its
-                // first use and waits vmcnt(0) every ten MFMAs: 26 % MFMA utilisation.)
+                // Loads for later steps are spread over this step's sub-blocks of matrix instructions and pinned there with
+                // sched_barrier: they stay in flight for a whole step while the matrix pipe never waits for a burst of load
+                // issue.  (Left to itself hipcc sinks each load next to its first use and waits vmcnt(0) every few MFMAs.)
+                const unsigned rowin = Lrow + (unsigned)(i + NBUF - 1) * ROWB;   // image row y0 + i + R + PD - 1: first needed at step i + PD
+                const unsigned an = (unsigned)(i + 1) * AROWB;             // template row i + 1 (the table carries one extra all-zero row)
+                const unsigned rwn = rw_row(i + 1);
+                const int inc = (s + NBUF - 1) % NBUF;   // (constant after unrolling)
+#define CUR(r) ((s + (r)) % NBUF)
+                if constexpr (NXB == 2) {
+                    // Six matrix instructions per (row, column block): block xb meets image blocks xb .. xb + 6; its first and last
+                    // Toeplitz blocks (d = 0: columns k >= m only; d = 6: k <= m - 5 only) share ONE 2:4-sparse instruction over the
+                    // paired operand P_xb = image blocks (xb, xb + 6); d = 1 of block 0 sits in the low positions of P1 and d = 5 of
+                    // block 1 in the high positions of P0 (sparse instructions with fixed positions); the rest is dense.
+                    // -- q0: the pair, both column blocks
+                    MELF_FENCE
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    // Image row y0 + i + R + PD - 1 is first needed (as row R-1) at step i + PD.  Its fragment kb is
-                    // requested one sub-block AFTER this step's last read of the oldest row's fragment kb (sub-block kb,
-                    // xb = 0): the two never live at once, so the incoming row shares the oldest row's registers and
-                    // the ring costs R rows + a fragment or two instead of R + 1 rows.
+                    for (int r = 0; r < R; ++r) { SP(r, 0, a06, pp[CUR(r)][0], idxP); SP(r, 1, a06, pp[CUR(r)][1], idxP); }
+                    ws_add(0);
+                    MELF_SPREAD(NM2)
+                    MELF_FENCE
+                    a06 = LD(rsA, an, 0);
+                    // -- q1: d = 5 of column block 1 (image block 6 = high half of P0)
+                    rwv[0] = LD(rsR, rwn, 0);
+                    MELF_FENCE
 #pragma unroll
-                    for (int kb = (d == 0 ? NKB : d - 1); kb < (d == 0 ? NKB : d); ++kb)
-                        buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
-                    // row-window sums: piece d - 1 of the NEXT template row's R row goes into the registers whose previous
-                    // content (this row's piece) was added up in sub-block d - 1
-                    if (d >= 1 && d <= 4) rwv[d - 1] = rw_row(i + 1)[(d - 1) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (d < 4) {   // piece d of this template row's R row, requested a step ago
+                    for (int r = 0; r < R; ++r) SP(r, 1, a5s, pp[CUR(r)][0], idxHi);
+                    MELF_FENCE
+                    a5s = LD(rsA, an, 7);
+                    // -- q2: d = 1 of column block 0 (image block 1 = low half of P1); the oldest row's P0 is free
+                    load_pp(pp[inc][0], rowin, 0);
+                    MELF_FENCE
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const uint32_t v = (uint32_t)rwv[d][c];
-                            wsa[8 * d + 2 * c] += v & 0xffffu;
-                            wsa[8 * d + 2 * c + 1] += v >> 16;
-                            // an empty, zero-instruction asm keeps the optimiser from reasoning through the chain of several
-                            // hundred additions per accumulator (InstCombine took minutes per instantiation without it)
-                            asm("" : "+v"(wsa[8 * d + 2 * c]));
-                            asm("" : "+v"(wsa[8 * d + 2 * c + 1]));
-                        }
+                    for (int r = 0; r < R; ++r) SP(r, 0, a1s, pp[CUR(r)][1], idxLo);
+                    MELF_FENCE
+                    a1s = LD(rsA, an, 6);
+                    // -- q3: d = 1 of column block 1 (image block 2)
+                    load_pp(pp[inc][1], rowin, 2);
+                    MELF_FENCE
+#pragma unroll
+                    for (int r = 0; r < R; ++r) DN(r, 1, ad[0], kd[CUR(r)][0]);
+                    MELF_FENCE
+                    ad[0] = LD(rsA, an, 1);
+                    // -- q4 .. q6: d = 2, 3, 4 of block 0 with d = 2, 3, 4 of block 1
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        if (q >= 1) { kd[inc][q - 1] = LD(rsL, rowin, 4 + q - 1); rwv[q] = LD(rsR, rwn, q); }
+                        MELF_FENCE
+#pragma unroll
+                        for (int r = 0; r < R; ++r) { DN(r, 0, ad[1 + q], kd[CUR(r)][q]); DN(r, 1, ad[1 + q], kd[CUR(r)][q + 1]); }
+                        ws_add(1 + q);
+                        MELF_SPREAD(NM2)
+                        MELF_FENCE
+                        ad[1 + q] = LD(rsA, an, 2 + q);
                     }
+                    // -- q7: d = 5 of column block 0 (image block 5)
+                    kd[inc][2] = LD(rsL, rowin, 6);
+                    rwv[3] = LD(rsR, rwn, 3);
+                    MELF_FENCE
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
+                    for (int r = 0; r < R; ++r) DN(r, 0, ad[4], kd[CUR(r)][3]);
+                    MELF_FENCE
+                    ad[4] = LD(rsA, an, 5);
+                    kd[inc][3] = LD(rsL, rowin, 7);
+                    MELF_FENCE
+                } else {
+                    // one column block: the pair over P0 = image blocks (0, 6), then d = 1 .. 5 dense over blocks 1 .. 5
+                    MELF_FENCE
 #pragma unroll
-                        for (int xb = 0; xb < NXB; ++xb)
-                            if (on(r, xb))
-                                acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], buf[(s + r) % NBUF][d + xb], acc[r][xb], 0, 0, 0);
-                    if (d < 4) {
-                        // ... issued BETWEEN the sub-block's MFMAs (a vector instruction that issues while a matrix
-                        // instruction runs is free; a cluster of them in front of the sub-block holds the matrix pipe up)
-                        constexpr int NM = R * NXB - (NXB == 2 ? (MFIRST != 3) + (MLAST != 3) : 0);   // MFMAs of the sub-block
-#define MELF_SGB(MFMAS, VALUS) __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALUS, 0);
-                        if constexpr (NM >= 8) { MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) MELF_SGB(1, 1) }
-                        else if constexpr (NM >= 4) { MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) }
-                        else { MELF_SGB(1, 4) MELF_SGB(1, 4) }
-#undef MELF_SGB
+                    for (int r = 0; r < R; ++r) SP(r, 0, a06, pp[CUR(r)][0], idxP);
+                    ws_add(0);
+                    MELF_SPREAD(NM1_0)
+                    MELF_FENCE
+                    a06 = LD(rsA, an, 0);
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) {
+                        if (d == 0) load_pp(pp[inc][0], rowin, 0);
+                        else kd[inc][d - 1] = LD(rsL, rowin, 2 + d - 1);
+                        if (d < 4) rwv[d] = LD(rsR, rwn, d);
+                        MELF_FENCE
+#pragma unroll
+                        for (int r = 0; r < R; ++r) DN(r, 0, ad[d], kd[CUR(r)][d]);
+                        if (d < 3) { ws_add(1 + d); MELF_SPREAD(NM1_0) }
+                        MELF_FENCE
+                        ad[d] = LD(rsA, an, 1 + d);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // fragment d of template row i + 1 (the table carries one extra all-zero row), into the registers the
-                    // MFMAs above have just read: issued in the shadow of the running MFMAs
-                    a[d] = Ap[((size_t)(i + 1) * ND + d) * 64];
-                    if (d == ND - 1) {  // the incoming row's last fragments
-#pragma unroll
-                        for (int kb = ND - 1; kb < NKB; ++kb)
-                            buf[(s + NBUF - 1) % NBUF][kb] = Lrow[(size_t)(i + NBUF - 1) * ROWV + kb * 64];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    kd[inc][4] = LD(rsL, rowin, 6);
+                    MELF_FENCE
                 }
+#undef CUR
             }
         }
     }
+#undef MELF_SGB
+#undef MELF_SPREAD
+#undef MELF_FENCE
 
 #ifdef MELF_MATCH_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_match_loop_end[blockIdx.x] = __builtin_amdgcn_s_memtime();
@@ -427,10 +557,10 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // ahead (while row r - 1's arithmetic runs)
     i32x4 slide[2][4];
     auto slide_load = [&](int r) {
-        const i32x4* rout = Rrows + (size_t)min(y0 + r - 1, g.rows - 1) * 256;
-        const i32x4* rin = Rrows + (size_t)min(y0 + r - 1 + g.th, g.rows - 1) * 256;
+        const unsigned rout = (unsigned)min(y0 + r - 1, g.rows - 1) * 4096u;
+        const unsigned rin = (unsigned)min(y0 + r - 1 + g.th, g.rows - 1) * 4096u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { slide[0][k] = rout[k * 64]; slide[1][k] = rin[k * 64]; }
+        for (int k = 0; k < 4; ++k) { slide[0][k] = LD(rsR, rout, k); slide[1][k] = LD(rsR, rin, k); }
     };
 #pragma unroll
     for (int r0 = 0; r0 < R; r0 += RB) {
@@ -551,6 +681,7 @@ __global__ __launch_bounds__(64 * KS, 1) void k_match_mfma(const int8_t* __restr
 // host side
 // ---------------------------------------------------------------------------
 constexpr int MM_ND = 7, MM_PD = 1;
+constexpr int MM_NF = 8;   // template fragments per row in Atab (mfma_build_atab)
 // Template rows are padded with zero rows to a multiple of every wave type's rotation period (R + PD image-row
 // buffers): a launch with RB-row waves and pairs of (RB + 1)-row waves needs lcm(RB + 1, RB + 2), without pairs
 // RB + 1.  The fragment table carries the largest padding any layout can ask for (60 = lcm(3, 4, 5, 6)).
@@ -568,7 +699,8 @@ bool mfma_match_ok(int th, int tw, int rows, int cols)
     const int rh = rows - th + 1, rw = cols - tw + 1;
     const int nd = (tw + 31 + 31) / 32;  // Toeplitz blocks per template row
     // th * tw * 255^2 < 2^32: the epilogue adds the correlation's three terms modulo 2^32
-    return rh >= 1 && rw >= 1 && rw <= 64 && nd == MM_ND && cols <= 32 * (MM_ND + (rw > 32 ? 2 : 1) - 1) &&
+    // tw <= 32 (nd - 1): the first and last Toeplitz blocks of a template row never meet in a group of four (mfma_build_atab)
+    return rh >= 1 && rw >= 1 && rw <= 64 && nd == MM_ND && tw <= 32 * (MM_ND - 1) && cols <= 32 * (MM_ND + (rw > 32 ? 2 : 1) - 1) &&
            (long)th * tw * 65025L < (1L << 32);
 }
 
@@ -580,8 +712,9 @@ bool mfma_match_ok(int th, int tw, int rows, int cols)
 // through LDS (zeroing, ~150 ds_add + as many reads, two barriers -- one of them waits for the tile's slowest slice) ~6 000.
 static double mm_wave_cycles(int R, int units, int nxb, int th_pad, int ks = 1)
 {
-    const int nkb = MM_ND + nxb - 1;   // image-row fragments per step; + MM_ND template fragments + 4 pieces of the R row
-    return (double)(th_pad / ks) * ((double)units * MM_ND * 33.0 + (double)(nkb + MM_ND + 4) * 11.0) + (double)((units + ks - 1) / ks) * 2400.0 + 4000.0 + R * 1200.0 +
+    const int nkb = MM_ND + nxb - 1;   // image-row fragments per step; + the template fragments + 4 pieces of the R row
+    const int nf = nxb == 2 ? 8 : 6;   // template fragments per step; MM_ND - 1 matrix instructions per unit (the first and last Toeplitz blocks pair up)
+    return (double)(th_pad / ks) * ((double)units * (MM_ND - 1) * 33.0 + (double)(nkb + nf + 4) * 11.0) + (double)((units + ks - 1) / ks) * 2400.0 + 4000.0 + R * 1200.0 +
            (ks > 1 ? 6000.0 : 0.0);
 }
 
@@ -637,28 +770,71 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
     return p;
 }
 
+// Atab: a 1 KiB header (the pair's index dword of every lane), then MM_NF fragments of 1 KiB per template row
 size_t mfma_atab_bytes(int th)
 {
-    return (size_t)(mm_th_pad_max(th) + MM_PD) * MM_ND * 1024;
+    return 1024 + (size_t)(mm_th_pad_max(th) + MM_PD) * MM_NF * 1024;
 }
 
-// Atab[i][d][lane][j] = T'[i][32 d + 16 (lane >> 5) + j - (lane & 31)], zero outside the template
+// The template as matrix-instruction A operands.  With T'[i][c] = templ - 128 inside the template and 0 outside, Toeplitz block d of
+// template row i is A_d[m][k] = T'[i][32 d + k - m] (m = map column inside a 32-column block, k = image column inside a 32-column
+// image block).  Per template row, fragments of 64 lanes x 16 bytes:
+//   f = 1 .. 5: A_d, d = f, dense: lane l byte j = A_d[l & 31][16 (l >> 5) + j]               (v_mfma_i32_32x32x32_i8)
+//   f = 0:      A_0 and A_6 in ONE 2:4-sparse operand over the paired image operand P (dword t of P's lane (n, h) = image block
+//               kb, columns 16 h + 2 t, + 1, then block kb + 6, same columns): A_0 is non-zero only for k >= m, A_6 only for
+//               k <= m - (193 - tw), so of the four candidates of a group {A_0[k0], A_0[k0 + 1], A_6[k0], A_6[k0 + 1]} at most two
+//               are ever inside the template -- for tw <= 192.  Compressed byte ja of lane (m, hA) belongs to the group of P's
+//               lane half hB = ja >> 3, dword t = 4 hA + ((ja >> 1) & 3), i.e. k0 = 16 hB + 2 t (v_smfmac_i32_32x32x64_i8; the map was
+//               found by probing the instruction: tools/ubench/smfmac_i8.hip); its 2-bit position goes to bits 2 ja of the lane's
+//               index dword, which depends on (m, hA, ja) only and is stored once, in the header
+//   f = 6:      A_1 for the LOW positions of a paired operand (image block 1 lives in P1 = blocks (1, 7)): bytes A_1[m][k0], A_1[m][k0 + 1], index 0x4 per group
+//   f = 7:      A_5 for the HIGH positions (image block 6 lives in P0 = blocks (0, 6)): index 0xE per group
 void mfma_build_atab(const uint8_t* templ, int th, int tw, int8_t* atab)
 {
     const int th_pad = mm_th_pad_max(th);
-    for (int i = 0; i < th_pad + MM_PD; ++i)
-        for (int d = 0; d < MM_ND; ++d)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 16; ++j) {
-                    const int col = 32 * d + 16 * (l >> 5) + j - (l & 31);
-                    int8_t v = 0;
-                    if (i < th && col >= 0 && col < tw) v = (int8_t)((int)templ[(size_t)i * tw + col] - 128);
-                    atab[(((size_t)i * MM_ND + d) * 64 + l) * 16 + j] = v;
-                }
+    uint32_t* idx = (uint32_t*)atab;
+    memset(atab, 0, 1024);
+    int8_t* fr = atab + 1024;
+    auto cand_cols = [&](int m, int hA, int ja, int cols[4]) {
+        const int hB = ja >> 3, t = 4 * hA + ((ja >> 1) & 3), k0 = 16 * hB + 2 * t;
+        cols[0] = k0 - m; cols[1] = k0 + 1 - m; cols[2] = 32 * (MM_ND - 1) + k0 - m; cols[3] = cols[2] + 1;
+        return k0;
+    };
+    // positions of the pair's two compressed bytes per group: the candidates inside the template, in increasing position,
+    // filled up with unused positions (their bytes are zero)
+    int pos[64][16];
+    for (int l = 0; l < 64; ++l)
+        for (int ja = 0; ja < 16; ja += 2) {
+            int cols[4], cand[4], nc = 0;
+            cand_cols(l & 31, l >> 5, ja, cols);
+            for (int v = 0; v < 4; ++v) if (cols[v] >= 0 && cols[v] < tw) cand[nc++] = v;
+            if (nc > 2) { fprintf(stderr, "[melf] mfma_build_atab: template of %d columns does not pair up\n", tw); abort(); }
+            int v0 = 0, v1 = 1;
+            if (nc == 2) { v0 = cand[0]; v1 = cand[1]; }
+            else if (nc == 1) { v0 = cand[0] < 3 ? cand[0] : 0; v1 = 3; }
+            pos[l][ja] = v0; pos[l][ja + 1] = v1;
+            idx[l] |= ((uint32_t)v0 << (2 * ja)) | ((uint32_t)v1 << (2 * ja + 2));
+        }
+    for (int i = 0; i < th_pad + MM_PD; ++i) {
+        auto Tq = [&](int col) -> int8_t { return (i < th && col >= 0 && col < tw) ? (int8_t)((int)templ[(size_t)i * tw + col] - 128) : (int8_t)0; };
+        int8_t* row = fr + (size_t)i * MM_NF * 1024;
+        for (int l = 0; l < 64; ++l) {
+            const int m = l & 31, hA = l >> 5;
+            for (int d = 1; d <= 5; ++d)
+                for (int j = 0; j < 16; ++j) row[((size_t)d * 64 + l) * 16 + j] = Tq(32 * d + 16 * hA + j - m);
+            for (int ja = 0; ja < 16; ++ja) {
+                int cols[4];
+                const int k0 = cand_cols(m, hA, ja & ~1, cols);
+                row[((size_t)0 * 64 + l) * 16 + ja] = Tq(cols[pos[l][ja]]);
+                row[((size_t)6 * 64 + l) * 16 + ja] = Tq(32 * 1 + k0 + (ja & 1) - m);
+                row[((size_t)7 * 64 + l) * 16 + ja] = Tq(32 * 5 + k0 + (ja & 1) - m);
+            }
+        }
+    }
 }
 
 void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int tw, int8_t* d_lg,
-                       uint16_t* d_r, hipStream_t stream)
+                       uint16_t* d_r, hipStream_t stream, int pairs)
 {
     dim3 grid(rows_pad, groups), block(256);
     const size_t pre_bytes = (size_t)32 * (nkb * 32 + 8) * sizeof(int16_t);
@@ -670,15 +846,15 @@ void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, in
         (void)hipFuncSetAttribute((const void*)k_prep_lplane<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_set[dev] = true;
     }
-    if (from_bgr) hipLaunchKernelGGL((k_prep_lplane<true>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
-    else hipLaunchKernelGGL((k_prep_lplane<false>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, d_lg, d_r);
+    if (from_bgr) hipLaunchKernelGGL((k_prep_lplane<true>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, pairs, d_lg, d_r);
+    else hipLaunchKernelGGL((k_prep_lplane<false>), grid, block, pre_bytes, stream, src, n, nkb, rows_pad, tw, rwp, pairs, d_lg, d_r);
 }
 
 void launch_mfma_prep(const MatchSrc& src, bool from_bgr, int n, const MfmaPlan& p, int th, int tw, int8_t* d_lg,
                       uint16_t* d_r, hipStream_t stream)
 {
     (void)th;
-    launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, tw, d_lg, d_r, stream);
+    launch_match_prep(src, from_bgr, n, p.groups, p.rows_pad, p.nkb, 64, tw, d_lg, d_r, stream, p.nxb);   // one paired operand per column block
 }
 
 template <int NXB, int RB, int KS>

@@ -446,7 +446,7 @@ static int setup_device_tables(melf_ctx* c)
     for (size_t i = 0; i < (size_t)th * tw; ++i) tsum += c->h_templ[i];
     g.tmean = (double)tsum * (1.0 / ((double)th * tw));
     c->tsum = tsum;
-    if ((tw + 62) / 32 == 7) {  // the MFMA kernel is instantiated for 7 Toeplitz blocks per template row (tw 162..193)
+    if ((tw + 62) / 32 == 7 && tw <= 192) {  // the MFMA kernel is instantiated for 7 Toeplitz blocks per template row whose first and last pair up (tw 162..192)
         std::vector<int8_t> atab(mfma_atab_bytes(th));
         mfma_build_atab(c->h_templ.data(), th, tw, atab.data());
         HIP_TRY(hipMalloc((void**)&c->d_atab, atab.size()));

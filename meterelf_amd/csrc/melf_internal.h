@@ -92,8 +92,9 @@ void launch_gen_match(int n, const GenPlan& p, int rows, int th, int tw, long ts
                       const uint16_t* d_r, float* d_result_map, MatchPartial* d_partials, hipStream_t stream,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // prep for either matrix-core kernel: Lg (fragment order) and the row-window sums R in the match waves' epilogue order
+// (pairs > 0: the tuned kernel's paired-operand row layout, see k_prep_lplane)
 void launch_match_prep(const MatchSrc& src, bool from_bgr, int n, int groups, int rows_pad, int nkb, int rwp, int tw, int8_t* d_lg,
-                       uint16_t* d_r, hipStream_t stream);
+                       uint16_t* d_r, hipStream_t stream, int pairs = 0);
 
 // ---- K3: per-dial reading ---------------------------------------------------
 struct DialGeom {
