@@ -16,10 +16,11 @@ scaling); the only collectives are set-up ones (RCCL broadcast of the calibratio
 Objects on the line besides the contract's fields:
   roofline       dominant kernel of the step (k_match), timed by the dispatch's own start/stop stamps
                  (hipExtLaunchKernelGGL) on the stream it runs on, over the timed region
-  sustained      >= 2 s of back-to-back steps (DVFS-settled rate) with the same roofline figure
-  two_streams    ~1 s of the same steps alternating between two caller streams (the context's two lanes overlap them)
-  resident_hint  ~1 s of the same steps on ONE caller stream with melf_ctx_set_frames_resident (the library alternates its
-                 lanes itself); the config4 block carries the same object
+  single_lane    the same K steps on ONE caller stream (every kernel behind the previous one): the launches roofline / kernel_ms
+                 describe; the timed region itself alternates the steps between two caller streams (the context's two lanes)
+  sustained      >= 2 s of back-to-back steps (DVFS-settled rate), and the same length on one lane with k_match's stamps
+  two_streams    ~1 s of the timed mode (steps alternating between two caller streams)
+  resident_hint  ~1 s on ONE caller stream with melf_ctx_set_frames_resident (the library alternates its lanes per call)
   cpu_baseline   the CPU oracle (restated port) on a bounded sample of the same frames; doubles as parity gate
   fused_mask     BASELINE config 2 (B=256, fused HLS+inRange+closing) rotating over 4 buffer pairs, HBM roofline
   config4        BASELINE config 4 per GPU: sample-images2 params, 1024 frames/GPU, blob via RCCL broadcast
@@ -186,20 +187,24 @@ class Env:
 
 
 def timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=None, nstreams=1):
-    """Exactly `steps` steps between barrier + synchronize on both sides; step i reads batch i % nbuf and writes that
-    batch's record slice.  Returns (elapsed seconds of this rank, records of all nbuf batches)."""
+    """Exactly `steps` steps between barrier + synchronize on both sides; step i reads batch i % nbuf and writes record slice
+    i % (slices d_results holds).  nstreams = 2: consecutive steps alternate between two caller streams -- the context hands each
+    stream one of its two lanes (own work buffers), so that a step's prep / dials kernels fill the other step's launch gaps and the
+    tail of its match kernel; nothing orders the two streams against each other until the end of the region.  Returns (elapsed
+    seconds of this rank, records of all slices)."""
     from meterelf_amd import _hip
     torch = env.torch
     fs = frame_stride or H * W * 3
     rsz = _hip.RESULT_DTYPE.itemsize
+    nres = max(1, d_results.numel() // (B * rsz))
     env.barrier()
     env.sync()
     t0 = time.perf_counter()
-    streams = env.stream_objs[:max(1, min(nstreams, len(env.stream_objs), nbuf))]
+    streams = env.stream_objs[:max(1, min(nstreams, len(env.stream_objs), nres))]
     for i in range(steps):
         b = i % nbuf
         ctx.process_batch_dev(frames.data_ptr() + b * B * fs, B, H, W, frame_stride=fs,
-                              d_results_ptr=d_results.data_ptr() + b * B * rsz, want_host=False,
+                              d_results_ptr=d_results.data_ptr() + (i % nres) * B * rsz, want_host=False,
                               stream=streams[i % len(streams)].cuda_stream)
     for so in streams[1:]:
         env.stream_obj.wait_stream(so)
@@ -358,18 +363,21 @@ class Traffic:
         return self.valu.get(key)
 
 
-def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustained_s, traffic, cpu_sample, label, two_stream_s=0.0,
-                    resident_hint=False):
-    """One context + nbuf distinct batches; the contract's timed region, per-kernel times, optional sustained run and
-    optional CPU-oracle sample.  Returns a dict of raw results."""
+def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustained_s, traffic, cpu_sample, label, two_stream_s=0.0):
+    """One context + nbuf distinct batches.  Three passes over the same steps:
+      1. every kernel bracketed by events, one lane (informational per-kernel times: kernel_ms);
+      2. `steps` steps on ONE lane with the dispatch's own stamps on k_match: the undisturbed launches `roofline` describes, and
+         the step as the plain sum of its kernels (single_lane);
+      3. the contract's timed region the way a throughput caller with frames in HBM drives the library: the same calls alternating
+         between TWO caller streams (include/meterelf_hip.h: the context hands each stream one of its two lanes), so that a step's
+         prep / dials kernels fill the other step's launch gaps and the tail of its match kernel; no event records, no stamps, nothing
+         between the streams until the end of the region.  Same records, byte for byte (checked).
+    Then optional sustained / two-caller-stream runs and the CPU-oracle sample.  Returns a dict of raw results."""
     from meterelf_amd import _hip
     torch = env.torch
     (ctx, names) = env.make_context(pfile)
-    # Every batch of the timed regions is resident in HBM before the first step (the metric's premise).  Telling the library
-    # so (melf_ctx_set_frames_resident) lets a step's prep kernels run under the previous step's dials kernel: worth 8 % with
-    # sample-images2 params (small kernels, launch gaps), nothing with sample-images1 params (prep and dials both fill the
-    # chip: overlapped they just take turns), so only the config-4 block uses it.
-    ctx.set_frames_resident(resident_hint and not env.args.no_resident_hint)
+    two_lanes = not env.args.no_resident_hint
+    ctx.set_frames_resident(False)
     P = ctx.params
     base = load_fixture_frames(sample_dir)
     (H, W) = base.shape[1:3]
@@ -383,67 +391,68 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
         return timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, k, nstreams=nstreams)
 
     run(max(warmup, 1))
-    # a few steps with every kernel bracketed by events (informational per-kernel times) ...
+    # 1. a few steps with every kernel bracketed by events (informational per-kernel times) ...
     ctx.set_profiling(1)
     ctx.timings()
     run(max(3, nbuf))
     kt_all = ctx.timings()
-    # ... then the timed region with stamps on the dominant kernel only (the dispatch's own start / stop events: ~10 us of
-    # idle time around that kernel per step)
+    # 2. ... the same K steps on one lane with stamps on the dominant kernel only (the dispatch's own start / stop events: ~10 us
+    # of idle time around that kernel per step), pre-heated: the event read-back above leaves the GPU idle for
+    # a moment and the first launches after a pause run at a lower clock
     ctx.set_profiling(2)
     ns = env.args.streams
-    # untimed pre-heat right in front of the timed region: the event read-back above leaves the GPU idle for a moment and
-    # the first launches after a pause run at a lower clock (k_match 0.178 ms against 0.169 ms settled); K = 20 steps are
-    # only 7 ms.  The `sustained` block is the long-run figure either way.
     preheat = env.args.preheat
-    if preheat > 0 or ns > 1:
-        run(max(preheat, warmup, 2), ns)
-        ctx.timings()
-    (elapsed, recs) = run(steps, ns)
+    run(max(preheat, warmup, 2))
+    ctx.timings()
+    (elapsed1, recs1) = run(steps)
     kt = ctx.timings()
+    (elapsed1_max, _p1) = max_over_ranks(env, elapsed1)
+    # 3. the timed region
+    ctx.set_profiling(0)
+    ns_timed = 2 if (two_lanes and ns == 1) else ns
+    run(max(preheat, warmup, 2), ns_timed)
+    (elapsed, recs) = run(steps, ns_timed)
     (elapsed_max, per_rank) = max_over_ranks(env, elapsed)
     # per-step distribution: the same K steps again, an event after each (this rank's; single stream)
-    ctx.set_profiling(0)
     step_ms = step_event_times(env, ctx, frames, B, nbuf, H, W, d_results, max(steps, 20))
-    ctx.set_profiling(2)
-    ctx.timings()
     out = {'ctx': ctx, 'P': P, 'H': H, 'W': W, 'frames': frames, 'recs': recs, 'elapsed': elapsed_max,
            'per_rank_ms': [round(t / steps * 1e3, 4) for t in per_rank], 'kt': kt, 'kt_all': kt_all,
            'roofline': match_roofline(P, H, W, kt, B * steps, traffic.get(label + ':k_match'))}
-    out['step_events'] = dict(percentiles(step_ms), what='event-to-event time of each of %d further steps of the same loop (one '
-                              'hipEvent per step on the stream, rank 0; the timed region itself carries no per-step events)' % len(step_ms))
+    out['mode'] = ('one melf_process_batch_dev call per step, consecutive steps on %d caller stream(s)%s'
+                   % (ns_timed, ' (the context runs them on its two lanes)' if ns_timed > 1 else ''))
+    out['single_lane'] = {'ms_per_step': round(elapsed1_max / steps * 1e3, 4), 'frames_per_s': round(env.world * B * steps / elapsed1_max, 1), 'steps': steps,
+                          'what': 'the same K steps as K melf_process_batch_dev calls on one stream: every kernel behind the previous one (the '
+                                  'step is the sum of its kernels); these are the launches `roofline` and `kernel_ms` describe',
+                          'records_identical_to_timed_region': bool(recs1.tobytes() == recs.tobytes())}
+    out['step_events'] = dict(percentiles(step_ms), what='event-to-event time of each of %d further steps of the timed loop (one '
+                              'hipEvent per step on the caller\'s stream, rank 0; the timed region itself carries no events)' % len(step_ms))
     out['match_layout'] = ctx.last_match()
     out['kernel_ms'] = {k: round(ms / n, 4) for (k, (ms, n)) in kt_all.items() if n}
     if sustained_s > 0:
         est = max(elapsed / steps, 1e-5)
         k = int(sustained_s / est * 1.15) + nbuf
-        (el, _r) = run(k, ns)
-        kts = ctx.timings()
+        (el, _r) = run(k, ns_timed)
         (el_max, _p) = max_over_ranks(env, el)
-        r = match_roofline(P, H, W, kts, B * k, (None, None))
         out['sustained'] = {'seconds': round(el_max, 3), 'steps': k, 'ms_per_step': round(el_max / k * 1e3, 4),
-                            'frames_per_s': round(env.world * B * k / el_max, 1),
-                            'k_match_avg_launch_ms': r['avg_launch_ms'], 'k_match_frac': r['frac']}
-    ctx.set_profiling(0)
+                            'frames_per_s': round(env.world * B * k / el_max, 1)}
+        # ... and the dominant kernel's settled launch time: the same length on one lane, stamps on k_match
+        ctx.set_profiling(2)
+        ctx.timings()
+        (el1, _r) = run(k)
+        kts = ctx.timings()
+        ctx.set_profiling(0)
+        (el1_max, _p) = max_over_ranks(env, el1)
+        r = match_roofline(P, H, W, kts, B * k, (None, None))
+        out['sustained'].update({'single_lane_ms_per_step': round(el1_max / k * 1e3, 4), 'k_match_avg_launch_ms': r['avg_launch_ms'], 'k_match_frac': r['frac']})
     if two_stream_s > 0 and ns == 1:
-        # the same steps alternating between TWO caller streams: the context runs them on its two pipeline lanes, so one
-        # step's prep / dials kernels overlap the other's match kernel.  Reported beside the headline, not as it: a match
-        # launch that shares the chip has a stretched launch time, and `roofline` is meant to describe the kernel.
+        # ~1 s of the timed mode (two caller streams) ...
         est = max(elapsed / steps, 1e-5)
         k = int(two_stream_s / est * 1.2) + nbuf
-        ctx.set_frames_resident(False)   # with two lanes in flight the side streams only add queue traffic (measured)
         run(max(4, nbuf), 2)
         (el2, recs2) = run(k, 2)
         (el2_max, _p) = max_over_ranks(env, el2)
-        out['two_streams'] = {'steps': k, 'seconds': round(el2_max, 3), 'ms_per_step': round(el2_max / k * 1e3, 4),
-                              'frames_per_s': round(env.world * B * k / el2_max, 1),
-                              'records_identical_to_single_stream': bool(recs2.tobytes() == recs.tobytes())}
-    if two_stream_s > 0 and ns == 1 and not resident_hint:
-        # ONE caller stream with the frames-resident promise (melf_ctx_set_frames_resident): the library alternates its two
-        # lanes by itself, a call's prep and match kernels run beside the previous call's dials kernel.  Like two_streams
-        # this is reported beside the headline, whose roofline is meant to describe an undisturbed match launch.
-        est = max(elapsed / steps, 1e-5)
-        k = int(two_stream_s / est * 1.2) + nbuf
+        # ... and on ONE caller stream with the frames-resident promise (melf_ctx_set_frames_resident: the library alternates its lanes
+        # per call; three event hand-overs per call)
         ctx.set_frames_resident(True)
         run(max(4, nbuf))
         (el3, recs3) = run(k)
@@ -451,7 +460,10 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
         (el3_max, _p) = max_over_ranks(env, el3)
         out['resident_hint'] = {'steps': k, 'seconds': round(el3_max, 3), 'ms_per_step': round(el3_max / k * 1e3, 4),
                                 'frames_per_s': round(env.world * B * k / el3_max, 1),
-                                'records_identical_to_headline': bool(recs3.tobytes() == recs.tobytes())}
+                                'records_identical_to_timed_region': bool(recs3.tobytes() == recs.tobytes())}
+        out['two_streams'] = {'steps': k, 'seconds': round(el2_max, 3), 'ms_per_step': round(el2_max / k * 1e3, 4),
+                              'frames_per_s': round(env.world * B * k / el2_max, 1),
+                              'records_identical_to_timed_region': bool(recs2.tobytes() == recs.tobytes())}
     if cpu_sample > 0:
         # rank 0 runs the CPU sample (and the parity gate) outside every timed region; the other ranks wait at the barrier
         if env.rank == 0:
@@ -676,22 +688,33 @@ def config5_block(env, cfg3_frames, steps, warmup, traffic):
     fused = fused_block(env, ctx, B5, H5, W5, 1, max(12, steps), 6, traffic, 'config5', frames=frames)
     fused['workload'] = ('B=%d frames of 1920x1080 (%.2f GB in + %.2f GB out per launch), fused HLS+inRange+closing over '
                          'whole frames' % (B5, B5 * H5 * W5 * 3 / 1e9, B5 * H5 * W5 / 1e9))
-    d_results = torch.zeros(B5 * _hip.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=env.device)
+    d_results = torch.zeros(2 * B5 * _hip.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=env.device)   # two record slices: one per caller stream
     timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, max(warmup, 1))
     ctx.set_profiling(1)
     ctx.timings()
     timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, 3)
     kt_all = ctx.timings()
     ctx.set_profiling(2)
-    (el, recs) = timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, steps)
+    (el1, recs1) = timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, steps)
     kt = ctx.timings()
     ctx.set_profiling(0)
+    (el1_max, _p) = max_over_ranks(env, el1)
+    # the timed figure: like the headline, the same calls alternating between two caller streams (two lanes), no stamps
+    if env.args.no_resident_hint:
+        (el, recs) = (el1, recs1)
+    else:
+        timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, max(warmup, 4), nstreams=2)
+        (el, recs) = timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, steps, nstreams=2)
+    (recs, recs1) = (recs[:B5], recs1[:B5])
     (el_max, _p) = max_over_ranks(env, el)
     P = ctx.params
     out = {'workload': 'B=%d per GPU, 1920x1080 frames (%d B/frame, %.2f GB per GPU), 6 dials, meter_rect 250x250 inside '
                        'the frame' % (B5, H5 * W5 * 3, B5 * H5 * W5 * 3 / 1e9),
            'fused_mask': fused,
            'full_path': {'frames_per_s': round(env.world * B5 * steps / el_max, 1), 'ms_per_step': round(el_max / steps * 1e3, 4),
+                         'single_lane': {'ms_per_step': round(el1_max / steps * 1e3, 4), 'frames_per_s': round(env.world * B5 * steps / el1_max, 1),
+                                         'records_identical_to_timed_region': bool(recs1.tobytes() == recs.tobytes()),
+                                         'what': 'the same steps as melf_process_batch_dev calls on one stream: the launches roofline / kernel_ms describe'},
                          'dials': int(P.ndials), 'frames_read_ok': int((recs['status'] == 0).sum()),
                          'kernel_ms': {k_: round(ms / n, 4) for (k_, (ms, n)) in kt_all.items() if n},
                          'match_layout': ctx.last_match(),
@@ -879,8 +902,8 @@ def main():
     ap.add_argument('--sustained', type=float, default=2.0, help='seconds of back-to-back steps in the sustained block')
     ap.add_argument('--streams', type=int, default=1, help='caller streams the steps alternate between (2: steps overlap on the context\'s two lanes)')
     ap.add_argument('--no-resident-hint', action='store_true',
-                    help='kept for old command lines: no timed region uses the frames-resident hint any more (the resident_hint '
-                         'objects beside the headline and config 4 carry that mode)')
+                    help='time the headline, config 4 and config 5 on ONE caller stream (every kernel behind the previous one) instead of '
+                         'two; the single_lane objects carry that figure either way')
     ap.add_argument('--preheat', type=int, default=300, help='untimed steps run immediately before the timed region (clock settling)')
     ap.add_argument('--skip', default='', help='comma list of blocks to skip: ' + ','.join(ALL_BLOCKS))
     ap.add_argument('--only', default='', help='comma list of extra blocks to run (default: all)')
@@ -956,14 +979,13 @@ def main():
         cfg4 = {'workload': 'Batch=%d per GPU (%d in total), sample-images2 params (crop 135x220, 561 match positions), '
                             'calibration blob broadcast from rank 0%s, %d distinct batches in rotation'
                             % (B, B * world, ' over RCCL' if env.backend == 'nccl' else '', args.nbuf),
-                'timed_region': 'one caller stream, no frames-resident hint, like the headline: roofline and kernel_ms describe '
-                                'undisturbed launches (rounds 2-3 timed this block WITH the hint: that figure is resident_hint below)',
+                'timed_region': f4['mode'] + ', like the headline; roofline and kernel_ms describe the undisturbed launches of single_lane',
                 'frames_per_s': round(world * B * args.steps / f4['elapsed'], 1), 'ms_per_step': round(f4['elapsed'] / args.steps * 1e3, 4),
                 'per_rank_ms_per_step': f4['per_rank_ms'], 'frames_read_ok_batch0': int((f4['recs'][:B]['status'] == 0).sum()),
                 'kernel_ms': f4['kernel_ms'], 'step_events': f4.get('step_events'), 'match_layout': f4.get('match_layout'),
                 'roofline': f4['roofline'], 'roofline_dials': dials_roofline(f4['kernel_ms'], traffic, 'config4'),
                 'roofline_prep': prep_roofline(f4['P'], f4['H'], f4['W'], f4['kernel_ms'], traffic, 'config4', args.batch),
-                'two_streams': f4.get('two_streams'), 'resident_hint': f4.get('resident_hint'),
+                'two_streams': f4.get('two_streams'), 'single_lane': f4.get('single_lane'), 'resident_hint': f4.get('resident_hint'),
                 'cpu_baseline': f4.get('cpu')}
         f4['ctx'].close()
 
@@ -979,11 +1001,11 @@ def main():
                                    '%d distinct batches in rotation (%.2f GB of frames per GPU)'
                                    % (B, args.sample_dir, W, H, args.nbuf, args.nbuf * B * H * W * 3 / 1e9),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'frames_read_ok_batch0': n_ok,
-                       'untimed_preheat_steps': args.preheat},
+                       'untimed_preheat_steps': args.preheat, 'mode': full['mode']},
             'per_rank_ms_per_step': full['per_rank_ms'], 'rccl_ranks': rccl_ranks, 'backend': env.backend,
             'kernel_ms': full['kernel_ms'], 'step_events': full.get('step_events'), 'match_layout': full.get('match_layout'),
             'roofline': roofline, 'roofline_dials': roofline_dials, 'roofline_prep': roofline_prep, 'sustained': full.get('sustained'), 'two_streams': full.get('two_streams'),
-            'resident_hint': full.get('resident_hint'),
+            'single_lane': full.get('single_lane'), 'resident_hint': full.get('resident_hint'),
             'cpu_baseline': full.get('cpu'),
             'fused_mask': fused, 'config4': cfg4, 'config5': cfg5, 'host_fed': hostfed, 'jpeg_decode': jpeg,
         }

@@ -550,9 +550,10 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     // first maximum is "strictly greater wins".  One map row at a time: a row's window sums and its accumulators
     // (which leave the accumulator file for the vector ALU) stay within the registers the main loop needs anyway.
     const bool lane_ok = f < g.nframes;
+    // The running maximum carries the element's CODE (row, column block, accumulator element: a literal in the select), not its
+    // map index: the index is put together once at the end.  Lanes beyond the batch compute on zero rows and never store.
     float bestv = -INFINITY;
-    int besti = INT_MAX;
-    constexpr int RB = 1;
+    int bestc = -1;
     // fused window sums: the two R rows that leave / enter the window between map rows r - 1 and r are requested one row
     // ahead (while row r - 1's arithmetic runs)
     i32x4 slide[2][4];
@@ -563,52 +564,70 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
         for (int k = 0; k < 4; ++k) { slide[0][k] = LD(rsR, rout, k); slide[1][k] = LD(rsR, rin, k); }
     };
 #pragma unroll
-    for (int r0 = 0; r0 < R; r0 += RB) {
-        uint32_t wsr[RB][NXB][16];
-        {
-            // window sums of row y0 + r0: those of the row above minus the image row that left, plus the one that entered
-            if (r0 > 0) {
+    for (int r = 0; r < R; ++r) {
+        // window sums of row y0 + r: those of the row above minus the image row that left, plus the one that entered
+        if (r > 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const uint32_t a0 = (uint32_t)slide[1][k][c], b0 = (uint32_t)slide[0][k][c];
-                        wsa[8 * k + 2 * c] += (a0 & 0xffffu) - (b0 & 0xffffu);
-                        wsa[8 * k + 2 * c + 1] += (a0 >> 16) - (b0 >> 16);
-                    }
-            }
-            if (r0 + 1 < R) slide_load(r0 + 1);
-#pragma unroll
-            for (int xb = 0; xb < NXB; ++xb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) wsr[0][xb][e] = wsa[16 * xb + e];
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t a0 = (uint32_t)slide[1][k][c], b0 = (uint32_t)slide[0][k][c];
+                    wsa[8 * k + 2 * c] += (a0 & 0xffffu) - (b0 & 0xffffu);
+                    wsa[8 * k + 2 * c + 1] += (a0 >> 16) - (b0 >> 16);
+                }
         }
+        if (r + 1 < R) slide_load(r + 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (!mine(r)) continue;   // (wave-uniform) another slice's wave runs this row; the window sums above slide on regardless
+        const int y = y0 + r;
+        if (y >= g.rh) continue;  // (wave-uniform) rows below the map: the last tile's padding
+        // The row's values first (ten instructions per element, nothing lane-dependent in the control flow) ...
+        float v[NXB][16];
 #pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
-            const int r = r0 + rr;
-            if (r >= R) continue;
-            if (!mine(r)) continue;   // (wave-uniform) another slice's wave runs this row; the window sums above slide on regardless
-            const int y = y0 + r;
-            const bool row_ok = lane_ok && y < g.rh;
+        for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (!on(r, xb)) continue;
+                const uint32_t wsv = wsa[16 * xb + e];
+                const uint32_t cc = (uint32_t)acc[r][xb][e] + 128u * wsv + (uint32_t)g.k1;
+                double num = (double)cc;
+                num -= (double)wsv * g.tmean;
+                v[xb][e] = (float)num;
+            }
+        // ... columns beyond the map (only a column block that sticks out of it has any) ...
+#pragma unroll
+        for (int xb = 0; xb < NXB; ++xb) {
+            if (!on(r, xb) || 32 * xb + 32 <= g.rw) continue;   // (wave-uniform)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh >= g.rw) v[xb][e] = -INFINITY;
+        }
+        // ... the maximum: a lane visits its elements in increasing raster index, so the first maximum is "strictly greater wins" ...
+#pragma unroll
+        for (int xb = 0; xb < NXB; ++xb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (!on(r, xb)) continue;
+                if (v[xb][e] > bestv) { bestv = v[xb][e]; bestc = (r * NXB + xb) * 16 + e; }
+            }
+        // ... and the whole map for the callers that ask for it (tests, melf_match_ccoeff with a result map): one uniform branch per row
+        if (result_map) {
+            float* mrow = result_map + (size_t)f * g.rh * g.rw + (size_t)y * g.rw;
 #pragma unroll
             for (int xb = 0; xb < NXB; ++xb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     if (!on(r, xb)) continue;
                     const int x = 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    const bool valid = row_ok && x < g.rw;
-                    const uint32_t wsv = wsr[rr][xb][e];
-                    const uint32_t cc = (uint32_t)acc[r][xb][e] + 128u * wsv + (uint32_t)g.k1;
-                    double num = (double)cc;
-                    num -= (double)wsv * g.tmean;
-                    const float v = valid ? (float)num : -INFINITY;
-                    const int idx = y * g.rw + x;
-                    if (result_map && valid) result_map[(size_t)f * g.rh * g.rw + idx] = v;
-                    if (v > bestv) { bestv = v; besti = idx; }
+                    if (lane_ok && x < g.rw) mrow[x] = v[xb][e];
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    int besti = INT_MAX;
+    if (bestc >= 0) {
+        const int e = bestc & 15, xb = (bestc >> 4) % NXB, r = (bestc >> 4) / NXB;
+        besti = (y0 + r) * g.rw + 32 * xb + (e & 3) + 8 * (e >> 2) + 4 * hh;
     }
     {
         const float ov = __shfl_xor(bestv, 32, 64);
@@ -669,6 +688,12 @@ __global__ __launch_bounds__(64 * KS, 1) void k_match_mfma(const int8_t* __restr
                                                            const uint32_t* __restrict__ ws, MfmaGeom g,
                                                            float* __restrict__ result_map, MatchPartial* __restrict__ partials)
 {
+    // The large tiles keep their SIMD to themselves.  They use 440-450 of its 512 registers; whether the 64 or 72 left over admit a
+    // wave of the other lane's prep kernel (65 registers, allocated as 72) was an accident of the allocator -- and when it does, both
+    // kernels lose: the prep kernel streams the next batch through the L2 this kernel keeps its image rows in (config 5, 512 frames:
+    // 0.174 ms per step on two lanes against 0.154 on one; profiles/r06/overlap_*.txt).  Naming a high accumulator register makes
+    // the allocation 456: nothing else fits, the other lane's kernels fill the SIMDs as the waves of this launch retire.
+    if constexpr (NXB == 2 && RB >= 4) asm volatile("" ::: "a199");
     if constexpr (KS > 1) {
         // room for the largest tile of the launch: (RB + 1)-row pair waves
         __shared__ __attribute__((aligned(16))) SliceLds<(NXB == 2 && RB < 5 ? RB + 1 : RB), NXB, KS> lds;

@@ -60,5 +60,5 @@ for (label, sel) in (('4-row waves (8 half-row units)', rblk < na), ('5-row wave
           % (label, sel.sum(), c[len(c) // 10], c[len(c) // 2], c[len(c) * 9 // 10], c[-1], w[len(w) // 2], w[len(w) * 9 // 10], w[-1]))
 start = (buf[:, 2] - buf[:, 2].min()) / 100.0
 print('  wave start offsets us: p50 %.1f p90 %.1f max %.1f' % (np.median(start), np.sort(start)[n * 9 // 10], start.max()))
-for mf in (6720, 7560):
+for mf in (5760, 6480):   # 8 / 9 half-row units x 120 template rows x 6 matrix instructions
     print('  %d MFMAs x 32 cycles = %d busy cycles = %.0f %% of the median wave' % (mf, mf * 32, 100 * mf * 32 / np.median(cyc)))

@@ -9,13 +9,16 @@ print('value %.0f frames/s  ms/step %.4f  n_gpus %s  rccl_ranks %s' % (d['value'
 print('  kernels ms', d.get('kernel_ms'), '| k_match %.4f ms frac %.4f' % (r.get('avg_launch_ms', 0), r.get('frac', 0)))
 s = d.get('sustained')
 if s:
-    print('  sustained %.4f ms/step over %.2f s, k_match %.4f ms frac %.4f' % (s['ms_per_step'], s['seconds'], s['k_match_avg_launch_ms'], s['k_match_frac']))
+    print('  sustained %.4f ms/step over %.2f s (one lane %s), k_match %.4f ms frac %.4f' % (s['ms_per_step'], s['seconds'], s.get('single_lane_ms_per_step'), s['k_match_avg_launch_ms'], s['k_match_frac']))
 t = d.get('two_streams')
 if t:
-    print('  two streams %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t['records_identical_to_single_stream']))
+    print('  two caller streams %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t.get('records_identical_to_timed_region', t.get('records_identical_to_single_stream'))))
+t = d.get('single_lane')
+if t:
+    print('  one lane (no hint) %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t['records_identical_to_timed_region']))
 t = d.get('resident_hint')
 if t:
-    print('  one stream + resident hint %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t['records_identical_to_headline']))
+    print('  one stream + resident hint %.4f ms/step  %.0f frames/s  identical %s' % (t['ms_per_step'], t['frames_per_s'], t.get('records_identical_to_timed_region', t.get('records_identical_to_headline'))))
 f = d.get('fused_mask')
 if f:
     print('  fused (config 2) %.4f ms  %.0f GB/s  frac %.4f  | two streams %s' % (f['roofline']['avg_launch_ms'], f['roofline']['achieved'], f['roofline']['frac'], f.get('two_streams')))
@@ -25,6 +28,8 @@ if c:
         c['frames_per_s'], c['ms_per_step'], c['kernel_ms'], c['roofline']['frac'], (c.get('cpu_baseline') or {}).get('parity_mismatches_vs_gpu')))
     if c.get('two_streams'):
         print('    two streams %.4f ms/step  %.0f frames/s' % (c['two_streams']['ms_per_step'], c['two_streams']['frames_per_s']))
+    if c.get('single_lane'):
+        print('    one lane %.4f ms/step  %.0f frames/s' % (c['single_lane']['ms_per_step'], c['single_lane']['frames_per_s']))
 c = d.get('config5')
 if c:
     fm = c['fused_mask']['roofline']

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--hw', default='480x640', help='fused stage: frame rows x columns')
     ap.add_argument('--profiling', type=int, default=1, help='full stage: 0 no event records, 1 every kernel, 2 only k_match (the bench setting)')
     ap.add_argument('--device-records', action='store_true', help='full stage: records stay in HBM, no copy and no sync per call (the bench loop)')
+    ap.add_argument('--resident', action='store_true', help='full stage: melf_ctx_set_frames_resident(1): consecutive calls alternate between the two lanes')
     ap.add_argument('--nbuf', type=int, default=4, help='distinct buffer sets the launches rotate over (beyond the Infinity Cache)')
     a = ap.parse_args()
     import torch
@@ -64,6 +65,7 @@ def main():
         frames = bench.synth_frames_gpu(torch, torch.from_numpy(base).to(dev), NB * B, 2024, dev)
         (H, W) = base.shape[1:3]
         ctx.set_profiling(a.profiling)
+        ctx.set_frames_resident(a.resident)
         recs = torch.empty((NB, B * _hip.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         for i in range(a.iters):
             if a.device_records:
