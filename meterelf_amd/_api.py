@@ -4,9 +4,11 @@
 
 Lazy, yields in input order, per-image ImageProcessingError becomes the `error`
 field (re-raised only when DEBUG is set).  Unlike the reference's one-at-a-time
-loop, files go to the GPU in chunks (METERELF_BATCH, default 1024) and the library already
-works on the next two chunks while the current chunk's results are consumed, so up to three chunks
-are read ahead of the consumer.
+loop, files go to the GPU in chunks: 32 names first, then 64, 128 ... up to METERELF_BATCH (default 1024;
+METERELF_BATCH_FIRST sets the first size, 0 = no ramp), so that a slow or unbounded `filenames` iterator has its first
+results after 32 names; nothing is pulled from the iterator while a short chunk's results are outstanding.  Once the
+chunks are full-sized the library already works on the next chunks while the current chunk's results are consumed, so up
+to three chunks are read ahead of the consumer.
 
 Several GPUs in one process (round 4): the chunks are dealt round-robin over METERELF_DEVICES (a comma list of
 device indices; "all" = every visible device; "0,0" = two contexts on one GPU), one MeterReader and one
@@ -21,9 +23,11 @@ library) and decoded on the GPU (METERELF_DECODE=gpu, the default; bit-identical
 everything when METERELF_DECODE=host, is decoded on the host by Pillow on a small thread pool
 (METERELF_DECODE_THREADS, default min(8, cpu count); Pillow releases the GIL).
 """
+import collections
 import hashlib
 import os
 import queue
+import sys
 import threading
 from concurrent.futures import ThreadPoolExecutor
 from time import perf_counter
@@ -96,7 +100,17 @@ def _acquire_readers_bcast(params, devices: List[int]) -> Dict[int, MeterReader]
             out[w] = r
         else:
             missing.append(w)
-    if missing:
+    if len(missing) == 1:     # one context to make: a plain upload (a communicator for a broadcast to oneself costs more than it moves)
+        w = missing[0]
+        try:
+            r = MeterReader(params, device=devices[w], blob=blob)
+        except Exception:
+            for r2 in out.values():
+                _release_reader(r2)
+            return {}
+        r._cache_key = _reader_key(params, blob, devices[w])
+        out[w] = r
+    elif missing:
         try:
             ctxs = _hip.Context.create_bcast(blob, [devices[w] for w in missing])
         except Exception:
@@ -154,25 +168,38 @@ if hasattr(os, 'register_at_fork'):
     os.register_at_fork(after_in_child=_forget_contexts_in_child)
 
 
+_noted_one_device = False
+
+
 def _device_list() -> List[int]:
     """METERELF_DEVICES: comma list of device indices (an index may repeat: that many contexts on that GPU), or "all".
     Unset or empty: one device -- LOCAL_RANK's (torchrun: one process per GPU), else device 0."""
+    global _noted_one_device
     spec = os.getenv('METERELF_DEVICES', '').strip()
     if spec == '':
         rank = os.getenv('LOCAL_RANK', '').strip()
-        return [int(rank) % max(1, _hip.device_count())] if rank.isdigit() else [0]
+        ndev = max(1, _hip.device_count())
+        if ndev > 1 and not rank.isdigit() and not _noted_one_device:
+            _noted_one_device = True      # once per process: before round 5 an unset METERELF_DEVICES meant every visible GPU
+            print('meterelf_amd: %d GPUs visible, using device 0 only (set METERELF_DEVICES=all or a comma list to fan out)' % ndev, file=sys.stderr)
+        return [int(rank) % ndev] if rank.isdigit() else [0]
     if spec == 'all':
         return list(range(max(1, _hip.device_count())))
     return [int(x) for x in spec.split(',') if x.strip() != ''] or [0]
 
 
-def _chunks(items: Iterable[str], size: int) -> Iterator[List[str]]:
+def _chunks(items: Iterable[str], size: int, first: int = 0) -> Iterator[List[str]]:
+    """Lists of `size` names; with `first` > 0 the sizes ramp up geometrically from it (first, 2 first, 4 first ... size): a slow
+    or unbounded `filenames` iterator gets its first results after `first` names instead of after a whole chunk (the reference
+    pulls ONE name per result: meterelf/_api.py:22-33)."""
+    want = min(size, first) if first > 0 else size
     chunk: List[str] = []
     for item in items:
         chunk.append(item)
-        if len(chunk) == size:
+        if len(chunk) == want:
             yield chunk
             chunk = []
+            want = min(size, 2 * want)
     if chunk:
         yield chunk
 
@@ -182,17 +209,18 @@ _REAL_READER = MeterReader   # tests substitute MeterReader with a CPU stand-in:
 # Where the Python side of get_meter_values spends its time, per device pipeline (bench.py's jpeg_decode.get_meter_values.host):
 # seconds summed over the chunks since the last api_stats(reset=True).  A few perf_counter() calls per 1024-file chunk.
 _stats_lock = threading.Lock()
-_stats = {'chunks': 0, 'files': 0, 's_begin': 0.0, 's_end_wait': 0.0, 's_convert': 0.0, 'library': []}
+_LIB_STATS_KEPT = 64   # the newest per-pipeline library records api_stats() hands out (a long-running service never calls it)
+_stats = {'chunks': 0, 'files': 0, 's_begin': 0.0, 's_end_wait': 0.0, 's_convert': 0.0, 'library': collections.deque(maxlen=_LIB_STATS_KEPT)}
 
 
 def api_stats(reset: bool = True) -> dict:
     """{'chunks', 'files', 's_begin' (marshalling + melf_jpeg_process_files_begin), 's_end_wait' (blocked in _end: the library
     had not finished the chunk), 's_convert' (records -> MeterImageData objects), 'library': [melf_ctx_files_stats of every
-    context released since the last reset]}."""
+    context released since the last reset, the newest 64]}."""
     with _stats_lock:
         out = dict(_stats, library=list(_stats['library']))
         if reset:
-            _stats.update({'chunks': 0, 'files': 0, 's_begin': 0.0, 's_end_wait': 0.0, 's_convert': 0.0, 'library': []})
+            _stats.update({'chunks': 0, 'files': 0, 's_begin': 0.0, 's_end_wait': 0.0, 's_convert': 0.0, 'library': collections.deque(maxlen=_LIB_STATS_KEPT)})
     return out
 
 
@@ -275,11 +303,13 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
                     raw = (raw[0], raw[1].tolist())
                 else:
                     raw = _gpu_read(chunk)
-            if pipelined:
-                _begin_more()  # before this chunk's records are touched: the library has DEPTH chunks to work on
-                following = begun[0] if begun else None
-            else:
-                following = next(chunks, None)
+            # Look-ahead: before this chunk's records are touched the library gets DEPTH chunks to work on -- but only once the
+            # chunks have reached full size.  While they ramp up (a short chunk: the start of the list, or its end) nothing is pulled
+            # from `filenames` until the chunk's results have been handed out, so a slow iterator sees its first results at once.
+            ahead = pipelined and (len(chunk) >= batch or bool(begun))
+            if ahead:
+                _begin_more()
+            following = begun[0] if begun else None
             items = None  # the chunk's result objects, when every file went through the GPU decoder
             t0 = perf_counter()
             if isinstance(raw, tuple):
@@ -295,7 +325,7 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
             local['files'] += len(chunk)
             if items is not None:
                 yield items
-                chunk = following
+                chunk = following if following is not None else next(chunks, None)
                 continue
             on_host = [i for i in range(len(chunk)) if converted[i] is None]
             if on_host:
@@ -328,7 +358,7 @@ def _process_chunks(params, chunks: Iterator[List[str]], device: int, gpu_decode
                     raise error
                 out.append(MeterImageData(filename, meter_values.get('value'), error, meter_values))
             yield out
-            chunk = following
+            chunk = following if following is not None else next(chunks, None)
         clean = True
     except GeneratorExit:
         clean = True   # dropped by the consumer half way: whatever is in flight is collected below
@@ -368,7 +398,8 @@ def get_meter_values(params_file: str, filenames: Iterable[str]) -> Iterator[Met
     if _debug.DEBUG:
         batch = 1  # DEBUG re-raises at the failing file, before any later file is touched
         devices = devices[:1]
-    chunks = _chunks(filenames, batch)
+    # METERELF_BATCH_FIRST: size of the first chunk (default 32; 0 = every chunk METERELF_BATCH names); the sizes double up to METERELF_BATCH
+    chunks = _chunks(filenames, batch, max(0, int(os.getenv('METERELF_BATCH_FIRST', '32'))))
     if len(devices) == 1:
         for items in _process_chunks(params, chunks, devices[0], gpu_decode, batch):
             yield from items

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * MELF_MAX_DIALS, 4) __attribute__((amdgpu_num_v
     const int npiece = (ws + 3) >> 2;   // wave-uniform: 12-byte pieces of a window row
     // wave-uniform: every piece lies inside the crop's rows (no column clamping: a lane's four pixels stay four neighbours) and
     // the last load ends inside the frames' buffer; otherwise every pixel takes the exact path below
-    const uint8_t* const buf_end = src.base + (size_t)gridDim.x * src.frame_stride;
+    const uint8_t* const buf_end = src.base + src.readable;   // (not frames x stride: the last frame of a padded-stride buffer may end earlier)
     const bool quads = !FROM_HLS && ((uintptr_t)src.base & 3) == 0 && wx0 >= 0 && wx0 + 4 * npiece <= P.tw &&
                        origin + (size_t)th1 * rstride + (size_t)(wx0 + 4 * npiece) * 3 + 4 <= buf_end;
     u32x4v raw[NG];

@@ -1205,6 +1205,7 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
             DialsSrc ds;
             ds.base = base; ds.frame_stride = frame_stride; ds.row_stride = row_stride;
             ds.x0 = x0; ds.y0 = y0; ds.crop_rows = crows; ds.crop_cols = ccols;
+            ds.readable = (size_t)(m - 1) * frame_stride + (size_t)H * row_stride;
             if (c->order_valid) {
                 // resident mode: prep and match above ran unordered with the caller's stream (they touch only the frames
                 // and the lane's buffers); the kernel that writes the caller's records waits for everything that stream
@@ -1509,6 +1510,7 @@ extern "C" int melf_read_dials(melf_ctx* c, const uint8_t* dials_hls_host, int n
     DialsSrc ds;
     ds.base = c->d_stage_in; ds.frame_stride = per; ds.row_stride = P.tw * 3;
     ds.x0 = 0; ds.y0 = 0; ds.crop_rows = P.th; ds.crop_cols = P.tw;
+    ds.readable = (size_t)n * per;
     {
         KernelTimer t(c, MELF_K_DIALS, c->stream);
         launch_dials(ds, true, n, P, c->d_geom, c->d_rowmasks, nullptr, 0, 1, c->d_results, c->stream, c->ws_max);

@@ -109,6 +109,7 @@ struct DialsSrc {
     int row_stride;        // bytes
     int x0, y0;            // origin of the meter crop inside the frame (BGR mode)
     int crop_rows, crop_cols;  // meter crop size (BGR mode): cvtColor image width for the tail rule
+    size_t readable;       // bytes from `base` the caller guarantees readable: (frames - 1) * frame_stride + the last frame's rows
 };
 
 void launch_dials(const DialsSrc& src, bool from_hls, int n, const melf_params& P, const DialGeom* d_geom,

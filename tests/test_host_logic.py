@@ -317,6 +317,7 @@ def test_get_meter_values_keeps_two_chunks_in_flight(tmp_path, monkeypatch):
     from meterelf_amd import _api
     monkeypatch.setattr(_api, 'MeterReader', _TwoInFlightReader)
     monkeypatch.setenv('METERELF_BATCH', '100')
+    monkeypatch.setenv('METERELF_BATCH_FIRST', '0')     # every chunk full-sized (the ramp has its own test below)
     pfile = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
     files = []
     for k in range(1, 731):
@@ -347,6 +348,46 @@ def test_get_meter_values_keeps_two_chunks_in_flight(tmp_path, monkeypatch):
     gen.close()
     assert [r.filename for r in first] == files[:150]
     assert 'discard' in _TwoInFlightReader.log and _TwoInFlightReader.log[-1] == 'close'
+
+
+def test_get_meter_values_first_results_after_32_names(tmp_path, monkeypatch):
+    """The reference pulls one name and yields one result (meterelf/_api.py:22-33).  Here the chunk sizes ramp up 32, 64, 128 ...
+    METERELF_BATCH and nothing is pulled from `filenames` while a short chunk's results are outstanding: an iterator that stalls
+    after 40 names has had its first 32 results by then; a long list ends up in full-sized, pipelined chunks."""
+    from meterelf_amd import _api
+    monkeypatch.setattr(_api, 'MeterReader', _TwoInFlightReader)
+    monkeypatch.delenv('METERELF_BATCH', raising=False)
+    monkeypatch.delenv('METERELF_BATCH_FIRST', raising=False)
+    pfile = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
+    pulled = []
+
+    class Stalled(Exception):
+        pass
+
+    def names():
+        for k in range(1, 41):
+            if k % 50 == 17:
+                continue
+            pulled.append(k)
+            yield str(tmp_path / ('f%d.jpg' % k))
+        raise Stalled()     # stands for "blocks here": nothing after the 40th name may be needed for the first 32 results
+
+    _TwoInFlightReader.log = []
+    gen = _api.get_meter_values(pfile, names())
+    first = [next(gen) for _ in range(32)]
+    assert len(pulled) == 32 and [os.path.basename(r.filename) for r in first] == ['f%d.jpg' % k for k in pulled]
+    with pytest.raises(Stalled):
+        next(gen)
+    # sizes: 32, 64, ... 1024, then full chunks through begin / end with the library's look-ahead
+    files = [str(tmp_path / ('f%d.jpg' % k)) for k in range(1, 6001) if k % 50 != 17]
+    sizes = [len(c) for c in _api._chunks(files, 1024, 32)]
+    assert sizes[:6] == [32, 64, 128, 256, 512, 1024] and set(sizes[6:-1]) == {1024} and sum(sizes) == len(files)
+    assert [len(c) for c in _api._chunks(files[:100], 1024, 0)] == [100] and [len(c) for c in _api._chunks(files[:70], 16, 32)] == [16, 16, 16, 16, 6]
+    _TwoInFlightReader.log = []
+    got = list(_api.get_meter_values(pfile, files))
+    assert [r.filename for r in got] == files
+    log = _TwoInFlightReader.log
+    assert log.count('begin 1024') >= 3 and not any(x.startswith('begin') and x != 'begin 1024' and not x.startswith('begin %d' % sizes[-1]) for x in log)
 
 
 class _PerDeviceReader(_TwoInFlightReader):
@@ -381,6 +422,7 @@ def test_get_meter_values_over_several_devices(tmp_path, monkeypatch, devices):
     from meterelf_amd import _api
     monkeypatch.setattr(_api, 'MeterReader', _PerDeviceReader)
     monkeypatch.setenv('METERELF_BATCH', '50')
+    monkeypatch.setenv('METERELF_BATCH_FIRST', '0')   # full-sized chunks from the start (the ramp has its own test)
     monkeypatch.setenv('METERELF_DEVICES', devices)
     dev = [int(x) for x in devices.split(',')]
     pfile = os.path.join(GOLDEN, 'sample-images2', 'params.yml')
@@ -726,6 +768,7 @@ def test_fan_out_throughput_scales_with_devices(monkeypatch):
     from meterelf_amd import _api
     monkeypatch.setattr(_api, 'MeterReader', _TimedDeviceReader)
     monkeypatch.setenv('METERELF_BATCH', '1024')
+    monkeypatch.setenv('METERELF_BATCH_FIRST', '0')   # the stand-in device takes a full chunk's time for any chunk: no ramp here
     pfile = os.path.join(GOLDEN, 'sample-images1', 'params.yml')
     names = ['/nowhere/f%06d.jpg' % i for i in range(48 * 1024)]
     device_rate = 1024 / _TimedDeviceReader.PERIOD
