@@ -548,6 +548,97 @@ def cpu_block(pfile, frames, recs, S, P=None):
             'parity_gate': 'status, match position, float32 match value bit for bit, printed value, dial positions to 1e-9'}
 
 
+DIAG_LIB = os.path.join(ROOT, 'meterelf_amd', 'csrc', 'libmeterelf_hip_diag.so')
+
+
+def stream_ceiling_child(env, FB, H, W, nbuf, steps):
+    """fused_mask.stream_ceiling: run by a CHILD process that loads the diagnostic build (make -C meterelf_amd/csrc diag ->
+    libmeterelf_hip_diag.so: the product's code + melf_stream_probe_dev and its bare-stream kernels) on this rank's GPU, while this
+    process idles: bare streams and the fused kernel itself (same source, same launch shape as the product's) interleaved over the
+    child's own buffers of the same size.  None when the diagnostic build is missing."""
+    if not os.path.exists(DIAG_LIB):
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), '--ceiling-child', '%d,%d,%d,%d,%d,%d' % (FB, H, W, nbuf, steps, env.dev_index)]
+    envv = dict(os.environ, MELF_LIB_PATH=DIAG_LIB)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        envv.pop(k, None)
+    try:
+        p = subprocess.run(cmd, env=envv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+        return json.loads(lines[-1]) if p.returncode == 0 and lines else {'error': p.stderr.decode()[-400:]}
+    except Exception as e:   # the ceiling is an annotation: the line goes out without it
+        return {'error': repr(e)}
+
+
+def ceiling_child_main(spec):
+    """The child of stream_ceiling_child (MELF_LIB_PATH = the diagnostic build): prints the stream_ceiling object."""
+    (FB, H, W, nbuf, steps, dev) = (int(x) for x in spec.split(','))
+    import torch
+    from meterelf_amd import _engine, _hip, _params
+    assert hasattr(_hip.lib(), 'melf_stream_probe_dev'), 'the child needs the diagnostic build (MELF_LIB_PATH)'
+    torch.cuda.set_device(dev)
+    device = torch.device('cuda', dev)
+    ctx = _hip.Context(_engine.make_blob(_params.load(os.path.join(GOLDEN, 'sample-images1', 'params.yml'))), dev)
+    stream = torch.cuda.Stream(device=device).cuda_stream
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+    frames = torch.randint(0, 256, (nbuf * FB, H, W, 3), dtype=torch.uint8, device=device, generator=g)
+    masks = torch.empty((nbuf * FB, H, W), dtype=torch.uint8, device=device)
+    alg_bytes = FB * H * W * 4
+
+    def launch(i):
+        b = i % nbuf
+        ctx.hls_inrange_close_dev(frames.data_ptr() + b * FB * H * W * 3, FB, H, W, masks.data_ptr() + b * FB * H * W, stream=stream)
+    for i in range(max(6, nbuf)):
+        launch(i)
+    torch.cuda.synchronize()
+    in_bytes = FB * H * W * 3
+    variants = [('static', 0), ('static_prefetch', -1), ('queue2', 2), ('queue4', 4), ('comb', -2), ('comb_stride48', -3), ('comb_stride48_barriers', -4),
+                ('comb_stride48_barriers_tables', -5)]
+    ctx.set_profiling(1)
+    ctx.timings()
+    rounds = max(6, min(steps, 24))
+    for i in range(rounds + 2):
+        if i == 2:
+            torch.cuda.synchronize()
+            ctx.timings()       # the first two rounds are warm-up
+        b = i % nbuf
+        for (_name, ch) in variants:
+            ctx.stream_probe_dev(frames.data_ptr() + b * in_bytes, in_bytes, masks.data_ptr() + b * FB * H * W, ch, stream=stream)
+    torch.cuda.synchronize()
+    (pms, pn) = ctx.timings()['k_stream_probe']
+    # per variant: the launches alternate, so a second pass with one variant at a time gives the split
+    per = {}
+    for (name, ch) in variants:
+        for i in range(rounds):
+            b = i % nbuf
+            ctx.stream_probe_dev(frames.data_ptr() + b * in_bytes, in_bytes, masks.data_ptr() + b * FB * H * W, ch, stream=stream)
+        torch.cuda.synchronize()
+        (vms, vn) = ctx.timings()['k_stream_probe']
+        moved = (in_bytes // (48 * 1024)) * 64 * 1024
+        per[name] = {'avg_launch_ms': round(vms / max(vn, 1), 4), 'GBps': round(moved / (vms / max(vn, 1) * 1e-3) / 1e9, 1)}
+    # the kernel, right after, for a same-minute comparison
+    for i in range(rounds):
+        launch(i)
+    torch.cuda.synchronize()
+    (kms, kn) = ctx.timings()['k_fused_mask']
+    ctx.set_profiling(0)
+    best = max(v['GBps'] for v in per.values())
+    k_gbs = alg_bytes / (kms / max(kn, 1) * 1e-3) / 1e9
+    out = {'what': 'bare persistent 3:1 stream (48 B read + 16 B written per thread and step, lane-contiguous 16-byte loads, '
+                   'non-temporal stores, 512 workgroups of 1024 threads, no arithmetic) over buffers of the same size in the same '
+                   'rotation, dispatch time stamps like the kernel\'s, in a child process on the diagnostic build of the library; '
+                   'static = grid-stride split, static_prefetch = the same with the next chunk requested before this one is stored '
+                   '(the kernel\'s register prefetch), queueN = blocks of N chunks from a work queue',
+           'variants': per, 'best_GBps': best, 'frac_of_hbm_peak': round(best / HBM_PEAK_GBS, 4),
+           'interleaved_avg_launch_ms': round(pms / max(pn, 1), 4),
+           'kernel_right_after': {'avg_launch_ms': round(kms / max(kn, 1), 4), 'GBps': round(k_gbs, 1),
+                                  'frac_of_hbm_peak': round(k_gbs / HBM_PEAK_GBS, 4)},
+           'kernel_frac_of_achievable': round(k_gbs / best, 4)}
+    ctx.close()
+    print(json.dumps(out))
+
+
 def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=None):
     """Fused HLS + inRange + closing over nbuf distinct input / output buffer pairs (the pairs together exceed the
     Infinity Cache several times over).  HBM roofline from the per-launch event times."""
@@ -596,54 +687,9 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
         t2 = time.perf_counter() - t20
         two = {'launches': n2, 'ms_per_launch': round(t2 / n2 * 1e3, 4), 'GBps': round(alg_bytes * n2 / t2 / 1e9, 1),
                'frac_of_hbm_peak': round(alg_bytes * n2 / t2 / 1e9 / HBM_PEAK_GBS, 4)}
-    # What the part streams for this traffic mix, measured HERE: a bare persistent stream (48 B in, 16 B out per thread and
-    # step, no pixel arithmetic, the kernel's launch shape) over the same buffers in the same rotation, launches interleaved
-    # with the kernel's own so that both see the same clocks; the masks it overwrites are not used again.
-    ceiling = None
-    if hasattr(ctx, 'stream_probe_dev'):
-        in_bytes = FB * H * W * 3
-        variants = [('static', 0), ('static_prefetch', -1), ('queue2', 2), ('queue4', 4), ('comb', -2), ('comb_stride48', -3), ('comb_stride48_barriers', -4),
-                    ('comb_stride48_barriers_tables', -5)]
-        ctx.set_profiling(1)
-        ctx.timings()
-        rounds = max(6, min(steps, 24))
-        for i in range(rounds + 2):
-            if i == 2:
-                env.sync()
-                ctx.timings()       # the first two rounds are warm-up
-            b = i % nbuf
-            for (_name, ch) in variants:
-                ctx.stream_probe_dev(frames.data_ptr() + b * in_bytes, in_bytes, masks.data_ptr() + b * FB * H * W, ch, stream=env.stream)
-        env.sync()
-        (pms, pn) = ctx.timings()['k_stream_probe']
-        # per variant: the launches alternate, so a second pass with one variant at a time gives the split
-        per = {}
-        for (name, ch) in variants:
-            for i in range(rounds):
-                b = i % nbuf
-                ctx.stream_probe_dev(frames.data_ptr() + b * in_bytes, in_bytes, masks.data_ptr() + b * FB * H * W, ch, stream=env.stream)
-            env.sync()
-            (vms, vn) = ctx.timings()['k_stream_probe']
-            moved = (in_bytes // (48 * 1024)) * 64 * 1024
-            per[name] = {'avg_launch_ms': round(vms / max(vn, 1), 4), 'GBps': round(moved / (vms / max(vn, 1) * 1e-3) / 1e9, 1)}
-        # the kernel again, right after, for a same-minute comparison
-        for i in range(rounds):
-            launch(i)
-        env.sync()
-        (kms, kn) = ctx.timings()['k_fused_mask']
-        ctx.set_profiling(0)
-        best = max(v['GBps'] for v in per.values())
-        k_gbs = alg_bytes / (kms / max(kn, 1) * 1e-3) / 1e9
-        ceiling = {'what': 'bare persistent 3:1 stream (48 B read + 16 B written per thread and step, lane-contiguous 16-byte loads, '
-                           'non-temporal stores, 512 workgroups of 1024 threads, no arithmetic) over the SAME buffers in the same '
-                           'rotation, dispatch time stamps like the kernel\'s; static = grid-stride split, static_prefetch = the same with the '
-                           'next chunk requested before this one is stored (the kernel\'s register prefetch), queueN = blocks of N '
-                           'chunks from a work queue',
-                   'variants': per, 'best_GBps': best, 'frac_of_hbm_peak': round(best / HBM_PEAK_GBS, 4),
-                   'interleaved_avg_launch_ms': round(pms / max(pn, 1), 4),
-                   'kernel_right_after': {'avg_launch_ms': round(kms / max(kn, 1), 4), 'GBps': round(k_gbs, 1),
-                                          'frac_of_hbm_peak': round(k_gbs / HBM_PEAK_GBS, 4)},
-                   'kernel_frac_of_achievable': round(k_gbs / best, 4)}
+    # What the part streams for this traffic mix: a bare persistent stream of the same mix and launch shape, measured in this run by
+    # a child process on the DIAGNOSTIC build of the library (the product library does not carry measurement kernels)
+    ceiling = stream_ceiling_child(env, FB, H, W, nbuf, steps) if env.rank == 0 else None
     del masks
     return {
         'workload': 'B=%d %dx%d uniform-random u8 frames, fused HLS+inRange+closing only, %d distinct buffer pairs '
@@ -910,7 +956,10 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (nccl = RCCL)')
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal: ranks share the visible GPUs (gloo backend only)')
     ap.add_argument('--dry-run', action='store_true', help='launcher / collective rehearsal without a GPU; measures nothing')
+    ap.add_argument('--ceiling-child', default='', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.ceiling_child:
+        return ceiling_child_main(args.ceiling_child)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(args))

@@ -163,7 +163,9 @@ int melf_hls_inrange_close(melf_ctx* ctx, const uint8_t* frames_host, int n, int
 int melf_hls_inrange_close_dev(melf_ctx* ctx, const void* d_frames, int n, int H, int W,
                                void* d_masks, void* stream);
 
-/* Measurement aid for the fused stage's roofline (bench.py: fused_mask.stream_ceiling), nothing the reference has: one launch
+#ifdef MELF_DIAG
+/* DIAGNOSTIC BUILD ONLY (make -C meterelf_amd/csrc diag -> libmeterelf_hip_diag.so; the product library does not export it).
+ * Measurement aid for the fused stage's roofline (bench.py: fused_mask.stream_ceiling), nothing the reference has: one launch
  * of a BARE persistent stream with the fused kernel's traffic mix and launch shape -- 48 bytes read and 16 bytes written per
  * thread and step, no pixel arithmetic -- over the caller's device buffers: floor(in_bytes / 48 KiB) chunks of d_in are read,
  * a third as many bytes of d_out are overwritten with garbage (XOR of the input: point it at a mask buffer that is rewritten
@@ -173,6 +175,7 @@ int melf_hls_inrange_close_dev(melf_ctx* ctx, const void* d_frames, int n, int H
  * tables filled first); > 0: blocks of that many chunks from a work queue.  The launch
  * is timed like the fused kernel's (melf_ctx_set_profiling(1), entry MELF_K_STREAM_PROBE of melf_ctx_timings). */
 int melf_stream_probe_dev(melf_ctx* ctx, const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, void* stream);
+#endif
 
 /* Number of entries of the fused stage's hue lookup table whose in-range answer
  * depends on the float32 rounding of the individual BGR triple (exact rounding
@@ -234,6 +237,14 @@ int melf_jpeg_probe_batch(const uint8_t* const* data, const size_t* sizes, int n
  * Synchronises the context's stream. */
 int melf_jpeg_decode_batch(melf_ctx* ctx, const uint8_t* const* data, const size_t* sizes, int n, int H, int W,
                            void* out, int out_on_device, int32_t* status);
+
+/* Stage entry point (parity tests): the first decode stage alone -- byte stuffing (FF 00), fill bytes and RSTn markers taken out
+ * of ONE entropy-coded segment on the GPU, as libjpeg's bit reader does while it reads (cv2.imread, meterelf/_image.py:49).
+ * raw[n]: any bytes; restart_expected > 0: the segment of a file with restart intervals, rst receives the bit offsets of its
+ * restart_expected + 1 intervals (as the kernel leaves them) and rst_cnt the number found.  out must hold n + 192 bytes (clean
+ * bytes, then zero fill); out_len receives the cleaned length.  Returns 0, or -1 on a bad argument / HIP error. */
+int melf_jpeg_clean_segment(const uint8_t* raw, int n, int restart_expected, uint8_t* out, int32_t* out_len, uint32_t* rst,
+                            int32_t* rst_cnt);
 
 /* get_meter_value for n JPEG files (meterelf/_api.py:22-33 with _image.py:46-51): decode on the GPU
  * straight into HBM, then the same path as melf_process_batch.  Records of files whose status is

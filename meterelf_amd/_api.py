@@ -60,9 +60,8 @@ _idle_readers: Dict[bytes, MeterReader] = {}
 _idle_lock = threading.Lock()
 _IDLE_MAX = 2
 _devices_used = 1
-_ENV_IN_KEY = ('MELF_MATCH', 'MELF_MATCH_LAYOUT', 'MELF_GEN_SHAPE', 'MELF_LANES', 'MELF_FORCE_GENERIC_MASK', 'MELF_FUSED_VARIANT',
-               'MELF_FUSED_CONFIG', 'MELF_JPEG_CHUNK', 'MELF_JPEG_SERIAL', 'MELF_JPEG_READ', 'MELF_JPEG_PARSE', 'MELF_JPEG_NO_REORDER', 'MELF_FILES_NO_OVERLAP',
-               'MELF_IO_THREADS', 'MELF_LIB_PATH')
+_ENV_IN_KEY = ('MELF_MATCH', 'MELF_MATCH_LAYOUT', 'MELF_GEN_SHAPE', 'MELF_FORCE_GENERIC_MASK', 'MELF_FUSED_VARIANT', 'MELF_JPEG_CHUNK',
+               'MELF_IO_THREADS', 'MELF_HOST_THREADS', 'MELF_LIB_PATH')
 
 
 def _reader_key(params, blob, device: int) -> bytes:

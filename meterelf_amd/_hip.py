@@ -72,14 +72,16 @@ class HipError(RuntimeError):
     pass
 
 
-# every symbol include/meterelf_hip.h declares
+# every symbol include/meterelf_hip.h declares for the product library; DIAG_EXPORTS: what its `#ifdef MELF_DIAG` part adds (the
+# diagnostic build, make -C meterelf_amd/csrc diag, loaded through MELF_LIB_PATH)
+DIAG_EXPORTS = ['melf_stream_probe_dev']
 EXPORTS = [
     'melf_last_error', 'melf_abi_version', 'melf_device_count', 'melf_build_dial_masks',
     'melf_blob_size', 'melf_blob_pack', 'melf_blob_params', 'melf_ctx_create', 'melf_ctx_create_bcast', 'melf_ctx_destroy',
     'melf_ctx_params', 'melf_ctx_sync', 'melf_ctx_get_masks', 'melf_process_batch', 'melf_process_batch_dev', 'melf_process_stream_dev',
-    'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_stream_probe_dev', 'melf_match_ccoeff',
+    'melf_bgr2hls', 'melf_hls_inrange_close', 'melf_hls_inrange_close_dev', 'melf_match_ccoeff',
     'melf_read_dials', 'melf_aligned_average', 'melf_inrange', 'melf_ctx_fused_table_ties', 'melf_ctx_set_frames_resident', 'melf_ctx_last_match', 'melf_match_layout_query', 'melf_match_gen_plan_query', 'melf_ctx_set_profiling', 'melf_ctx_timings', 'melf_kernel_name',
-    'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_process_batch',
+    'melf_jpeg_probe', 'melf_jpeg_probe_batch', 'melf_jpeg_decode_batch', 'melf_jpeg_clean_segment', 'melf_jpeg_process_batch',
     'melf_jpeg_process_files', 'melf_jpeg_process_files_begin', 'melf_jpeg_process_files_end', 'melf_jpeg_files_in_flight_max', 'melf_ctx_files_stats', 'melf_files_open_probe',
 ]
 
@@ -119,7 +121,8 @@ def lib():
     L.melf_bgr2hls.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp]
     L.melf_hls_inrange_close.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.melf_hls_inrange_close_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
-    L.melf_stream_probe_dev.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
+    if hasattr(L, 'melf_stream_probe_dev'):   # the diagnostic build only
+        L.melf_stream_probe_dev.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
     L.melf_match_ccoeff.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.melf_read_dials.argtypes = [vp, vp, C.c_int, vp]
     L.melf_aligned_average.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, C.c_int, vp]
@@ -393,6 +396,8 @@ class Context:
                                                   C.c_void_p(d_masks_ptr), C.c_void_p(stream) if stream else None))
 
     def stream_probe_dev(self, d_in_ptr, in_bytes, d_out_ptr, chunks_per_block=0, stream=None):
+        if not hasattr(self._L, 'melf_stream_probe_dev'):
+            raise HipError('melf_stream_probe_dev is part of the diagnostic build only (make -C meterelf_amd/csrc diag; MELF_LIB_PATH)')
         """Measurement aid: one bare 3:1 stream launch over device buffers (include/meterelf_hip.h); d_out is overwritten."""
         check(self._L.melf_stream_probe_dev(self._h, C.c_void_p(d_in_ptr), C.c_size_t(in_bytes), C.c_void_p(d_out_ptr),
                                              int(chunks_per_block), C.c_void_p(stream) if stream else None))

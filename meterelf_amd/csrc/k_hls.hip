@@ -878,7 +878,7 @@ bool fused_mask_lut_ok(const void* d_frames, const void* d_masks, int H, int W)
     return W >= 16 && W <= 512 * 16 && (W & 15) == 0 && (((size_t)d_frames | (size_t)d_masks) & 15) == 0 && H >= 1;
 }
 
-// launch configuration (MELF_FUSED_CONFIG=0..3 for experiments):
+// launch configuration (the product compiles ONE per kernel variant, see launch_lut_v; MELF_FUSED_CONFIG of the diagnostic build selects the others):
 //   0: 512 threads, 3 workgroups/CU (6 waves/SIMD, <= 80 VGPRs), no prefetch   [default of the bit-table variants until round 4]
 //   4: 1024 threads, 2 workgroups/CU (8 waves/SIMD, <= 64 VGPRs), register prefetch [default of the interval-table
 //      variants: with the launches rotating over buffers beyond the Infinity Cache it is 3-10 % faster than 2 x 512
@@ -914,8 +914,8 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
         per_cu = std::min<int>(per_cu, (int)(160 * 1024 / lds_wg));
     }
     const int target = 256 * (per_cu < 1 ? 1 : per_cu);
-    static const int seg_mult = getenv("MELF_FUSED_SEGMULT") ? atoi(getenv("MELF_FUSED_SEGMULT")) : 1;  // experiments
-    static const int plain_store = getenv("MELF_FUSED_PLAINSTORE") ? atoi(getenv("MELF_FUSED_PLAINSTORE")) : 0;
+    static const int seg_mult = diag_env("MELF_FUSED_SEGMULT") ? atoi(diag_env("MELF_FUSED_SEGMULT")) : 1;  // experiments
+    static const int plain_store = diag_env("MELF_FUSED_PLAINSTORE") ? atoi(diag_env("MELF_FUSED_PLAINSTORE")) : 0;
     int segs = (target * seg_mult + n - 1) / n;
     int seg_rows = (H + segs - 1) / segs;
     if (seg_rows < 32) seg_rows = H < 32 ? H : 32;
@@ -928,12 +928,12 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // split, config 5 0.769-0.828 against 0.740-0.748: with one pass of register prefetch a workgroup that is alone on its CU
     // still saturates its share of HBM, so the early finishers cost nothing, and the queue's segments pay their halo rows.
     // The default stays the static split; MELF_FUSED_DYN=N switches the queue on (tests keep it honest).
-    const int dyn = (PF == 1 && REP == 32 && T == 1024) ? (getenv("MELF_FUSED_DYN") ? atoi(getenv("MELF_FUSED_DYN")) : 0) : 0;
-    const int grid_cap = getenv("MELF_FUSED_GRID") ? std::max(1, atoi(getenv("MELF_FUSED_GRID"))) : target;
+    const int dyn = (PF == 1 && REP == 32 && T == 1024) ? (diag_env("MELF_FUSED_DYN") ? atoi(diag_env("MELF_FUSED_DYN")) : 0) : 0;
+    const int grid_cap = diag_env("MELF_FUSED_GRID") ? std::max(1, atoi(diag_env("MELF_FUSED_GRID"))) : target;
     const int wgs = std::min(target, grid_cap);
     // MELF_FUSED_BIG = percent of a frame's rows dealt as one big first segment per workgroup (the queue then hands out the rest
     // in small ones: the halo rows of small segments are paid only where balancing needs them); 0 = small segments only
-    const int big_pct = getenv("MELF_FUSED_BIG") ? std::min(95, std::max(0, atoi(getenv("MELF_FUSED_BIG")))) : 0;
+    const int big_pct = diag_env("MELF_FUSED_BIG") ? std::min(95, std::max(0, atoi(diag_env("MELF_FUSED_BIG")))) : 0;
     uint32_t* wq = nullptr;
     int big_segs = 0, big_rows = 0;
     if (dyn > 0) {
@@ -967,7 +967,7 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, REP>, hipFuncAttributeMaxDynamicSharedMemorySize, PF < 0 ? 160 * 1024 - 65664 : 28 * 1024);
-        if (getenv("MELF_FUSED_TRACE")) {
+        if (diag_env("MELF_FUSED_TRACE")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fused_mask_lut<V, T, PF, WPS, REP>, T, shmem);
             fprintf(stderr, "[melf fused] V=%d T=%d PD=%d WPS=%d grid=%d shmem=%zu resident blocks/CU=%d\n", V, T, PF, WPS, grid, shmem, nb);
@@ -976,12 +976,13 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     }
     // timing events (optional, set by the caller through fused_mask_timing_events): the dispatch's own start / stop stamps,
     // no event-record packets in the queue around the kernel
-    const int ps = plain_store | ((getenv("MELF_FUSED_PRIO") ? atoi(getenv("MELF_FUSED_PRIO")) : 0) << 8);
+    const int ps = plain_store | ((diag_env("MELF_FUSED_PRIO") ? atoi(diag_env("MELF_FUSED_PRIO")) : 0) << 8);
+#ifdef MELF_DIAG   // work queue / early refill: experiments of round 5 (no gain: profiles/r05/fused_*_ab.txt), diagnostic build only
     if constexpr (PF == 1 && REP == 32 && T == 1024) {   // the two experiments below are instantiated for the default launch shapes only
         // early refill (round 5 experiment, MELF_FUSED_EARLY=1): measured no different from the refill at the start of the next
         // pass (config 2 0.0668 / 0.0681 against 0.0664 ms, config 5 0.782 / 0.824 against 0.781 / 0.820: profiles/r05/
         // fused_early_refill_ab.txt) -- the launch is not short of requests in flight.  Off by default.
-        const bool early = !wq && getenv("MELF_FUSED_EARLY") && atoi(getenv("MELF_FUSED_EARLY")) == 1;
+        const bool early = !wq && diag_env("MELF_FUSED_EARLY") && atoi(diag_env("MELF_FUSED_EARLY")) == 1;
         if (early) {
             static bool early_attr_set[64] = {false};
             if (dev >= 0 && dev < 64 && !early_attr_set[dev]) {
@@ -1005,6 +1006,9 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
             return;
         }
     }
+#else
+    (void)wq; (void)big_segs; (void)big_rows;
+#endif
     hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, REP>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
                           n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
     g_fused_ev_start = g_fused_ev_stop = nullptr;
@@ -1014,36 +1018,41 @@ template <int V>
 static void launch_lut_v(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const Bounds& B,
                          uint32_t* d_tables, uint8_t* d_masks, hipStream_t stream)
 {
+#ifdef MELF_DIAG   // the launch shapes of rounds 2-5 (MELF_FUSED_CONFIG), for A/B runs with the diagnostic build
     if constexpr (V >= 5) {  // interval tables (64 KiB per workgroup); 5: timing-only twin of the same launch shapes
         switch (g_fused_config) {
-            case 1: launch_lut_t<V, 512, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 3: launch_lut_t<V, 1024, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 4: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 5: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 6: launch_lut_t<V, 1024, -1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;   // LDS-DMA staging
-            case 0: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 1: launch_lut_t<V, 512, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;
+            case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;
+            case 3: launch_lut_t<V, 1024, 2, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;
+            case 5: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;
+            case 6: launch_lut_t<V, 1024, -1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;   // LDS-DMA staging
+            case 0: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;
             // round 5: smaller tables (8 / 16 copies of a row), more and smaller workgroups per CU
-            case 8: if constexpr (V >= 6) { launch_lut_t<V, 256, 1, 8, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
-            case 9: if constexpr (V >= 6) { launch_lut_t<V, 512, 1, 8, 16>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
-            case 10: if constexpr (V >= 6) { launch_lut_t<V, 512, 1, 8, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
-            default: launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+            case 8: if constexpr (V >= 6) { launch_lut_t<V, 256, 1, 8, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return; } break;
+            case 9: if constexpr (V >= 6) { launch_lut_t<V, 512, 1, 8, 16>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return; } break;
+            case 10: if constexpr (V >= 6) { launch_lut_t<V, 512, 1, 8, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return; } break;
+            default: break;
         }
     } else {
         switch (g_fused_config) {
-            case 0: if constexpr (V != 4) { launch_lut_t<V, 512, 0, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break; }
-            case 1: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 2: launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            case 3: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-            default:
-                // round 4, rotating buffers (tools/run_stage.py fused, MELF_FUSED_VARIANT=bits / generic): 1024 threads with the
-                // register prefetch 0.0705 / 0.093 ms per B = 256 launch against 0.100 / 0.110 for the old default (512 threads x 6
-                // waves per SIMD at <= 80 VGPRs, which spilled 14-44 registers into scratch); nothing spills at 128
-                if constexpr (V == 4) launch_lut_t<V, 512, 0, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);  // the tie path needs > 80 VGPRs
-                else launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
-                break;
+            case 0: if constexpr (V != 4) { launch_lut_t<V, 512, 0, 6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return; } break;
+            case 1: launch_lut_t<V, 512, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;
+            case 2: if constexpr (V == 4) { launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return; } break;
+            case 3: launch_lut_t<V, 1024, 0, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); return;
+            default: break;
         }
     }
+#endif
+    // ONE launch shape per variant (what production runs and the parity tests cover):
+    //   interval tables (6 / 7 / 8; single hue sector, every table row one run): 1024 threads, 2 workgroups per CU (8 waves per SIMD,
+    //     <= 64 registers), register prefetch one pass ahead -- with the launches rotating over buffers beyond the Infinity Cache 3-10 %
+    //     faster than 2 x 512 threads;
+    //   bit tables / generic (0 / 1 / 2 / 3): 1024 threads, 4 waves per SIMD, register prefetch (round 4: 0.0705 / 0.093 ms per B = 256
+    //     launch against 0.100 / 0.110 for 512 threads x 6 waves per SIMD, which spilled);
+    //   generic with tie re-evaluation (4): 512 threads, no prefetch (the tie path needs more than 80 registers).
+    if constexpr (V >= 5) launch_lut_t<V, 1024, 1, 8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
+    else if constexpr (V == 4) launch_lut_t<V, 512, 0, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
+    else launch_lut_t<V, 1024, 1, 4>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream);
 }
 
 // variant: 0/1/2 single sector r/g/b (bit tables), 3 generic, 4 generic with tie re-evaluation, 5 timing-only,
@@ -1055,7 +1064,7 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
     Bounds B;
     for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
     {   // read at every launch (a getenv is nothing beside a launch): tests and A/B scripts switch it inside one process
-        const char* e = getenv("MELF_FUSED_CONFIG");
+        const char* e = diag_env("MELF_FUSED_CONFIG");
         g_fused_config = e ? atoi(e) & 15 : -1;
     }
     switch (variant) {
@@ -1063,7 +1072,9 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
         case 1: launch_lut_v<1>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         case 2: launch_lut_v<2>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         case 3: launch_lut_v<3>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
-        case 5: launch_lut_v<5>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
+#ifdef MELF_DIAG
+        case 5: launch_lut_v<5>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;   // timing only (garbage output)
+#endif
         case 6: launch_lut_v<6>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         case 7: launch_lut_v<7>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
         case 8: launch_lut_v<8>(d_frames, n, H, W, hue_shift, B, d_tables, d_masks, stream); break;
@@ -1071,6 +1082,7 @@ void launch_fused_mask_lut(const uint8_t* d_frames, int n, int H, int W, int hue
     }
 }
 
+#ifdef MELF_DIAG
 // ---------------------------------------------------------------------------
 // Measurement aid (bench.py's `stream_ceiling`; no pixel arithmetic, no caller in the product path): a BARE persistent stream
 // of the fused kernel's traffic mix over the caller's buffers -- 48 bytes in, 16 bytes out per thread and step, lane-contiguous
@@ -1211,6 +1223,7 @@ size_t launch_stream_probe(const void* d_in, size_t in_bytes, void* d_out, int c
     }
     return (size_t)nchunks * 64 * 1024;
 }
+#endif  // MELF_DIAG
 
 void launch_fused_mask(const uint8_t* d_frames, int n, int H, int W, int hue_shift, const int lo[3], const int hi[3],
                        uint8_t* d_masks, hipStream_t stream)

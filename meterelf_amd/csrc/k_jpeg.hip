@@ -427,10 +427,10 @@ __global__ __launch_bounds__(CLEAN_T) void k_jpeg_clean(JpegImageDev* __restrict
     }
 }
 
-// Test entry (tests/test_jpeg.py; not part of the C ABI in include/): k_jpeg_clean on ONE byte string as if it were a file's
+// Stage entry point (include/meterelf_hip.h, melf_jpeg_clean_segment; tests/test_jpeg.py): k_jpeg_clean on ONE byte string as if it were a file's
 // entropy-coded segment -- arbitrary bytes, so that the tests can feed it every FF pattern, legal or not, and compare with the
 // sequential rule.  restart_expected > 0: a file with restart intervals, table of restart_expected + 1 entries.
-extern "C" __attribute__((visibility("default"))) int melf_debug_jpeg_clean(const uint8_t* raw, int n, int restart_expected, uint8_t* out,
+extern "C" __attribute__((visibility("default"))) int melf_jpeg_clean_segment(const uint8_t* raw, int n, int restart_expected, uint8_t* out,
                                                                             int32_t* out_len, uint32_t* rst, int32_t* rst_cnt)
 {
     if (n < 0 || !out || !out_len || (n > 0 && !raw)) return -1;
@@ -1567,7 +1567,7 @@ int jpeg_prepare_batch(JpegWorkspace** pws, const uint8_t* const* data, const si
 {
     if (!*pws) *pws = new JpegWorkspace();
     JpegWorkspace* w = *pws;
-    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    static const bool trace = diag_env("MELF_JPEG_TRACE") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     std::vector<JpegHeader> own;
     std::vector<size_t> scan_off(n + 1, 0), raw_off(n + 1, 0);
@@ -1787,10 +1787,10 @@ int jpeg_decode_batch_kernels(JpegWorkspace* w, int n, int H, int W, uint8_t* d_
         hipLaunchKernelGGL(k_jpeg_clean, dim3(n), dim3(CLEAN_T), 0, stream, (JpegImageDev*)(w->d_stage + w->off_imgs), w->d_raw, w->d_stage + w->off_scan);
     if (w->n_par > 0) {  // one workgroup per image, one lane per stream segment
         static int tenv = -1;
-        if (tenv < 0) { const char* e = getenv("MELF_JPEG_T"); tenv = e ? atoi(e) : 0; }
+        if (tenv < 0) { const char* e = diag_env("MELF_JPEG_T"); tenv = e ? atoi(e) : 0; }
         // 512 lanes per image; a batch with a scan too long for 512 segments of the length the kernel can address takes 1024
         const int tsel = tenv ? tenv : (w->max_par_scan > JPEG_MAX_PAR_SCAN / 2 ? 1024 : 512);
-        static const int limit = getenv("MELF_JPEG_WINDOW_LIMIT") ? atoi(getenv("MELF_JPEG_WINDOW_LIMIT")) : 1;   // A/B switch
+        static const int limit = diag_env("MELF_JPEG_WINDOW_LIMIT") ? atoi(diag_env("MELF_JPEG_WINDOW_LIMIT")) : 1;   // A/B switch
 #define LAUNCH_HUFF(TT) \
     hipLaunchKernelGGL(k_jpeg_huff<TT>, dim3(n), dim3(TT), 0, stream, imgs, slow, scan, w->d_coefs, w->d_status, win, limit)
         if (tsel == 128) LAUNCH_HUFF(128);

@@ -575,7 +575,9 @@ static int ensure_fused_tables(melf_ctx* c)
         if (!strcmp(ev, "generic") && namb == 0) c->fused_variant = 3;
         if (!strcmp(ev, "bits") && c->fused_variant >= 6) c->fused_variant -= 6;  // single-sector bit tables
         if (!strcmp(ev, "ties")) c->fused_variant = 4;
+#ifdef MELF_DIAG
         if (!strcmp(ev, "memonly")) c->fused_variant = 5;  // timing experiments only: output is garbage
+#endif
     }
     c->d_fused_tables = tables;
     return MELF_SUCCESS;
@@ -617,7 +619,7 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
             rc = fail(MELF_ERR_HIP, "hipStreamCreate failed");
     if (!rc && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess)
         rc = fail(MELF_ERR_HIP, "hipEventCreate failed");
-    if (const char* e = getenv("MELF_LANES")) c->lanes = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = diag_env("MELF_LANES")) c->lanes = atoi(e) == 2 ? 2 : 1;
     if (!rc) rc = setup_device_tables(c);
     if (rc) {
         melf_ctx_destroy(c);
@@ -1000,7 +1002,7 @@ static int gen_entry(melf_ctx* c, int rows, int cols, int n, melf_ctx::GenEntry*
     ge->rows = rows; ge->cols = cols; ge->groups = groups;
     ge->plan = gen_plan(c->P.th, c->P.tw, rows, cols, n);
     const GenPlan& p = ge->plan;
-    if (getenv("MELF_GEN_TRACE"))
+    if (diag_env("MELF_GEN_TRACE"))
         fprintf(stderr, "[melf gen] crop %dx%d n=%d: map %dx%d nd=%d tiles of %d rows x %d blocks, %d tiles (%d V columns) x %d groups = %d workgroups of %d waves, %zu B of LDS each\n",
                 rows, cols, n, p.rh, p.rw, p.nd, p.rc, p.nxb_tile, p.ntiles, p.vcols, p.groups, p.ntiles * p.groups, p.nslices, p.lds_bytes);
     auto upload = [&]() -> int {
@@ -1055,7 +1057,7 @@ static int run_match_impl(melf_ctx* c, const MatchSrc& ms, bool from_bgr, int m,
     melf_match_info& info = c->last_match;
     memset(&info, 0, sizeof(info));
     info.kernel = kind; info.n = m; info.rows = ms.rows; info.cols = ms.cols; info.groups = (m + 31) / 32;
-    static const bool trace = getenv("MELF_MATCH_TRACE") != nullptr;
+    static const bool trace = diag_env("MELF_MATCH_TRACE") != nullptr;
     if (c->profiling && kind != MK_DOT4) {  // the dispatch's own time stamps: no event-record packets around the kernel
         // timing only: without the system-scope fence (cache write-back and invalidate) a default event brings along
         // -- that fence put 7 us in front of the kernel and 5 us behind it (rocprofv3 kernel trace, round 2)
@@ -1320,7 +1322,7 @@ extern "C" int melf_process_batch(melf_ctx* c, const uint8_t* frames_host, int n
     } else if (int rc = acquire_lane(c, c->stream, &c->active_lane)) {
         return rc;
     }
-    static const bool trace = getenv("MELF_HOSTFED_TRACE") != nullptr;
+    static const bool trace = diag_env("MELF_HOSTFED_TRACE") != nullptr;
     double pack_ms = 0;
     const auto t_begin = std::chrono::steady_clock::now();
     const int rect[4] = {0, 0, ccols, crows};
@@ -1422,6 +1424,7 @@ extern "C" int melf_hls_inrange_close_dev(melf_ctx* c, const void* d_frames, int
     return MELF_SUCCESS;
 }
 
+#ifdef MELF_DIAG   // measurement aid of the diagnostic build (bench.py's stream_ceiling): not an entry point of the product library
 extern "C" int melf_stream_probe_dev(melf_ctx* c, const void* d_in, size_t in_bytes, void* d_out, int chunks_per_block, void* stream_)
 {
     if (!c || !d_in || !d_out) return fail(MELF_ERR_INVALID, "bad argument");
@@ -1440,6 +1443,7 @@ extern "C" int melf_stream_probe_dev(melf_ctx* c, const void* d_in, size_t in_by
     HIP_TRY(hipGetLastError());
     return MELF_SUCCESS;
 }
+#endif
 
 extern "C" int melf_hls_inrange_close(melf_ctx* c, const uint8_t* frames_host, int n, int H, int W, uint8_t* masks_host)
 {
@@ -1617,7 +1621,7 @@ int jpeg_decode_to_device(melf_ctx* c, const uint8_t* const* data, const size_t*
                           uint8_t* d_frames, int32_t* status, const int* rect)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned stage buffer of the previous batch is free again
-    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    static const bool trace = diag_env("MELF_JPEG_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int32_t> hstat(n);
     std::string err;
@@ -1750,7 +1754,7 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
     // every file's headers in one parallel pass; the chunks then only build tables and clean scans
     // (MELF_JPEG_PARSE=all, the round-3 arrangement; by default each chunk parses its own files, so that only the first
     // chunk's headers are parsed before the first upload can start: 0.24 ms of a 1024-file call's head otherwise)
-    const char* pmode = getenv("MELF_JPEG_PARSE");
+    const char* pmode = diag_env("MELF_JPEG_PARSE");
     const bool parse_all = pmode && !strcmp(pmode, "all");
     struct ParsedGuard { JpegParsed* p; ~ParsedGuard() { if (p) jpeg_parsed_free(p); } } parsed{
         parse_all && !src ? jpeg_parse_files(data, sizes, n, H, W, hstat.data()) : nullptr};
@@ -1760,7 +1764,7 @@ static int jpeg_decode_pipelined(melf_ctx* c, const uint8_t* const* data, const 
         if (m > n - f0) m = n - f0;
         const uint64_t seq = seq0 + (uint64_t)k;
         const int b = (int)(seq % NJ);
-        static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+        static const bool trace = diag_env("MELF_JPEG_TRACE") != nullptr;
         double tt[5] = {};
         if (trace) tt[0] = trace_clock_ms(std::chrono::steady_clock::now());
         // the upload that last read this workspace's pinned stage buffer must be done before the host refills it
@@ -1829,7 +1833,7 @@ static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, cons
     const int cs = overlapped ? tl_jpeg_slot % melf_ctx::NJC : 0;
     // the reading path only looks at the meter_rect crop: IDCT and colour conversion are limited to it
     const int rect[4] = {c->P.rect_x0, c->P.rect_y0, c->P.rect_x1, c->P.rect_y1};
-    const bool serial = getenv("MELF_JPEG_SERIAL") != nullptr;   // A/B and tests: the one-piece path
+    const bool serial = diag_env("MELF_JPEG_SERIAL") != nullptr;   // A/B and tests: the one-piece path
     if (!overlapped) HIP_TRY(hipStreamSynchronize(c->stream));   // a caller's earlier work on the context's stream
     if (serial || n <= 64) {
         if (overlapped) HIP_TRY(hipDeviceSynchronize());   // the one-piece path shares its buffers with every call: alone on the GPU
@@ -1837,7 +1841,7 @@ static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, cons
         if (int rc = jpeg_decode_to_device(c, data, sizes, n, H, W, c->d_stage_in, status, rect)) return rc;
         return melf_process_batch_dev(c, c->d_stage_in, n, H, W, (size_t)H * W * 3, nullptr, out_host, c->stream);
     }
-    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    static const bool trace = diag_env("MELF_JPEG_TRACE") != nullptr;
     const auto tc0 = std::chrono::steady_clock::now();
     // Files with very few bits per block (a dark, flat frame: "DC difference 0, end of block" and nothing else) keep the
     // Huffman kernel's wrongly-phased decoders in step with their garbage, so the truth crawls one segment per round and
@@ -1850,7 +1854,7 @@ static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, cons
     std::vector<int> pindex;
     JpegSource psrc;
     int nsparse = 0;
-    if (!getenv("MELF_JPEG_NO_REORDER")) {
+    if (!diag_env("MELF_JPEG_NO_REORDER")) {
         const double blocks = ((H + 7) / 8) * (double)((W + 7) / 8) * 1.5;
         for (int i = 0; i < n; ++i) nsparse += (double)sizes[i] * 8.0 < 12.0 * blocks ? 1 : 0;
         if (nsparse > 0 && nsparse < n) {
@@ -1874,7 +1878,7 @@ static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, cons
     // the reading path: ONE pass over all n frames behind the last chunk (the tuned match kernel in its full-batch layout);
     // MELF_JPEG_READ=chunk runs it per chunk on the chunk's stream instead (3 % faster on sample-images1, 1 % slower on
     // sample-images2, equal with three calls in flight: not the default, the full-batch layout is what the tests assert)
-    const char* rmode = getenv("MELF_JPEG_READ");
+    const char* rmode = diag_env("MELF_JPEG_READ");
     const bool read_chunks = rmode && !strcmp(rmode, "chunk");
     if (int rc = grow(&c->d_jframes[cs], &c->jframes_cap[cs], bytes)) return rc;
     if (int rc = grow(&c->d_jresults[cs], &c->jresults_cap[cs], (size_t)n)) return rc;
@@ -1889,7 +1893,7 @@ static int jpeg_process_batch_from(melf_ctx* c, const uint8_t* const* data, cons
     }
     // blocking sync: the thread that waits for a call's kernels sleeps instead of spinning (several calls wait at any time --
     // three per context, times the contexts of a process -- and the cores are needed by the I/O pool's readers)
-    static const bool spin = getenv("MELF_JPEG_SPIN_WAIT") != nullptr;   // A/B
+    static const bool spin = diag_env("MELF_JPEG_SPIN_WAIT") != nullptr;   // A/B
     if (!c->ev_jcall[cs]) HIP_TRY(hipEventCreateWithFlags(&c->ev_jcall[cs], hipEventDisableTiming | (spin ? 0 : hipEventBlockingSync)));
     int rc = jpeg_decode_pipelined(c, data, sizes, n, H, W, rect, hstat, read_chunks, nsparse, c->d_jframes[cs], c->d_jresults[cs], c->h_jstatus[cs],
                                    overlapped, src);
@@ -1958,7 +1962,7 @@ static int jpeg_files_read(melf_ctx* c, int slot, const char* const* paths, int 
     // pageable memory (the decode stage then copies it like a caller's buffer), and the arena is replaced by a larger one
     // before the slot's NEXT call reads into it.  Files sit in the arena in the order the threads claimed their places; the
     // decode stage forms its chunks in arena order, so that a chunk's upload is still one contiguous span.
-    static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+    static const bool trace = diag_env("MELF_JPEG_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int>&hs = R.hs, &ws = R.ws, &oks = R.oks;
     std::vector<size_t>&off = R.off, &len = R.len;
@@ -2170,7 +2174,7 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
             // whatever happens in the stages, the ticket must be handed on: the next call's decode stage waits for it
             int rc = MELF_SUCCESS;
             FilesRead R;
-            static const bool trace = getenv("MELF_JPEG_TRACE") != nullptr;
+            static const bool trace = diag_env("MELF_JPEG_TRACE") != nullptr;
             const auto tb0 = std::chrono::steady_clock::now();
             try {
                 rc = jpeg_files_read(c, (int)(ticket % melf_ctx::NFJ), paths, n, H_used, W_used, out_host, status, R);
@@ -2202,7 +2206,7 @@ extern "C" int melf_jpeg_process_files_begin(melf_ctx* c, const char* const* pat
             };
             if (rc == MELF_SUCCESS) {
                 try {
-                    rc = jpeg_files_decode(c, n, H_used, W_used, out_host, status, R, getenv("MELF_FILES_NO_OVERLAP") ? nullptr : &release,
+                    rc = jpeg_files_decode(c, n, H_used, W_used, out_host, status, R, diag_env("MELF_FILES_NO_OVERLAP") ? nullptr : &release,
                                            (int)(ticket % melf_ctx::NJC), true);
                 } catch (const std::exception& e) {
                     rc = fail(MELF_ERR_INVALID, std::string("out of host memory: ") + e.what());

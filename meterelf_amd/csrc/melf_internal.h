@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libmeterelf_hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <stdint.h>
@@ -8,6 +9,16 @@
 #include "../../include/meterelf_hip.h"
 
 namespace melf {
+
+// Environment switches.  The PRODUCT library reads only the documented ones (README.md, "Environment switches": MELF_MATCH,
+// MELF_MATCH_LAYOUT, MELF_GEN_SHAPE, MELF_FUSED_VARIANT, MELF_FORCE_GENERIC_MASK, MELF_JPEG_CHUNK, MELF_IO_THREADS,
+// MELF_HOST_THREADS).  Trace output and the A/B switches of past experiments exist only in the diagnostic build
+// (`make -C meterelf_amd/csrc diag`, -DMELF_DIAG, loaded through MELF_LIB_PATH): there diag_env is getenv, here it is nothing.
+#ifdef MELF_DIAG
+inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+#endif
 
 // ---- K2: template match -----------------------------------------------------
 // One partial (max, first-argmax) per workgroup tile of the correlation map.

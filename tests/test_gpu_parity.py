@@ -207,96 +207,6 @@ def test_fused_mask_other_bounds(env, tmp_path, needle):
         reader.close()
 
 
-@pytest.mark.parametrize('grid,dyn,big', [(1, 3, 0), (2, 1, 60), (3, 7, 0), (5, 2, 70), (16, 4, 50), (4, 3, 30)])
-def test_fused_mask_work_queue(env, monkeypatch, grid, dyn, big):
-    """Round 5: the fused launch's persistent workgroups take their segments from a work queue (k_fused_mask_lut<.., DYN>), with
-    the register prefetch running across segment boundaries.  Production shapes reach it with 512 workgroups; here
-    MELF_FUSED_GRID leaves a few workgroups for small inputs, so that every one of them walks through many segments
-    (whole-frame segments, several segments per frame, a short last segment, more workgroups than segments' first round;
-    MELF_FUSED_BIG: one big first segment per workgroup, the rest of the rows in small ones behind them):
-    masks equal to the oracle's AND to the static split's (MELF_FUSED_DYN=0), twice in a row (the queue slot is left zeroed)."""
-    from oracle import pyoracle as po
-    ctx = env['sample-images1']['reader'].ctx
-    p = ctx.params
-    rng = np.random.default_rng(100 * grid + dyn)
-    for (n, H, W) in ((6, 200, 160), (3, 640, 480), (2, 333, 1920), (9, 37, 64), (5, 101, 48), (2, 1080, 1920)):
-        frames = _blobby(rng, n, H, W)
-        monkeypatch.setenv('MELF_FUSED_DYN', '0')
-        monkeypatch.delenv('MELF_FUSED_GRID', raising=False)
-        static = ctx.hls_inrange_close(frames)
-        monkeypatch.setenv('MELF_FUSED_DYN', str(dyn))
-        monkeypatch.setenv('MELF_FUSED_GRID', str(grid))
-        monkeypatch.setenv('MELF_FUSED_BIG', str(big))
-        for rep in range(2):
-            got = ctx.hls_inrange_close(frames)
-            assert np.array_equal(got, static), (n, H, W, rep, np.argwhere(got != static)[:5])
-        for f in range(n):
-            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
-
-
-@pytest.mark.parametrize('grid', [0, 3])
-def test_fused_mask_early_refill(env, monkeypatch, grid):
-    """MELF_FUSED_EARLY=1 (round 5 experiment, k_fused_mask_lut<.., 2>): the rows of pass p + 2 requested as soon as pass p's in-range
-    test has consumed its register set, nothing fetched beyond a segment's end.  Same masks as the default launch and the oracle:
-    one-pass, two-pass and many-pass segments, several segments per workgroup (MELF_FUSED_GRID), a full-size batch."""
-    from oracle import pyoracle as po
-    ctx = env['sample-images1']['reader'].ctx
-    p = ctx.params
-    rng = np.random.default_rng(77 + grid)
-    for (n, H, W) in ((6, 200, 160), (3, 640, 480), (2, 333, 1920), (9, 37, 64), (5, 101, 48), (40, 480, 640)):
-        frames = _blobby(rng, n, H, W)
-        monkeypatch.delenv('MELF_FUSED_EARLY', raising=False)
-        monkeypatch.delenv('MELF_FUSED_GRID', raising=False)
-        ref = ctx.hls_inrange_close(frames)
-        monkeypatch.setenv('MELF_FUSED_EARLY', '1')
-        if grid:
-            monkeypatch.setenv('MELF_FUSED_GRID', str(grid))
-        for rep in range(2):
-            got = ctx.hls_inrange_close(frames)
-            assert np.array_equal(got, ref), (n, H, W, rep, np.argwhere(got != ref)[:5])
-        for f in range(min(n, 3)):
-            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
-
-
-@pytest.mark.parametrize('config', [8, 9, 10])
-def test_fused_mask_small_table_launch_shapes(env, monkeypatch, config):
-    """MELF_FUSED_CONFIG=8 / 9 / 10 (round 5): 8 or 16 copies of every interval-table row instead of 32 (16 / 32 KiB of LDS), eight
-    256-thread or four 512-thread workgroups per CU.  Same masks as the oracle and the default launch: aligned, narrow, 1080p and a
-    full-size batch (every workgroup several passes, several segments per workgroup)."""
-    from oracle import pyoracle as po
-    ctx = env['sample-images1']['reader'].ctx
-    p = ctx.params
-    rng = np.random.default_rng(800 + config)
-    for (n, H, W) in ((2, 640, 480), (1, 1080, 1920), (3, 50, 64), (5, 101, 48), (64, 480, 640)):
-        frames = _blobby(rng, n, H, W)
-        monkeypatch.delenv('MELF_FUSED_CONFIG', raising=False)
-        ref = ctx.hls_inrange_close(frames)
-        monkeypatch.setenv('MELF_FUSED_CONFIG', str(config))     # read by the library at every fused launch
-        got = ctx.hls_inrange_close(frames)
-        assert np.array_equal(got, ref), (n, H, W, np.argwhere(got != ref)[:5])
-        for f in range(min(n, 2)):
-            assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
-
-
-def test_fused_mask_lds_dma_launch_shape(env, monkeypatch):
-    """MELF_FUSED_CONFIG=6 (round 4's experiment: pixel rows through LDS-DMA into two staging buffers, one workgroup per CU)
-    must stay what it is measured as: the same masks as the oracle's, on an aligned and on a narrow shape and at 1080p."""
-    from meterelf_amd import MeterReader
-    from oracle import pyoracle as po
-    monkeypatch.setenv('MELF_FUSED_CONFIG', '6')     # read by the library at every fused launch
-    rng = np.random.default_rng(66)
-    reader = MeterReader(env['sample-images1']['params'])
-    try:
-        p = reader.ctx.params
-        for (n, H, W) in ((2, 640, 480), (1, 1080, 1920), (3, 50, 64)):
-            frames = _blobby(rng, n, H, W)
-            got = reader.ctx.hls_inrange_close(frames)
-            for f in range(n):
-                assert np.array_equal(got[f], po.hls_inrange_close(frames[f], p.hue_shift, list(p.needle_lo), list(p.needle_hi))), (H, W, f)
-    finally:
-        reader.close()
-
-
 def test_fused_mask_on_fixture_frames(env):
     from meterelf_amd._image import imread_bgr
     from oracle import pyoracle as po

@@ -26,12 +26,24 @@ HEADER = os.path.join(ROOT, 'include', 'meterelf_hip.h')
 def test_library_exports_every_declared_symbol():
     with open(HEADER) as fp:
         text = re.sub(r'/\*.*?\*/', '', fp.read(), flags=re.S)
+    # the `#ifdef MELF_DIAG` part of the header belongs to the diagnostic build (make diag): the product library must NOT export it
+    diag_text = ''.join(re.findall(r'#ifdef MELF_DIAG(.*?)#endif', text, flags=re.S))
+    diag_declared = sorted(set(re.findall(r'\b(melf_[a-z0-9_]+)\s*\(', diag_text)))
+    text = re.sub(r'#ifdef MELF_DIAG.*?#endif', '', text, flags=re.S)
     declared = sorted(set(re.findall(r'\b(melf_[a-z0-9_]+)\s*\(', text)))
     assert len(declared) >= 20
     L = _hip.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert sorted(_hip.EXPORTS) == declared
+    assert sorted(_hip.EXPORTS) == declared and sorted(_hip.DIAG_EXPORTS) == diag_declared
+    if 'MELF_LIB_PATH' not in os.environ:
+        for name in diag_declared:
+            assert not hasattr(L, name), name
+        # ... and nothing else either: the dynamic symbol table is the header's list (plus nothing of the measurement scaffolding)
+        import subprocess
+        nm = subprocess.run(['nm', '-D', '--defined-only', _hip.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+        exported = sorted(ln.split()[-1] for ln in nm.splitlines() if ' T ' in ln and ln.split()[-1].startswith('melf_'))
+        assert exported == declared, sorted(set(exported) ^ set(declared))
     # constants the Python side mirrors from the header
     assert L.melf_jpeg_files_in_flight_max() == _hip.FILES_IN_FLIGHT_MAX == int(re.search(r'#define MELF_FILES_IN_FLIGHT_MAX (\d+)', text).group(1))
 

@@ -226,14 +226,14 @@ def _clean_scan_rule(s, rst_cap):
 
 @pytest.mark.gpu
 def test_scan_cleaner_kernel_against_the_sequential_rule():
-    """k_jpeg_clean alone (melf_debug_jpeg_clean) on byte strings no encoder would write: random bytes, strings made of nothing
+    """k_jpeg_clean alone (melf_jpeg_clean_segment) on byte strings no encoder would write: random bytes, strings made of nothing
     but FF / 00 / D0..D7 / others, mostly-legal streams with stuffing, fill runs and markers at every alignment, lengths around
     the 16-byte thread windows and the 16 KiB rounds, empty input, markers beyond the table's capacity.  Clean bytes, clean
     length, restart table and count equal the sequential rule's; the region behind the clean bytes is zero."""
     import ctypes as C
     from meterelf_amd import _hip
     L = _hip.lib()
-    L.melf_debug_jpeg_clean.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
+    L.melf_jpeg_clean_segment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
     rng = np.random.default_rng(20260410)
     lengths = [0, 1, 2, 15, 16, 17, 31, 33, 255, 1000, 4095, 4097, 16383, 16384, 16385, 16400, 32768, 32769, 50000] + \
         [int(v) for v in rng.integers(1, 70000, 40)]
@@ -259,7 +259,7 @@ def test_scan_cleaner_kernel_against_the_sequential_rule():
         out_len = C.c_int32(-1)
         rst = np.full(expected + 1, 0xFFFFFFFF, np.uint32)
         rst_cnt = C.c_int32(-1)
-        rc = L.melf_debug_jpeg_clean(s, n, expected, out.ctypes.data_as(C.c_void_p), C.byref(out_len), rst.ctypes.data_as(C.c_void_p), C.byref(rst_cnt))
+        rc = L.melf_jpeg_clean_segment(s, n, expected, out.ctypes.data_as(C.c_void_p), C.byref(out_len), rst.ctypes.data_as(C.c_void_p), C.byref(rst_cnt))
         assert rc == 0
         (ref, ref_rst, found) = _clean_scan_rule(s, expected + 1)
         assert out_len.value == len(ref), (trial, n, kind, out_len.value, len(ref))
@@ -814,14 +814,24 @@ def test_exif_oriented_file_takes_the_host_branch(tmp_path):
         reader.close()
 
 
+def _one_piece(ctx, batch, H, W):
+    """The reference for the pipelined calls: the same files in calls of at most 64, which take the library's one-piece path
+    (one upload, one launch per stage, no chunk ring) -- what production does for a short list."""
+    (recs, stats) = ([], [])
+    for i in range(0, len(batch), 64):
+        (r, st) = ctx.jpeg_process_batch(batch[i:i + 64], H, W)
+        recs.append(r)
+        stats.append(st)
+    return (np.concatenate(recs), np.concatenate(stats))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize('chunk,read,parse', [('', 'whole', ''), ('512', 'whole', 'all'), ('96', 'whole', ''), ('200', 'chunk', ''),
-                                              ('64,300,128', 'chunk', 'all'), ('40,260', 'whole', '')])
-def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read, parse):
+@pytest.mark.parametrize('chunk', ['', '512', '96', '200', '64,300,128', '40,260'])
+def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk):
     """melf_jpeg_process_batch decodes in chunks on a ring of streams while the host prepares the next chunk: same
-    records and per-file status as the one-piece path (MELF_JPEG_SERIAL), with a corrupt file, a file of another size,
-    a progressive file and a greyscale file spread over different chunks, and when called twice in a row -- at the default
-    chunk size, at other sizes, with an uneven plan, with the headers parsed per chunk (default) and all up front."""
+    records and per-file status as the one-piece path (the same files in calls of <= 64), with a corrupt file, a file of another
+    size, a progressive file and a greyscale file spread over different chunks, and when called twice in a row -- at the default
+    chunk size, at other sizes (MELF_JPEG_CHUNK), with an uneven plan."""
     rng = np.random.default_rng(77)
     good = [open(f, 'rb').read() for f in _files('sample-images1')]
     from meterelf_amd import _hip
@@ -832,14 +842,9 @@ def test_pipelined_chunks_equal_the_one_piece_call(ctx, monkeypatch, chunk, read
     batch[300] = _encode(_natural_image(rng, 48, 64))                         # another size
     batch[301] = _encode(_natural_image(rng, H, W), progressive=True)         # unsupported
     batch[650] = _encode(_natural_image(rng, H, W)[..., 0])                   # greyscale, right size
-    monkeypatch.setenv('MELF_JPEG_SERIAL', '1')
-    (ref, rstat) = ctx.jpeg_process_batch(batch, H, W)
-    monkeypatch.delenv('MELF_JPEG_SERIAL')
+    (ref, rstat) = _one_piece(ctx, batch, H, W)
     if chunk:
         monkeypatch.setenv('MELF_JPEG_CHUNK', chunk)
-    if parse:
-        monkeypatch.setenv('MELF_JPEG_PARSE', parse)
-    monkeypatch.setenv('MELF_JPEG_READ', read)
     for _ in range(2):
         (got, gstat) = ctx.jpeg_process_batch(batch, H, W)
         assert np.array_equal(gstat, rstat)
@@ -867,16 +872,12 @@ def test_flat_frames_are_scheduled_first_and_come_back_in_place(ctx, monkeypatch
     for (k, i) in enumerate(where):
         batch[i] = flat[k % 3]
     batch[7 if 7 not in where else 8] = good[0][:len(good[0]) // 3]  # a corrupt one among them
-    monkeypatch.setenv('MELF_JPEG_SERIAL', '1')
-    (ref, rstat) = ctx.jpeg_process_batch(batch, H, W)
-    monkeypatch.delenv('MELF_JPEG_SERIAL')
+    (ref, rstat) = _one_piece(ctx, batch, H, W)
     monkeypatch.setenv('MELF_JPEG_CHUNK', '128')
     (got, gstat) = ctx.jpeg_process_batch(batch, H, W)
-    monkeypatch.setenv('MELF_JPEG_NO_REORDER', '1')
-    (got2, gstat2) = ctx.jpeg_process_batch(batch, H, W)
-    assert np.array_equal(gstat, rstat) and np.array_equal(gstat2, rstat)
+    assert np.array_equal(gstat, rstat)
     ok = rstat == 0
-    assert ok.sum() == 299 and got[ok].tobytes() == ref[ok].tobytes() and got2[ok].tobytes() == ref[ok].tobytes()
+    assert ok.sum() == 299 and got[ok].tobytes() == ref[ok].tobytes()
     assert (ref['status'][where] != _hip.FRAME_OK).all()  # a flat frame has no dials
 
 

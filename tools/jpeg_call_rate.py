@@ -10,6 +10,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the reading-path / header-parse arrangements (second and third field of a plan) are switches of the DIAGNOSTIC build
+os.environ.setdefault('MELF_LIB_PATH', os.path.join(ROOT, 'meterelf_amd', 'csrc', 'libmeterelf_hip_diag.so'))
 import numpy as np
 
 from meterelf_amd import MeterReader, _hip, _params
