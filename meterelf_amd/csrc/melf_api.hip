@@ -1201,6 +1201,7 @@ static int process_batch_on(melf_ctx* c, const void* d_frames, int n, int H, int
             MatchSrc ms;
             ms.base = base; ms.frame_stride = frame_stride; ms.row_stride = row_stride;
             ms.x0 = x0; ms.y0 = y0; ms.rows = crows; ms.cols = ccols;
+            ms.readable = (size_t)(m - 1) * frame_stride + (size_t)H * row_stride;
             int nparts = 0;
             MatchPartial* parts = nullptr;
             if (int rc = run_match(c, ms, true, m, bl, ls, nullptr, &parts, &nparts)) return rc;
@@ -1478,6 +1479,7 @@ extern "C" int melf_match_ccoeff(melf_ctx* c, const uint8_t* images_host, int n,
     MatchSrc ms;
     ms.base = c->d_stage_in; ms.frame_stride = (size_t)rows * cols; ms.row_stride = cols;
     ms.x0 = 0; ms.y0 = 0; ms.rows = rows; ms.cols = cols;
+    ms.readable = (size_t)n * rows * cols;
     int nparts = 0;
     MatchPartial* d_parts = nullptr;
     if (int rc = run_match(c, ms, false, n, 0, c->stream, result_map ? (float*)c->d_stage_out : nullptr, &d_parts, &nparts)) return rc;

@@ -49,6 +49,7 @@ struct MatchSrc {
     int row_stride;       // bytes between rows
     int x0, y0;           // origin of the searched image inside the frame (pixels)
     int rows, cols;       // searched image size
+    size_t readable;      // bytes from `base` the caller guarantees readable: (images - 1) * frame_stride + the last image's rows
 };
 
 void launch_match(const MatchSrc& src, bool from_bgr, int n, const MatchGeom& g, const uint32_t* d_tplT,
