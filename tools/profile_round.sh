@@ -10,7 +10,7 @@
 #       config5  fused mask, 1080p, B=512
 #       jpeg     1024 fixture files
 #     -> traffic.json: bytes per launch for bench.py, stamped with the hash of the kernel sources they were measured on
-#  2. rocprofv3 --kernel-trace --stats of the default bench command minus its two_streams blocks (`--skip twostream`:
+#  2. rocprofv3 --kernel-trace --stats of the bench command on one lane and without its two_streams blocks (`--skip twostream --no-resident-hint`:
 #     launches that share the chip with another stream's kernels have stretched durations and would blur the per-kernel
 #     averages the roofline lines are checked against) -> bench_kernel_stats.csv + the JSON line of that run
 #  3. one --kernel-trace --stats run PER WORKLOAD whose roofline the line quotes, so that every roofline.frac can be
@@ -45,6 +45,11 @@ valu() {  # name, command...
 }
 valu config3 python3 tools/run_stage.py full --iters 8
 valu config4 python3 tools/run_stage.py full --iters 8 --sample-dir sample-images2
+# k_match_mfma's matrix pipe (round 6: after the sparse pairing): matrix instructions issued, cycles the pipe was busy, wave lifetime
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv \
+    --kernel-include-regex 'k_match_mfma' -d /tmp/prof/mfma_busy -- python3 tools/run_stage.py full --iters 8 > /dev/null 2>&1 || true
+python3 tools/pmc_summary.py /tmp/prof/mfma_busy > $OUT/pmc_match_mfma_busy.txt || true
+echo "mfma busy done" >> $OUT/progress.txt
 pmc config2 python3 tools/run_stage.py fused --iters 8
 pmc config5 python3 tools/run_stage.py fused --iters 4 --hw 1080x1920 --batch 512 --nbuf 1
 pmc jpeg python3 tools/jpeg_timing.py sample-images1 1024
@@ -106,7 +111,8 @@ stats() {  # name, command...
   echo "$*" > $OUT/${name}_command.txt
   echo "stats $name done" >> $OUT/progress.txt
 }
-stats bench python3 bench.py --skip twostream
+# (--no-resident-hint: every timed region on ONE caller stream, so that no launch of the trace shares the chip with another lane's kernels)
+stats bench python3 bench.py --skip twostream --no-resident-hint
 mv $OUT/bench_kernel_stats_bench.csv $OUT/bench_kernel_stats.csv
 mv $OUT/bench_stdout.txt $OUT/bench_under_rocprof.json; mv $OUT/bench_stderr.txt $OUT/bench_under_rocprof.err
 stats config2 python3 tools/run_stage.py fused --iters 60 --hw 640x480 --batch 256 --nbuf 4 --profiling 0
