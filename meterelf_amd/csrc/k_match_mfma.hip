@@ -386,6 +386,10 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
     else if constexpr ((NM) >= 4) { MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) MELF_SGB(1, 2) } \
     else { MELF_SGB(1, 4) MELF_SGB(1, 4) }
 #define MELF_FENCE __builtin_amdgcn_sched_barrier(0);
+#define MELF_LOAD1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one matrix instruction, one vector-memory read
+#define MELF_LOADS1 MELF_LOAD1
+#define MELF_LOADS2 MELF_LOAD1 MELF_LOAD1
+#define MELF_LOADS3 MELF_LOAD1 MELF_LOAD1 MELF_LOAD1
     for (int phase = 0; phase < 2; ++phase) {
         const int ibeg = phase == 0 ? istart : i_lo, iend = phase == 0 ? i_hi : istart;
         if (ibeg >= iend) continue;
@@ -425,56 +429,62 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
                     // Toeplitz blocks (d = 0: columns k >= m only; d = 6: k <= m - 5 only) share ONE 2:4-sparse instruction over the
                     // paired operand P_xb = image blocks (xb, xb + 6); d = 1 of block 0 sits in the low positions of P1 and d = 5 of
                     // block 1 in the high positions of P0 (sparse instructions with fixed positions); the rest is dense.
+                    // Eight regions (one template fragment each).  A region's loads -- the fragment the region before has finished with,
+                    // for the next template row; the incoming image row's pieces whose registers the oldest row has just released; the
+                    // next piece of row-window sums -- are issued ONE AFTER EACH of the region's first matrix instructions
+                    // (sched_group_barrier): a 1 KiB load takes the wave's issue port for about half a matrix instruction's 32 cycles,
+                    // so one per instruction is free while two or three in a row let the pipe run dry (round 5 issued them in
+                    // clusters between the regions: ~300 idle cycles per template row, tools/match_clock.py).
+                    const unsigned rowinp = rowin - ROWB, anc = (unsigned)i * AROWB;
+                    const int incp = (s + NBUF - 2) % NBUF;   // the row that came in during the step before (its last piece is fetched here)
                     // -- q0: the pair, both column blocks
                     MELF_FENCE
+                    ad[4] = LD(rsA, anc, 5);                   // d = 5 of THIS template row (its registers were last read at the end of the step before)
+                    kd[incp][3] = LD(rsL, rowinp, 7);
 #pragma unroll
                     for (int r = 0; r < R; ++r) { SP(r, 0, a06, pp[CUR(r)][0], idxP); SP(r, 1, a06, pp[CUR(r)][1], idxP); }
                     ws_add(0);
-                    MELF_SPREAD(NM2)
+                    MELF_LOADS2 MELF_SPREAD(NM2 - 2)
+                    // -- q1: d = 5 of column block 1 (image block 6 = high half of P0)
                     MELF_FENCE
                     a06 = LD(rsA, an, 0);
-                    // -- q1: d = 5 of column block 1 (image block 6 = high half of P0)
                     rwv[0] = LD(rsR, rwn, 0);
-                    MELF_FENCE
 #pragma unroll
                     for (int r = 0; r < R; ++r) SP(r, 1, a5s, pp[CUR(r)][0], idxHi);
+                    MELF_LOADS2
+                    // -- q2: d = 1 of column block 0 (image block 1 = low half of P1); the oldest row's P0 is free
                     MELF_FENCE
                     a5s = LD(rsA, an, 7);
-                    // -- q2: d = 1 of column block 0 (image block 1 = low half of P1); the oldest row's P0 is free
                     load_pp(pp[inc][0], rowin, 0);
-                    MELF_FENCE
 #pragma unroll
                     for (int r = 0; r < R; ++r) SP(r, 0, a1s, pp[CUR(r)][1], idxLo);
+                    MELF_LOADS3
+                    // -- q3: d = 1 of column block 1 (image block 2)
                     MELF_FENCE
                     a1s = LD(rsA, an, 6);
-                    // -- q3: d = 1 of column block 1 (image block 2)
                     load_pp(pp[inc][1], rowin, 2);
-                    MELF_FENCE
 #pragma unroll
                     for (int r = 0; r < R; ++r) DN(r, 1, ad[0], kd[CUR(r)][0]);
-                    MELF_FENCE
-                    ad[0] = LD(rsA, an, 1);
+                    MELF_LOADS3
                     // -- q4 .. q6: d = 2, 3, 4 of block 0 with d = 2, 3, 4 of block 1
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        if (q >= 1) { kd[inc][q - 1] = LD(rsL, rowin, 4 + q - 1); rwv[q] = LD(rsR, rwn, q); }
                         MELF_FENCE
+                        ad[q] = LD(rsA, an, 1 + q);
+                        if (q >= 1) { kd[inc][q - 1] = LD(rsL, rowin, 4 + q - 1); rwv[q] = LD(rsR, rwn, q); }
 #pragma unroll
                         for (int r = 0; r < R; ++r) { DN(r, 0, ad[1 + q], kd[CUR(r)][q]); DN(r, 1, ad[1 + q], kd[CUR(r)][q + 1]); }
                         ws_add(1 + q);
-                        MELF_SPREAD(NM2)
-                        MELF_FENCE
-                        ad[1 + q] = LD(rsA, an, 2 + q);
+                        if (q >= 1) { MELF_LOADS3 MELF_SPREAD(NM2 - 3) } else { MELF_LOADS1 MELF_SPREAD(NM2 - 1) }
                     }
                     // -- q7: d = 5 of column block 0 (image block 5)
+                    MELF_FENCE
+                    ad[3] = LD(rsA, an, 4);
                     kd[inc][2] = LD(rsL, rowin, 6);
                     rwv[3] = LD(rsR, rwn, 3);
-                    MELF_FENCE
 #pragma unroll
                     for (int r = 0; r < R; ++r) DN(r, 0, ad[4], kd[CUR(r)][3]);
-                    MELF_FENCE
-                    ad[4] = LD(rsA, an, 5);
-                    kd[inc][3] = LD(rsL, rowin, 7);
+                    MELF_LOADS3
                     MELF_FENCE
                 } else {
                     // one column block: the pair over P0 = image blocks (0, 6), then d = 1 .. 5 dense over blocks 1 .. 5
@@ -507,6 +517,10 @@ __device__ __forceinline__ void match_wave(const int8_t* __restrict__ Lg, const 
 #undef MELF_SGB
 #undef MELF_SPREAD
 #undef MELF_FENCE
+#undef MELF_LOAD1
+#undef MELF_LOADS1
+#undef MELF_LOADS2
+#undef MELF_LOADS3
 
 #ifdef MELF_MATCH_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_match_loop_end[blockIdx.x] = __builtin_amdgcn_s_memtime();
