@@ -16,10 +16,10 @@ scaling); the only collectives are set-up ones (RCCL broadcast of the calibratio
 Objects on the line besides the contract's fields:
   roofline       dominant kernel of the step (k_match), timed by the dispatch's own start/stop stamps
                  (hipExtLaunchKernelGGL) on the stream it runs on, over the timed region
-  single_lane    the same K steps on ONE caller stream (every kernel behind the previous one): the launches roofline / kernel_ms
-                 describe; the timed region itself alternates the steps between two caller streams (the context's two lanes)
+  single_lane    the same K steps on ONE caller stream without the hint (every kernel behind the previous one): the launches roofline /
+                 kernel_ms describe; the timed region itself runs on the context's two lanes (--mode resident | two_streams)
   sustained      >= 2 s of back-to-back steps (DVFS-settled rate), and the same length on one lane with k_match's stamps
-  two_streams    ~1 s of the timed mode (steps alternating between two caller streams)
+  two_streams    ~1 s of the steps alternating between two caller streams
   resident_hint  ~1 s on ONE caller stream with melf_ctx_set_frames_resident (the library alternates its lanes per call)
   cpu_baseline   the CPU oracle (restated port) on a bounded sample of the same frames; doubles as parity gate
   fused_mask     BASELINE config 2 (B=256, fused HLS+inRange+closing) rotating over 4 buffer pairs, HBM roofline
@@ -368,10 +368,10 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
       1. every kernel bracketed by events, one lane (informational per-kernel times: kernel_ms);
       2. `steps` steps on ONE lane with the dispatch's own stamps on k_match: the undisturbed launches `roofline` describes, and
          the step as the plain sum of its kernels (single_lane);
-      3. the contract's timed region the way a throughput caller with frames in HBM drives the library: the same calls alternating
-         between TWO caller streams (include/meterelf_hip.h: the context hands each stream one of its two lanes), so that a step's
-         prep / dials kernels fill the other step's launch gaps and the tail of its match kernel; no event records, no stamps, nothing
-         between the streams until the end of the region.  Same records, byte for byte (checked).
+      3. the contract's timed region the way a throughput caller with frames in HBM drives the library: the same calls with
+         melf_ctx_set_frames_resident on one caller stream (--mode resident, the default: the library alternates its two lanes, a
+         call's prep and match kernels start beside the previous call's dials kernel) or alternating between TWO caller streams
+         (--mode two_streams: the context hands each stream a lane); no event records, no stamps.  Same records, byte for byte (checked).
     Then optional sustained / two-caller-stream runs and the CPU-oracle sample.  Returns a dict of raw results."""
     from meterelf_amd import _hip
     torch = env.torch
@@ -409,7 +409,9 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     (elapsed1_max, _p1) = max_over_ranks(env, elapsed1)
     # 3. the timed region
     ctx.set_profiling(0)
-    ns_timed = 2 if (two_lanes and ns == 1) else ns
+    resident = two_lanes and ns == 1 and env.args.mode == 'resident'
+    ns_timed = 2 if (two_lanes and ns == 1 and not resident) else ns
+    ctx.set_frames_resident(resident)
     run(max(preheat, warmup, 2), ns_timed)
     (elapsed, recs) = run(steps, ns_timed)
     (elapsed_max, per_rank) = max_over_ranks(env, elapsed)
@@ -418,7 +420,8 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     out = {'ctx': ctx, 'P': P, 'H': H, 'W': W, 'frames': frames, 'recs': recs, 'elapsed': elapsed_max,
            'per_rank_ms': [round(t / steps * 1e3, 4) for t in per_rank], 'kt': kt, 'kt_all': kt_all,
            'roofline': match_roofline(P, H, W, kt, B * steps, traffic.get(label + ':k_match'))}
-    out['mode'] = ('one melf_process_batch_dev call per step, consecutive steps on %d caller stream(s)%s'
+    out['mode'] = ('one melf_process_batch_dev call per step on one caller stream with melf_ctx_set_frames_resident (the library alternates its two lanes)' if resident else
+                   'one melf_process_batch_dev call per step, consecutive steps on %d caller stream(s)%s'
                    % (ns_timed, ' (the context runs them on its two lanes)' if ns_timed > 1 else ''))
     out['single_lane'] = {'ms_per_step': round(elapsed1_max / steps * 1e3, 4), 'frames_per_s': round(env.world * B * steps / elapsed1_max, 1), 'steps': steps,
                           'what': 'the same K steps as K melf_process_batch_dev calls on one stream: every kernel behind the previous one (the '
@@ -432,6 +435,7 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
         est = max(elapsed / steps, 1e-5)
         k = int(sustained_s / est * 1.15) + nbuf
         (el, _r) = run(k, ns_timed)
+        ctx.set_frames_resident(False)
         (el_max, _p) = max_over_ranks(env, el)
         out['sustained'] = {'seconds': round(el_max, 3), 'steps': k, 'ms_per_step': round(el_max / k * 1e3, 4),
                             'frames_per_s': round(env.world * B * k / el_max, 1)}
@@ -444,8 +448,9 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
         (el1_max, _p) = max_over_ranks(env, el1)
         r = match_roofline(P, H, W, kts, B * k, (None, None))
         out['sustained'].update({'single_lane_ms_per_step': round(el1_max / k * 1e3, 4), 'k_match_avg_launch_ms': r['avg_launch_ms'], 'k_match_frac': r['frac']})
+    ctx.set_frames_resident(False)
     if two_stream_s > 0 and ns == 1:
-        # ~1 s of the timed mode (two caller streams) ...
+        # ~1 s of the steps alternating between two caller streams ...
         est = max(elapsed / steps, 1e-5)
         k = int(two_stream_s / est * 1.2) + nbuf
         run(max(4, nbuf), 2)
@@ -749,8 +754,11 @@ def config5_block(env, cfg3_frames, steps, warmup, traffic):
     if env.args.no_resident_hint:
         (el, recs) = (el1, recs1)
     else:
-        timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, max(warmup, 4), nstreams=2)
-        (el, recs) = timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, steps, nstreams=2)
+        ns5 = 1 if env.args.mode == 'resident' else 2
+        ctx.set_frames_resident(ns5 == 1)
+        timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, max(warmup, 4), nstreams=ns5)
+        (el, recs) = timed_steps(env, ctx, frames, B5, 1, H5, W5, d_results, steps, nstreams=ns5)
+        ctx.set_frames_resident(False)
     (recs, recs1) = (recs[:B5], recs1[:B5])
     (el_max, _p) = max_over_ranks(env, el)
     P = ctx.params
@@ -950,6 +958,8 @@ def main():
     ap.add_argument('--no-resident-hint', action='store_true',
                     help='time the headline, config 4 and config 5 on ONE caller stream (every kernel behind the previous one) instead of '
                          'two; the single_lane objects carry that figure either way')
+    ap.add_argument('--mode', default='resident', choices=['two_streams', 'resident'], help='how the timed regions drive the two lanes: consecutive steps on two caller '
+                    'streams, or one caller stream with melf_ctx_set_frames_resident')
     ap.add_argument('--preheat', type=int, default=300, help='untimed steps run immediately before the timed region (clock settling)')
     ap.add_argument('--skip', default='', help='comma list of blocks to skip: ' + ','.join(ALL_BLOCKS))
     ap.add_argument('--only', default='', help='comma list of extra blocks to run (default: all)')

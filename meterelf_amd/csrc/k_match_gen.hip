@@ -356,12 +356,16 @@ __device__ __forceinline__ void gen_hform(const int8_t* __restrict__ Lg, const i
                 Lnext += rowb;
                 const int irow = i + PD < i_hi ? i + PD : g.th;  // scalar select, no branch
                 a[(s + PD) % NBUF] = ldfrag(rsA, lane16, (unsigned)(irow * g.nd + d) * 1024u);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int xb = 0; xb < NXB; ++xb)
                         acc[r][xb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s % NBUF], buf[(s + r) % NBUF][xb], acc[r][xb], 0, 0, 0);
+                // the step's NXB + 1 requests go out one after each of its first matrix instructions (a 1 KiB load takes the issue port
+                // for half a matrix instruction's time: one per instruction is free, a cluster in front of the step is not)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if constexpr (NXB == 2) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
