@@ -369,9 +369,10 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
       2. `steps` steps on ONE lane with the dispatch's own stamps on k_match: the undisturbed launches `roofline` describes, and
          the step as the plain sum of its kernels (single_lane);
       3. the contract's timed region the way a throughput caller with frames in HBM drives the library: the same calls with
-         melf_ctx_set_frames_resident on one caller stream (--mode resident, the default: the library alternates its two lanes, a
-         call's prep and match kernels start beside the previous call's dials kernel) or alternating between TWO caller streams
-         (--mode two_streams: the context hands each stream a lane); no event records, no stamps.  Same records, byte for byte (checked).
+         consecutive calls alternating between TWO caller streams (--mode two_streams, the default: the context hands each stream one
+         of its two lanes; nothing between the streams until the end of the region) or with melf_ctx_set_frames_resident on one caller
+         stream (--mode resident: the library alternates its lanes itself, three event hand-overs per call -- 1-2 % faster at config 3,
+         10-20 % slower at configs 4 and 5, whose kernels are short); no event records, no stamps.  Same records, byte for byte (checked).
     Then optional sustained / two-caller-stream runs and the CPU-oracle sample.  Returns a dict of raw results."""
     from meterelf_amd import _hip
     torch = env.torch
@@ -958,7 +959,7 @@ def main():
     ap.add_argument('--no-resident-hint', action='store_true',
                     help='time the headline, config 4 and config 5 on ONE caller stream (every kernel behind the previous one) instead of '
                          'two; the single_lane objects carry that figure either way')
-    ap.add_argument('--mode', default='resident', choices=['two_streams', 'resident'], help='how the timed regions drive the two lanes: consecutive steps on two caller '
+    ap.add_argument('--mode', default='two_streams', choices=['two_streams', 'resident'], help='how the timed regions drive the two lanes: consecutive steps on two caller '
                     'streams, or one caller stream with melf_ctx_set_frames_resident')
     ap.add_argument('--preheat', type=int, default=300, help='untimed steps run immediately before the timed region (clock settling)')
     ap.add_argument('--skip', default='', help='comma list of blocks to skip: ' + ','.join(ALL_BLOCKS))

@@ -63,8 +63,8 @@ typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 // pairs (k_match_mfma, round 6; 0 for the general kernel): the first `pairs` image blocks share their registers with blocks
 // 6 .. 6 + pairs - 1 as the B operand of a 2:4-sparse matrix instruction: P_p = blocks (p, p + 6), dword t of lane (n, h) =
 // {L'[32 p + 16 h + 2 t], L'[.. + 1], L'[32 (p + 6) + 16 h + 2 t], L'[.. + 1]}, dwords 0-3 in 1 KiB slot 2 p, dwords 4-7 in slot
-// 2 p + 1; the blocks in between follow in plain fragment order (slots 2 pairs ..).  The two threads of a pair swap the halves the
-// other one needs (lane shuffles) and interleave them with v_perm_b32; the row still leaves in coalesced 16-byte stores.
+// 2 p + 1; the blocks in between follow in plain fragment order (slots 2 pairs ..).  The interleave happens on the row's way out of LDS
+// (two 8-byte reads and four v_perm_b32 per 16-byte piece of a paired slot); the row still leaves in coalesced 16-byte stores.
 template <bool FROM_BGR>
 __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, int nkb, int rows_pad, int tw, int rwp, int pairs,
                                                      int8_t* __restrict__ Lg, uint16_t* __restrict__ R)
@@ -76,6 +76,11 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
     const int t = threadIdx.x, n = t >> 3, kl = t & 7;
     const int f = grp * 32 + n;
     int carry = 0;  // prefix of the blocks before this chunk (per frame, same in its 8 lanes)
+    // (wave-uniform, once) every 100-byte gather window of this row, in every frame of the group, ends inside the caller's buffer -- all
+    // rows but the last few of the last frame; the per-lane pointer test below then never runs (as the branch condition of every
+    // thread it cost 10 % of the kernel: profiles/r06/prep_bisect.txt)
+    const bool rows_safe = (size_t)min(grp * 32 + 31, nframes - 1) * src.frame_stride + (size_t)(src.y0 + y) * src.row_stride +
+                           (size_t)(src.x0 + 32 * (nkb - 1)) * 3 + 100 <= src.readable;
     u32x4m* out = (u32x4m*)(Lg + ((size_t)grp * rows_pad + y) * (size_t)nkb * 1024);
     for (int kc = 0; kc < nkb; kc += 8) {
         const int kb = kc + kl;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
                 const int mis = (int)((size_t)p & 3);
                 // 25 aligned dwords cover the 96 bytes of 32 pixels at any byte alignment; the window may
                 // reach past the crop (never used: masked) but must stay inside the caller's buffer
-                if (p + 100 <= src.base + src.readable) {
+                if (rows_safe || (size_t)f * src.frame_stride + (size_t)(src.y0 + y) * src.row_stride + o + 100 <= src.readable) {
                     const uint32_t* q = (const uint32_t*)(p - mis);
                     uint32_t d[25];
 #pragma unroll
@@ -125,41 +130,11 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
             }
         }
         if (kc) __syncthreads();  // the previous chunk's tile has been written out
-        // fragment-order image of the row
-        if (pairs == 0) {
+        // fragment-order image of the row (plain: the paired operands are put together when the row leaves, below)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
-                *(u32x4m*)(tile + ((kl * 2 + h) * 32 + n) * 4) = v;
-            }
-        } else {
-            // (uniform branch; nkb <= 8: one chunk)  role of this thread's block: low member p of a pair, high member p + 6, or plain
-            const bool lo = kl < pairs, hi = kl >= 6 && kl < 6 + pairs;
-            const int partner = lo ? kl + 6 : (hi ? kl - 6 : kl);
-            uint32_t got[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) got[q] = (uint32_t)__shfl((int)(lo ? w[4 + q] : w[q]), partner, 8);   // the low member hands over its h = 1 half, the high member its h = 0 half
-            if (lo || hi) {
-                // low member: lane half h = 0 of P (own columns 0..15 with the partner's); high member: h = 1 (the partner's columns 16..31 with its own)
-                const int h = hi ? 1 : 0, p = lo ? kl : kl - 6;
-                uint32_t o[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const uint32_t mine = w[4 * h + (t >> 1)], other = got[t >> 1];
-                    const uint32_t a = lo ? mine : other, b = lo ? other : mine;   // a = block p's pair of columns, b = block p + 6's
-                    o[t] = __builtin_amdgcn_perm(b, a, (t & 1) ? 0x07060302u : 0x05040100u);
-                }
-                u32x4m v0 = {o[0], o[1], o[2], o[3]}, v1 = {o[4], o[5], o[6], o[7]};
-                *(u32x4m*)(tile + (((2 * p) * 2 + h) * 32 + n) * 4) = v0;
-                *(u32x4m*)(tile + (((2 * p + 1) * 2 + h) * 32 + n) * 4) = v1;
-            } else if (kl < nkb) {
-                const int slot = kl + pairs;   // blocks pairs .. 5 -> slots 2 pairs ..
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
-                    *(u32x4m*)(tile + ((slot * 2 + h) * 32 + n) * 4) = v;
-                }
-            }
+        for (int h = 0; h < 2; ++h) {
+            u32x4m v = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
+            *(u32x4m*)(tile + ((kl * 2 + h) * 32 + n) * 4) = v;
         }
         // inclusive prefix sums of L' along the row: the block's total (four signed bytes per v_dot4), a scan of the totals over the
         // frame's 8 lanes, then the 32 running sums are produced and stored pair by pair (nothing but the running sum stays live)
@@ -187,7 +162,25 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
         }
         __syncthreads();
         const int nb = min(8, nkb - kc);
-        for (int i = t; i < nb * 64; i += 256) out[kc * 64 + i] = *(const u32x4m*)(tile + i * 4);
+        if (pairs == 0) {
+            for (int i = t; i < nb * 64; i += 256) out[kc * 64 + i] = *(const u32x4m*)(tile + i * 4);
+        } else {
+            // (nkb <= 8: one chunk)  output piece i = 1 KiB slot i >> 6, lane i & 63.  Slots 2 p, 2 p + 1: dwords 0-3 / 4-7 of P_p -- two
+            // dwords of block p's fragment and two of block p + 6's, interleaved by 16-bit pairs; slots 2 pairs ..: blocks pairs .. 5
+            for (int i = t; i < nb * 64; i += 256) {
+                const int slot = i >> 6, li = i & 63;
+                u32x4m v;
+                if (slot < 2 * pairs) {   // (uniform per wave)
+                    const int p = slot >> 1, hl = slot & 1;
+                    const uint2 lo2 = *(const uint2*)(tile + (p * 64 + li) * 4 + 2 * hl), hi2 = *(const uint2*)(tile + ((p + 6) * 64 + li) * 4 + 2 * hl);
+                    v.x = __builtin_amdgcn_perm(hi2.x, lo2.x, 0x05040100u); v.y = __builtin_amdgcn_perm(hi2.x, lo2.x, 0x07060302u);
+                    v.z = __builtin_amdgcn_perm(hi2.y, lo2.y, 0x05040100u); v.w = __builtin_amdgcn_perm(hi2.y, lo2.y, 0x07060302u);
+                } else {
+                    v = *(const u32x4m*)(tile + ((slot - pairs) * 64 + li) * 4);
+                }
+                out[i] = v;
+            }
+        }
     }
     // window sums: R[x] = P[x + tw - 1] - P[x - 1] + 128 tw   (P = inclusive prefix of L - 128, modulo 2^16:
     // the window sum itself is below 2^16 for tw <= 257)
