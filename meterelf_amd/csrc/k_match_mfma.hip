@@ -111,13 +111,9 @@ __global__ __launch_bounds__(256) void k_prep_lplane(MatchSrc src, int nframes, 
                         const int L = hls_lightness_fast(px & 255, (px >> 8) & 255, (px >> 16) & 255);
                         w[k >> 2] |= (uint32_t)((L - 128) & 255) << ((k & 3) * 8);
                     }
-                    if (npx < 32) {   // the row's last block: bytes beyond the image are padding (L' = 0)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int nb = min(max(npx - 4 * j, 0), 4);
-                            w[j] &= nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
-                        }
-                    }
+                    // (The last block's columns beyond the image keep whatever the gather found there -- pixels of the same frame.  No map
+                    // position inside the map reaches them: x + j <= cols - 1 for x < rw, and the window sums stop at column cols - 1 too;
+                    // the positions that do are thrown away by the match kernels.  Masking them cost 40 issue slots per wave and row.)
                 } else {  // last bytes of the frame buffer: byte loads
                     for (int k = 0; k < npx; ++k) {
                         const int L = hls_lightness(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
