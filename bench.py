@@ -695,7 +695,8 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
                'frac_of_hbm_peak': round(alg_bytes * n2 / t2 / 1e9 / HBM_PEAK_GBS, 4)}
     # What the part streams for this traffic mix: a bare persistent stream of the same mix and launch shape, measured in this run by
     # a child process on the DIAGNOSTIC build of the library (the product library does not carry measurement kernels)
-    ceiling = stream_ceiling_child(env, FB, H, W, nbuf, steps) if env.rank == 0 else None
+    # (single-GPU runs only: a multi-rank job does not start further GPU processes beside its ranks)
+    ceiling = stream_ceiling_child(env, FB, H, W, nbuf, steps) if (env.rank == 0 and env.world == 1) else None
     del masks
     return {
         'workload': 'B=%d %dx%d uniform-random u8 frames, fused HLS+inRange+closing only, %d distinct buffer pairs '
