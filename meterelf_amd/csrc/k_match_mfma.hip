@@ -696,7 +696,9 @@ __global__ __launch_bounds__(64 * KS, 1) void k_match_mfma(const int8_t* __restr
     // kernels lose: the prep kernel streams the next batch through the L2 this kernel keeps its image rows in (config 5, 512 frames:
     // 0.174 ms per step on two lanes against 0.154 on one; profiles/r06/overlap_*.txt).  Naming a high accumulator register makes
     // the allocation 456: nothing else fits, the other lane's kernels fill the SIMDs as the waves of this launch retire.
+#ifndef MELF_NO_SIMD_OWNER   // (experiments only: tools/corun_partner.py builds the kernel without it)
     if constexpr (NXB == 2 && RB >= 4) asm volatile("" ::: "a199");
+#endif
     if constexpr (KS > 1) {
         // room for the largest tile of the launch: (RB + 1)-row pair waves
         __shared__ __attribute__((aligned(16))) SliceLds<(NXB == 2 && RB < 5 ? RB + 1 : RB), NXB, KS> lds;
