@@ -272,8 +272,9 @@ def match_roofline(P, H, W, kt, frames_total, traffic_entry):
         'unit': 'TFLOP/s', 'frac': round(tops / I8_MFMA_PEAK_TOPS, 5), 'traffic': traffic, 'traffic_source': source,
         'avg_launch_ms': round(match_avg_ms, 4), 'launches': match_n,
         'algorithmic': '%d int MAC/frame x %d frames/launch, 2 ops per MAC' % (mac_per_frame, frames_per_launch),
-        'note': 'exact integer TM_CCOEFF on v_mfma_i32_32x32x32_i8; algorithmic MACs only (Toeplitz zero padding is not '
-                'counted), priced against the dense i8 MFMA peak.  The match kernels also add up the window sums of TM_CCOEFF '
+        'note': 'exact integer TM_CCOEFF on v_mfma_i32_32x32x32_i8 (+ one 2:4-sparse v_smfmac_i32_32x32x64_i8 per template row and '
+                'column block in the tuned kernel: the first and last Toeplitz blocks share it); algorithmic MACs only (Toeplitz zero '
+                'padding is not counted), priced against the DENSE i8 MFMA peak.  The match kernels also add up the window sums of TM_CCOEFF '
                 'themselves (k_match_mfma since round 3, k_match_gen since round 4; before, a separate column-sum launch of 8-15 us): '
                 'their launches are 5-10 us longer for that and the step 8-14 us shorter',
     }
