@@ -165,6 +165,15 @@ class Env:
         if self.dist is not None:
             self.dist.barrier()
 
+    def pinned_like(self, t):
+        """A pinned host buffer of t's size (kept per size: the records of a timed region land here)."""
+        key = int(t.numel())
+        if not hasattr(self, '_pinned'):
+            self._pinned = {}
+        if key not in self._pinned:
+            self._pinned[key] = self.torch.empty(key, dtype=self.torch.uint8, pin_memory=True)
+        return self._pinned[key]
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -208,12 +217,13 @@ def timed_steps(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=
                               stream=streams[i % len(streams)].cuda_stream)
     for so in streams[1:]:
         env.stream_obj.wait_stream(so)
+    host = env.pinned_like(d_results)   # (allocated once per size, outside every timed region)
     with torch.cuda.stream(env.stream_obj):
-        recs = d_results.cpu()          # D2H of the records: inside the timed region
+        host.copy_(d_results, non_blocking=True)   # D2H of the records into pinned memory: inside the timed region
     env.sync()
     env.barrier()
     elapsed = time.perf_counter() - t0
-    return elapsed, recs.numpy().view(_hip.RESULT_DTYPE)
+    return elapsed, host.numpy().copy().view(_hip.RESULT_DTYPE)
 
 
 def step_event_times(env, ctx, frames, B, nbuf, H, W, d_results, steps, frame_stride=None):
