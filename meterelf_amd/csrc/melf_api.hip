@@ -592,7 +592,6 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
         return fail(MELF_ERR_NO_DEVICE, "no HIP device: libmeterelf_hip has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(MELF_ERR_INVALID, "bad device index");
     HIP_TRY(hipSetDevice(device));
-    pool_note_device(device);   // the host pools share the cores out over the devices this process has contexts on
     std::vector<uint8_t> host;
     if (blob_on_device) {
         if (!blob || blob_bytes < sizeof(BlobHeader)) return fail(MELF_ERR_INVALID, "blob too small");
@@ -604,6 +603,7 @@ extern "C" int melf_ctx_create(int device, const void* blob, size_t blob_bytes, 
     if (int rc = blob_check(blob, blob_bytes, &h)) return rc;
     melf_ctx* c = new melf_ctx();
     c->device = device;
+    pool_note_device(device);   // the host pools share the cores out over the devices this process has LIVE contexts on (undone in melf_ctx_destroy)
     if (const char* e = getenv("MELF_FORCE_GENERIC_MASK")) c->force_generic_mask = e[0] == '1';
     c->P = h.params;
     const size_t n = (size_t)c->P.th * c->P.tw;
@@ -750,6 +750,7 @@ extern "C" int melf_ctx_create_bcast(const int* devices, int n, const void* blob
 extern "C" void melf_ctx_destroy(melf_ctx* c)
 {
     if (!c) return;
+    pool_forget_device(c->device);
     for (auto* j : c->files_jobs) { if (j->th.joinable()) j->th.join(); delete j; }
     c->files_jobs.clear();
     for (int a = 0; a < melf_ctx::NFJ; ++a) {

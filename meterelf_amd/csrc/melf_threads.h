@@ -16,9 +16,12 @@ namespace melf {
 
 class WorkerPool {
 public:
-    explicit WorkerPool(int nthreads) : pid_(getpid()), active_(nthreads)
+    // max_threads: the most workers the pool may ever have; they are STARTED when set_active first asks for them (ADVICE, round 5:
+    // a pool that starts them all has its sleeping surplus woken by every loop's notify_all, only to go back to sleep)
+    explicit WorkerPool(int max_threads, bool start_all = false) : pid_(getpid()), max_(max_threads < 0 ? 0 : max_threads), active_(0)
     {
-        for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this, t]() { loop(t); });
+        workers_.reserve((size_t)max_);
+        if (start_all) set_active(max_);
     }
     ~WorkerPool()
     {
@@ -33,7 +36,19 @@ public:
     // workers that take part in a loop (the others sleep through it): the pool is created with the most threads a device's
     // share of the cores can ever be and uses as many of them as that share is NOW (pool_of)
     int size() const { return active_.load(); }
-    void set_active(int n) { active_.store(n < 0 ? 0 : (n > (int)workers_.size() ? (int)workers_.size() : n)); }
+    void set_active(int n)
+    {
+        n = n < 0 ? 0 : (n > max_ ? max_ : n);
+        if (n > (int)started_.load() && getpid() == pid_) {
+            std::lock_guard<std::mutex> one_caller(run_m_);   // not while a loop is running: workers_ must not move under it
+            while ((int)workers_.size() < n) {
+                const int t = (int)workers_.size();
+                workers_.emplace_back([this, t]() { loop(t); });
+            }
+            started_.store((int)workers_.size());
+        }
+        active_.store(n > (int)started_.load() ? (int)started_.load() : n);
+    }
 
     // fn(i) for i in [0, n): indices are handed out in small blocks; the caller works too and returns when all are done.
     // fn must not throw: an exception on a worker would terminate the process, one on the caller would unwind past
@@ -96,7 +111,9 @@ private:
     std::condition_variable cv_, done_;
     const std::function<void(int)>* fn_ = nullptr;
     int n_ = 0, pending_ = 0, run_active_ = 0;
+    const int max_;
     std::atomic<int> active_;
+    std::atomic<int> started_{0};
     std::atomic<int> next_{0};
     uint64_t generation_ = 0;
     bool stop_ = false;
@@ -107,15 +124,21 @@ private:
 // deliberately never destroyed: a destructor that joins the workers would hang exit() in a forked child (the threads exist
 // in the parent only), and at process exit the threads go away with the process anyway.  The entry points set the calling
 // thread's device (pool_use_device) before their first parallel loop.  The cores this process may run on (its affinity
-// mask, not the machine's core count) are shared out over the devices the process has CONTEXTS on (pool_note_device, called
-// by melf_ctx_create) -- not over the visible devices: a one-GPU rank on an eight-GPU node keeps its whole share (round 4
+// mask, not the machine's core count) are shared out over the devices the process has LIVE contexts on (pool_note_device /
+// pool_forget_device, called by melf_ctx_create / melf_ctx_destroy) -- not over the visible devices: a one-GPU rank on an eight-GPU node keeps its whole share (round 4
 // divided by the visible devices: 2 I/O threads instead of 12 there).  The share is re-read at every loop, so a process
 // that opens its second device later narrows the first device's loops from then on.
 inline thread_local int tl_pool_device = 0;
-inline std::atomic<uint64_t> g_pool_device_mask{0};
+inline std::atomic<int> g_pool_ctx_count[64];   // contexts alive per device (melf_ctx_create / melf_ctx_destroy)
 inline void pool_use_device(int device) { tl_pool_device = device >= 0 ? device & 63 : 0; }
-inline void pool_note_device(int device) { g_pool_device_mask.fetch_or(1ull << (device & 63)); }
-inline int pool_devices() { const int n = __builtin_popcountll(g_pool_device_mask.load()); return n < 1 ? 1 : n; }
+inline void pool_note_device(int device) { g_pool_ctx_count[device & 63].fetch_add(1); }
+inline void pool_forget_device(int device) { if (g_pool_ctx_count[device & 63].load() > 0) g_pool_ctx_count[device & 63].fetch_sub(1); }
+inline int pool_devices()
+{
+    int n = 0;
+    for (int d = 0; d < 64; ++d) n += g_pool_ctx_count[d].load() > 0 ? 1 : 0;
+    return n < 1 ? 1 : n;
+}
 inline unsigned pool_cores()
 {
     // the cores this process may USE: its affinity mask, cut down to the container's CPU quota (cgroup v2 cpu.max, v1
@@ -145,7 +168,7 @@ inline WorkerPool& pool_of(WorkerPool** pools, std::mutex& m, const char* env, u
     std::lock_guard<std::mutex> lk(m);
     WorkerPool*& p = pools[tl_pool_device];
     const bool fixed = getenv(env) != nullptr;
-    if (!p) p = new WorkerPool(fixed ? std::max(0, atoi(getenv(env)) - 1) : (int)hi);
+    if (!p) p = fixed ? new WorkerPool(std::max(0, atoi(getenv(env)) - 1), true) : new WorkerPool((int)hi);
     if (!fixed) {
         const unsigned share = std::max<unsigned>(pool_cores(), 2u) / (unsigned)pool_devices();
         p->set_active((int)std::min<unsigned>(std::max<unsigned>(share, lo + 1u) - 1u, hi));
