@@ -734,17 +734,19 @@ bool mfma_match_ok(int th, int tw, int rows, int cols)
            (long)th * tw * 65025L < (1L << 32);
 }
 
-// Cost model of one wave, in shader cycles (measured on MI355X): ~33 cycles per MFMA in the
-// loop, ~11 cycles of matrix-pipe idle per 1 KiB fragment load issued between the MFMA groups, the epilogue
-// (double-precision post-pass, arg-max) ~2 400 cycles per half-row unit + ~1 200 per map row (its window sums slide in:
-// eight loads, 64 additions), priming ~4 000.
+// Cost model of one wave, in shader cycles (round 6; fitted to tools/match_clock.py and tools/match_sweep.py, profiles/r06/
+// match_sweep_round6.txt): 32 cycles per matrix instruction; what a 1 KiB operand load adds on top depends on how many matrix
+// instructions a region has to hide it behind -- 7 cycles for waves of four rows or more (one load per instruction is free), 17 for
+// three rows, 30 for two; the epilogue (double-precision post-pass, arg-max) ~1 300 cycles per half-row unit + ~300 per map row (its
+// window sums slide in), priming ~4 000.
 // K slices (ks > 1): a wave runs th_pad / ks template rows of the whole tile and the epilogue of 1 / ks of its units; the exchange
 // through LDS (zeroing, ~150 ds_add + as many reads, two barriers -- one of them waits for the tile's slowest slice) ~6 000.
 static double mm_wave_cycles(int R, int units, int nxb, int th_pad, int ks = 1)
 {
     const int nkb = MM_ND + nxb - 1;   // image-row fragments per step; + the template fragments + 4 pieces of the R row
     const int nf = nxb == 2 ? 8 : 6;   // template fragments per step; MM_ND - 1 matrix instructions per unit (the first and last Toeplitz blocks pair up)
-    return (double)(th_pad / ks) * ((double)units * (MM_ND - 1) * 33.0 + (double)(nkb + nf + 4) * 11.0) + (double)((units + ks - 1) / ks) * 2400.0 + 4000.0 + R * 1200.0 +
+    const double load = R >= 4 ? 7.0 : (R == 3 ? 17.0 : 30.0);
+    return (double)(th_pad / ks) * ((double)units * (MM_ND - 1) * 32.0 + (double)(nkb + nf + 4) * load) + (double)((units + ks - 1) / ks) * 1300.0 + 4000.0 + R * 300.0 +
            (ks > 1 ? 6000.0 : 0.0);
 }
 
@@ -756,8 +758,12 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
     p.nxb = p.rw > 32 ? 2 : 1;
     p.nkb = MM_ND + p.nxb - 1;
     p.groups = (nframes + 31) / 32;
-    // Layout search: RB full rows per wave (2..5), np pairs of (RB + 1)-row waves sharing their middle row.  The
-    // launch's time is (rounds of waves over the 1024 SIMDs) x (its longest wave); among equals the fewest pairs.
+    // Layout search: RB full rows per wave (2..5), np pairs of (RB + 1)-row waves sharing their middle row.  The chip is
+    // power-limited in this kernel: a launch takes the LONGER of (rounds of waves over the 1024 SIMDs) x (its longest
+    // wave at the clock a part-filled chip reaches) and (the cycles of ALL its waves) / 1024 at the clock the full chip holds -- 1.5
+    // times lower (2.2 against 1.46 GHz-equivalents in tools/match_sweep.py).  So fewer, larger tiles beat a layout that fills every
+    // SIMD with smaller ones: 4-row waves on 594-990 SIMDs for 576-992 frames (rounds 3-5 ran 2- and 3-row layouts there: 5-7 %
+    // slower).  Among equals the fewest pairs.
     const int simds = 1024;
     int force_rb = 0, force_np = -1, force_ks = 0;
     if (const char* e = getenv("MELF_MATCH_LAYOUT")) {  // experiments / tests: "rb,np[,ks]"; anything outside the family is ignored
@@ -774,17 +780,33 @@ MfmaPlan mfma_plan(int th, int tw, int rows, int cols, int nframes)
             if (force_rb && rb != force_rb) continue;
             if (ks > 1 && rb != 4) continue;   // K slices are instantiated for the 4-row tiles (the 1024-frame layout's operand reuse)
             const int np_max = (p.nxb == 2 && rb < 5) ? (p.rh + 2 * rb) / (2 * rb + 1) : 0;
+            auto waves_of = [&](int np) -> long {
+                const int rest = p.rh - (2 * rb + 1) * np;
+                return (long)((rest > 0 ? (rest + rb - 1) / rb : 0) + 2 * np) * p.groups * ks;
+            };
+            // candidates: no pairs, and the FEWEST pairs that reach the fewest rounds any number of pairs reaches
+            long rounds_min = LONG_MAX;
+            for (int np = 0; np <= np_max; ++np) rounds_min = std::min(rounds_min, (waves_of(np) + simds - 1) / simds);
+            int np_few = 0;
+            while (np_few < np_max && (waves_of(np_few) + simds - 1) / simds > rounds_min) ++np_few;
             for (int np = 0; np <= np_max; ++np) {
-                if (force_np >= 0 && np != std::min(force_np, np_max)) continue;
+                if (force_np >= 0) { if (np != std::min(force_np, np_max)) continue; }
+                else if (np != 0 && np != np_few) continue;
                 const int rest = p.rh - (2 * rb + 1) * np;
                 const int na = rest > 0 ? (rest + rb - 1) / rb : 0;
                 const long waves = (long)(na + 2 * np) * p.groups * ks;
                 const long rounds = (waves + simds - 1) / simds;
                 const int th_pad = mm_th_pad(th, rb, np > 0, ks);
                 const int upr = p.nxb;  // units per full row
-                const double longest = np > 0 ? mm_wave_cycles(rb + 1, upr * rb + 1, p.nxb, th_pad, ks) : mm_wave_cycles(rb, upr * rb, p.nxb, th_pad, ks);
-                const double cost = (double)rounds * longest;
-                if (!p.rb || cost < best * 0.995) {
+                const double w_full = mm_wave_cycles(rb, upr * rb, p.nxb, th_pad, ks), w_pair = mm_wave_cycles(rb + 1, upr * rb + 1, p.nxb, th_pad, ks);
+                const double longest = np > 0 ? w_pair : w_full;
+                const double total = (double)p.groups * ks * ((double)na * w_full + 2.0 * np * w_pair);
+                // full rounds run at the full chip's (power-limited) rate, a last part-filled round at the faster of its longest wave and its share
+                const double w_avg = total / (double)std::max<long>(waves, 1);
+                const long full = waves / simds, part = waves - full * simds;
+                const double cost = (double)full * 1.5 * w_avg + (part > 0 ? std::max(longest, 1.5 * (double)part * w_avg / simds) : 0.0);
+                (void)rounds;
+                if (!p.rb || cost < best * 0.98) {
                     best = cost;
                     p.rb = rb; p.na = na; p.np = np; p.th_pad = th_pad; p.ks = ks;
                 }

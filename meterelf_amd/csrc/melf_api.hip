@@ -871,7 +871,8 @@ static int default_match_kind(int th, int tw, int rows, int cols, int n)
         // tuned / general 42 / 40 us at 128 frames, 44 / 51 at 192, 56 / 66 at 256, 73 / 70 at 320, 86 / 93 at 448, 98 / 153 at 512
         const int rh = rows - th + 1, rw = cols - tw + 1, groups = (n + 31) / 32;
         const MfmaPlan pl = mfma_plan(th, tw, rows, cols, n);
-        const bool few_waves = (long)pl.nparts * pl.groups < 700;          // even in four K slices the tuned kernel leaves a third of the chip idle
+        // round 6 (profiles/r06/match_sweep_round6.txt): tuned / general 33 / 39 us at 128 frames (528 waves), 58 / 64 at 288, 61 / 67 at 320
+        const bool few_waves = (long)pl.nparts * pl.groups < 500;          // even in four K slices the tuned kernel leaves half of the chip idle
         const bool small_map = rh < 64 && (long)((rh + 4) / 5) * groups * 2 <= 512;   // a few rows: the general kernel's tile shapes fit them better
         const bool odd_cols = rw > 32 && rw % 32 >= 1 && rw % 32 <= 4;     // a whole column block for <= 4 columns
         if (!gen_ok || !(few_waves || small_map || odd_cols)) return MK_FAST;
