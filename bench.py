@@ -308,6 +308,27 @@ def dials_roofline(kernel_ms, traffic, label):
     return out
 
 
+def jpeg_roofline(jt, traffic):
+    """k_jpeg_huff, the kernel a JPEG call waits for, is bound by neither bytes nor arithmetic: a workgroup (one image) walks
+    9-17 synchronisation rounds of 70-100 dependent decode steps, most of them on one or two waves (k_jpeg.hip, J1).  What
+    can be said about it in roofline terms is how little of the vector units it uses; the chain itself is in the note."""
+    (ms, c) = jt.get('k_jpeg_huff', (0.0, 0))
+    out = {'kernel': 'k_jpeg_huff', 'bound': 'latency', 'launches_per_call': c, 'avg_launch_ms': round(ms / c, 4) if c else None,
+           'note': 'a dependency chain, not a throughput kernel: the state-only decode step is 43 instructions (one LDS lookup, the next '
+                   'stream dword requested a step ahead) and costs a lone wave ~415 cycles, ~650 with all eight waves of the workgroup; '
+                   'an image needs 8-17 rounds of 70-100 such steps after the speculative pass (profiles/r06/jpeg_huff_rounds.txt); '
+                   'six phase hypotheses in round 0 would not shorten the chain (model: profiles/r06/huff_hypotheses_model.txt)'}
+    v = traffic.valu_entry('jpeg:k_jpeg_huff') if traffic else None
+    if v:
+        out.update({'achieved': round(v['valu_busy_frac'], 4), 'peak': 1.0, 'unit': 'fraction of vector-unit cycles busy', 'frac': round(v['valu_busy_frac'], 4),
+                    'insts_valu_per_launch': v.get('insts_valu_per_launch'), 'waves': v.get('waves'), 'source': traffic.source,
+                    'traffic': traffic.get('jpeg:k_jpeg_huff')[0],
+                    'formula': '4 x SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)'})
+    else:
+        out.update({'achieved': None, 'frac': None, 'source': traffic.source if traffic else None})
+    return out
+
+
 def prep_roofline(P, H, W, kernel_ms, traffic, label, frames_per_launch):
     """k_prep_lplane is HBM-bound; priced on ALGORITHMIC bytes (SURVEY.md 8d's rule): per frame the meter_rect crop read once
     (3 B/px) + the L' plane written once in the match kernels' fragment order (1 B/px, rows padded to whole 32-column blocks) +
@@ -820,7 +841,7 @@ def hostfed_block(env, ctx, frames, B, H, W):
             'frames_read_ok': int((recs['status'] == 0).sum())}
 
 
-def jpeg_block(ctx, sample_dir, H, W):
+def jpeg_block(ctx, sample_dir, H, W, traffic=None):
     from meterelf_amd import _hip
     from meterelf_amd._image import imread_bgr
     jfiles = [f for f in sorted(glob.glob(os.path.join(GOLDEN, sample_dir, '*.jpg'))) if os.path.basename(f) not in REJECTED]
@@ -920,6 +941,7 @@ def jpeg_block(ctx, sample_dir, H, W):
                                                                       '(same host cores, same GPU: a functional figure, not a scaling one)'}},
             'kernel_ms_per_call': {k: round(ms, 4) for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
             'kernel_launches_per_call': {k: c for (k, (ms, c)) in jt.items() if c and k.startswith('k_jpeg')},
+            'roofline_jpeg': jpeg_roofline(jt, traffic),
             'decoded_frames_equal_libjpeg_turbo': same, 'files_ok': int((jstatus == 0).sum())}
 
 
@@ -1031,7 +1053,7 @@ def main():
     (hostfed, jpeg) = (None, None)
     if rank == 0:
         hostfed = hostfed_block(env, ctx, full['frames'], B, H, W) if 'hostfed' in blocks else None
-        jpeg = jpeg_block(ctx, args.sample_dir, H, W) if 'jpeg' in blocks else None
+        jpeg = jpeg_block(ctx, args.sample_dir, H, W, traffic) if 'jpeg' in blocks else None
     env.barrier()
 
     cfg5 = None

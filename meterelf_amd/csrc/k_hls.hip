@@ -920,37 +920,54 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     int seg_rows = (H + segs - 1) / segs;
     if (seg_rows < 32) seg_rows = H < 32 ? H : 32;
     segs = (H + seg_rows - 1) / seg_rows;
-    // Work queue (PD == 1 launches; MELF_FUSED_DYN = segments per workgroup aimed at, 0 = the static split; MELF_FUSED_GRID =
-    // workgroups, for tests that want many segments per workgroup on small inputs): segments of P whole passes including the
-    // 4 halo rows a segment loads beyond its own, so that no pass is half empty; used when it gives some workgroup a second
-    // segment, otherwise the static split above (one segment or none per workgroup either way)
-    // Measured (profiles/r05/fused_work_queue_ab.txt): no gain.  Config 2 0.0643-0.0668 ms against 0.0657-0.0662 for the static
-    // split, config 5 0.769-0.828 against 0.740-0.748: with one pass of register prefetch a workgroup that is alone on its CU
-    // still saturates its share of HBM, so the early finishers cost nothing, and the queue's segments pay their halo rows.
-    // The default stays the static split; MELF_FUSED_DYN=N switches the queue on (tests keep it honest).
-    const int dyn = (PF == 1 && REP == 32 && T == 1024) ? (diag_env("MELF_FUSED_DYN") ? atoi(diag_env("MELF_FUSED_DYN")) : 0) : 0;
-    const int grid_cap = diag_env("MELF_FUSED_GRID") ? std::max(1, atoi(diag_env("MELF_FUSED_GRID"))) : target;
+    // Work queue (the default launch shape: PD == 1, 1024 threads, full tables).  Round 6: the launch's time depends on WHERE its
+    // buffers lie -- +-6 % between allocations of one process, stable within one (tools/fused_alloc_probe.py), and the bare stream
+    // shows the same: each workgroup walking its own long run ("comb") is what the placement hurts, all workgroups taking small
+    // consecutive pieces from one counter (a compact front moving through memory) is not.  So a launch whose workgroups would each
+    // stream a long run hands out SMALL segments instead: P = 3 passes including the 4 halo rows (20 rows of a 1080p frame: the halo
+    // rows are hits in the memory-side cache, their neighbours are being read at the same time), at least ~96 KB of pixels.  On the
+    // same buffers (tools/fused_queue_ab.py, profiles/r06/fused_queue_ab_*.txt): 1080p B = 512 0.749-0.783 ms on every placement
+    // against 0.738-0.833 for the static split (mean -3.3 %, worst case -6 %, best case +2 %); coarser segments lose (the round-5
+    // A/Bs used 135-540 rows and compared separate processes, i.e. placements).  Short runs (B = 256 640 x 480: 240 rows per
+    // workgroup) measure the same either way and keep the static split.
+    // Diagnostic build: MELF_FUSED_DYN = 0 forces the static split, N > 0 aims at N segments per workgroup (MELF_FUSED_BIG = percent
+    // of a frame's rows dealt as one big static first segment per workgroup, MELF_FUSED_GRID = workgroups).
+    constexpr bool queue_shape = PF == 1 && REP == 32 && T == 1024;
+    int dyn = queue_shape ? -1 : 0;   // -1: the rule below
+    int grid_cap = target, big_pct = 0;
+#ifdef MELF_DIAG
+    if (queue_shape && diag_env("MELF_FUSED_DYN")) dyn = atoi(diag_env("MELF_FUSED_DYN"));
+    if (diag_env("MELF_FUSED_GRID")) grid_cap = std::max(1, atoi(diag_env("MELF_FUSED_GRID")));
+    if (diag_env("MELF_FUSED_BIG")) big_pct = std::min(95, std::max(0, atoi(diag_env("MELF_FUSED_BIG"))));
+#endif
     const int wgs = std::min(target, grid_cap);
-    // MELF_FUSED_BIG = percent of a frame's rows dealt as one big first segment per workgroup (the queue then hands out the rest
-    // in small ones: the halo rows of small segments are paid only where balancing needs them); 0 = small segments only
-    const int big_pct = diag_env("MELF_FUSED_BIG") ? std::min(95, std::max(0, atoi(diag_env("MELF_FUSED_BIG")))) : 0;
     uint32_t* wq = nullptr;
     int big_segs = 0, big_rows = 0;
-    if (dyn > 0) {
+    if (dyn != 0) {
         int Hs = H;   // rows dealt as small segments
-        if (big_pct > 0 && n > 0) {
+        if (dyn > 0 && big_pct > 0 && n > 0) {
             big_segs = (wgs + n - 1) / n;                                      // every workgroup's first segment is a big one
             int Pb = (int)(((double)H * big_pct / 100.0 / big_segs + 4.0) / RC + 0.5);
             big_rows = Pb * RC - 4;
             if (big_rows < RC || big_segs * big_rows > H - RC) { big_segs = 0; big_rows = 0; }
             else Hs = H - big_segs * big_rows;
         }
-        const double rows_aimed = (double)n * Hs / ((double)wgs * dyn);
-        int P = (int)((rows_aimed + 4.0) / RC + 0.5);
+        int P;
+        bool use = true;
+        if (dyn > 0) {
+            const double rows_aimed = (double)n * Hs / ((double)wgs * dyn);
+            P = (int)((rows_aimed + 4.0) / RC + 0.5);
+        } else {
+            // three passes, more for narrow frames (>= 96 KB of pixels per segment); only where a workgroup gets six or more such
+            // segments and the halo stays under a quarter of the rows
+            P = std::max(3, (int)((96.0 * 1024 / ((double)W * 3) + 4.0) / RC + 0.999));
+            const int own = P * RC - 4;
+            use = own >= 16 && (double)n * H / wgs >= 6.0 * own;
+        }
         if (P * RC - 4 < RC) P = (2 * RC + 3) / RC;                           // at least RC rows of its own
         const int dr0 = std::min(P * RC - 4, Hs), ds = (Hs + dr0 - 1) / dr0;
         const int dr = (Hs + ds - 1) / ds;                                     // evenly: no short last segment
-        if ((long)n * (ds + big_segs) > wgs) {
+        if (use && (long)n * (ds + big_segs) > wgs) {
             seg_rows = dr;
             segs = ds;
             static std::atomic<unsigned> slot{0};
@@ -977,23 +994,7 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // timing events (optional, set by the caller through fused_mask_timing_events): the dispatch's own start / stop stamps,
     // no event-record packets in the queue around the kernel
     const int ps = plain_store | ((diag_env("MELF_FUSED_PRIO") ? atoi(diag_env("MELF_FUSED_PRIO")) : 0) << 8);
-#ifdef MELF_DIAG   // work queue / early refill: experiments of round 5 (no gain: profiles/r05/fused_*_ab.txt), diagnostic build only
-    if constexpr (PF == 1 && REP == 32 && T == 1024) {   // the two experiments below are instantiated for the default launch shapes only
-        // early refill (round 5 experiment, MELF_FUSED_EARLY=1): measured no different from the refill at the start of the next
-        // pass (config 2 0.0668 / 0.0681 against 0.0664 ms, config 5 0.782 / 0.824 against 0.781 / 0.820: profiles/r05/
-        // fused_early_refill_ab.txt) -- the launch is not short of requests in flight.  Off by default.
-        const bool early = !wq && diag_env("MELF_FUSED_EARLY") && atoi(diag_env("MELF_FUSED_EARLY")) == 1;
-        if (early) {
-            static bool early_attr_set[64] = {false};
-            if (dev >= 0 && dev < 64 && !early_attr_set[dev]) {
-                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, REP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
-                early_attr_set[dev] = true;
-            }
-            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, REP, 2>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
-                                  n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
-            g_fused_ev_start = g_fused_ev_stop = nullptr;
-            return;
-        }
+    if constexpr (queue_shape) {
         if (wq) {
             static bool dyn_attr_set[64] = {false};
             if (dev >= 0 && dev < 64 && !dyn_attr_set[dev]) {
@@ -1005,10 +1006,23 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
             g_fused_ev_start = g_fused_ev_stop = nullptr;
             return;
         }
-    }
-#else
-    (void)wq; (void)big_segs; (void)big_rows;
+#ifdef MELF_DIAG
+        // early refill (round 5 experiment, MELF_FUSED_EARLY=1): measured no different from the refill at the start of the next
+        // pass (config 2 0.0668 / 0.0681 against 0.0664 ms, config 5 0.782 / 0.824 against 0.781 / 0.820: profiles/r05/
+        // fused_early_refill_ab.txt) -- the launch is not short of requests in flight.  Diagnostic build only.
+        if (diag_env("MELF_FUSED_EARLY") && atoi(diag_env("MELF_FUSED_EARLY")) == 1) {
+            static bool early_attr_set[64] = {false};
+            if (dev >= 0 && dev < 64 && !early_attr_set[dev]) {
+                (void)hipFuncSetAttribute((const void*)k_fused_mask_lut<V, T, PF, WPS, REP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 28 * 1024);
+                early_attr_set[dev] = true;
+            }
+            hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, REP, 2>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
+                                  n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
+            g_fused_ev_start = g_fused_ev_stop = nullptr;
+            return;
+        }
 #endif
+    }
     hipExtLaunchKernelGGL((k_fused_mask_lut<V, T, PF, WPS, REP>), dim3(grid), dim3(T), shmem, stream, g_fused_ev_start, g_fused_ev_stop, 0, d_frames,
                           n, H, W, hue_shift, B, d_tables, d_masks, segs, seg_rows, NB, ps, RC, (uint32_t*)nullptr, 0, 0);
     g_fused_ev_start = g_fused_ev_stop = nullptr;

@@ -1024,6 +1024,33 @@ def test_full_size_batch_properties(env, sd, seed):
     assert 0 in statuses and len(statuses) >= 2  # readable frames and at least one kind of failure in the batch
 
 
+@pytest.mark.parametrize('n,H,W', [(64, 1080, 1920), (480, 480, 640), (72, 1077, 1904)])
+def test_fused_mask_work_queue_launches(env, n, H, W):
+    """Launches whose workgroups would each stream a long run of rows take small segments from a work queue instead of the
+    static split (k_hls.hip, launch_lut_t: six or more segments of three passes per workgroup).  The same frames in
+    pieces small enough for the static split give the same masks, as does the oracle on a sample; every segment border
+    (20 or 71 rows apart) lies inside a frame, so a wrong halo shows up as a wrong row there."""
+    from oracle import pyoracle as po
+    ctx = env['sample-images1']['reader'].ctx
+    p = ctx.params
+    rng = np.random.default_rng(n + H)
+    tiles = _blobby(rng, 6, H, W)
+    frames = tiles[rng.integers(0, 6, n)]
+    for i in range(n):
+        frames[i] = np.roll(frames[i], (i * 13) % H, axis=0)
+    whole = ctx.hls_inrange_close(frames)
+    assert whole.shape == (n, H, W) and set(np.unique(whole).tolist()) <= {0, 255} and (whole > 0).any()
+    step = max(1, n // 16)
+    parts = np.concatenate([ctx.hls_inrange_close(frames[a:a + step]) for a in range(0, n, step)])
+    assert np.array_equal(parts, whole)
+    lo, hi = list(p.needle_lo), list(p.needle_hi)
+    for f in rng.choice(n, 3, replace=False):
+        exp = po.hls_inrange_close(frames[f], p.hue_shift, lo, hi)
+        assert np.array_equal(whole[f], exp), (f, np.argwhere(whole[f] != exp)[:5])
+    # a second launch right behind the first finds its queue slot zeroed again
+    assert np.array_equal(ctx.hls_inrange_close(frames), whole)
+
+
 def test_full_size_fused_mask_properties(env):
     """Config 2: B = 256 frames of 640 x 480 in one launch.  The mask of a frame does not depend on its neighbours in the
     batch (pieces, permutation), closing is idempotent on its own output's domain (mask pixels are 0 / 255 only), and

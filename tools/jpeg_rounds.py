@@ -32,11 +32,13 @@ else:
 assert (status == 0).all()
 st = np.zeros(n, np.uint32)
 assert L.melf_debug_jpeg_rounds(st.ctypes.data_as(C.c_void_p), n) == 0
-rounds = (st >> 16).astype(int)
+rounds = (st >> 16).astype(int)   # (of a chunked call: the last launch's images, the rest of the array is zero)
 redo = (st & 0xffff).astype(int)
-print('%s: %d files | rounds after the first pass: min %d median %d max %d | segments decoded again (%% of segments, summed over rounds): median %d max %d'
-      % (sd, n, rounds.min(), int(np.median(rounds)), rounds.max(), int(np.median(redo)), redo.max()))
-print('  histogram of rounds:', dict(zip(*np.unique(rounds, return_counts=True))))
+per_launch = 256 if (len(sys.argv) > 2 and sys.argv[2] == 'crop' and n > 256) else n   # the pipelined call's chunk size
+(rounds, redo) = (rounds[:per_launch], redo[:per_launch])
+print('%s: %d files, %d in the last launch | rounds after the first pass: min %d median %d max %d | segments decoded again (%% of segments, summed over rounds): median %d max %d'
+      % (sd, n, per_launch, rounds.min(), int(np.median(rounds)), rounds.max(), int(np.median(redo)), redo.max()))
+print('  histogram of rounds:', {int(k): int(v) for (k, v) in zip(*np.unique(rounds, return_counts=True))})
 
 n2 = min(n, 8192)
 stamps = np.zeros((n2, 8), np.uint64)
@@ -44,21 +46,23 @@ assert L.melf_debug_jpeg_stamps(stamps.ctypes.data_as(C.c_void_p), n2) == 0
 t = stamps[:, :7].astype(np.float64)
 names = ['zero window + tables', 'round 0 (speculative decode)', 'synchronisation rounds', 'prefix scan', 'output pass', 'DC prefix scan + fix-up']
 tot = t[:, 6] - t[:, 0]
-print('cycles per workgroup: median %.0f max %.0f' % (np.median(tot), tot.max()))
+# a chunked call (melf_jpeg_process_batch: 256 files per launch) leaves the stamps of its LAST launch only
+seen = tot > 0
+(t, tot) = (t[seen], tot[seen])
+seen_idx = np.nonzero(seen)[0]
+print('%d workgroups stamped (the call\'s last launch); cycles per workgroup: median %.0f max %.0f' % (len(tot), np.median(tot), tot.max()))
 for k in range(6):
     dlt = t[:, k + 1] - t[:, k]
     print('  %-30s median %8.0f (%4.1f %%)  max %8.0f' % (names[k], np.median(dlt), 100 * np.median(dlt) / np.median(tot), dlt.max()))
 
 # the kernel ends with its slowest workgroup: which images are those?
 order = np.argsort(-tot)[:6]
-print('  slowest workgroups (image: cycles | per phase | rounds | file bytes):')
+print('  slowest workgroups (image of the launch: cycles | per phase | rounds):')
 for i in order:
-    print('    %4d: %8.0f | %s | %2d rounds | %6d B' % (i, tot[i], ' '.join('%7.0f' % (t[i, k + 1] - t[i, k]) for k in range(6)), rounds[i] if i < len(rounds) else -1, len(blobs[i])))
-sizes_b = np.array([len(b) for b in blobs[:n2]], dtype=np.float64)
-valid = tot > 0
-if valid.sum() > 2:
-    print('  correlation of a workgroup\'s cycles with: file size %.2f, rounds %.2f' % (np.corrcoef(tot[valid], sizes_b[valid])[0, 1], np.corrcoef(tot[valid], rounds[:n2][valid])[0, 1]))
-    print('  cycles: p50 %.0f p90 %.0f p99 %.0f max %.0f' % tuple(np.percentile(tot[valid], [50, 90, 99, 100])))
+    print('    %4d: %8.0f | %s | %2d rounds' % (i, tot[i], ' '.join('%7.0f' % (t[i, k + 1] - t[i, k]) for k in range(6)), rounds[i] if i < len(rounds) else -1))
+if len(tot) > 2:
+    print('  correlation of a workgroup\'s cycles with its rounds: %.2f' % np.corrcoef(tot, rounds[:len(tot)])[0, 1])
+    print('  cycles: p50 %.0f p90 %.0f p99 %.0f max %.0f' % tuple(np.percentile(tot, [50, 90, 99, 100])))
 
 if hasattr(L, 'melf_debug_jpeg_round_log'):
     log = np.zeros((8, 32, 5), np.uint32)

@@ -53,6 +53,12 @@ echo "mfma busy done" >> $OUT/progress.txt
 pmc config2 python3 tools/run_stage.py fused --iters 8
 pmc config5 python3 tools/run_stage.py fused --iters 4 --hw 1080x1920 --batch 512 --nbuf 1
 pmc jpeg python3 tools/jpeg_timing.py sample-images1 1024
+# k_jpeg_huff is a latency chain (dependent decode steps of a few waves per workgroup): what its launches issue and how busy
+# they keep the vector units, counters as for k_dials
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv \
+    --kernel-include-regex 'k_jpeg_huff' -d /tmp/prof/valu_jpeg -- python3 tools/jpeg_timing.py sample-images1 1024 > /dev/null 2>&1 || true
+python3 tools/pmc_summary.py /tmp/prof/valu_jpeg > $OUT/pmc_huff_jpeg.txt || true
+echo "valu jpeg done" >> $OUT/progress.txt
 python3 - "$OUT" <<'PY'
 import json, os, re, sys
 sys.path.insert(0, os.getcwd())
@@ -80,16 +86,16 @@ for (cfg, kernels) in (('config3', ('k_match_mfma', 'k_match_gen', 'k_prep_lplan
             detail['%s:%s' % (cfg, k)] = bytes_of(d[k])
             per['%s:%s' % (cfg, short)] = bytes_of(d[k])
 valu = {}
-for cfg in ('config3', 'config4'):
+for (cfg, fname, kern) in (('config3', 'dials_config3', 'k_dials'), ('config4', 'dials_config4', 'k_dials'), ('jpeg', 'huff_jpeg', 'k_jpeg_huff')):
     try:
-        d = load('dials_' + cfg).get('k_dials', {})
+        d = load(fname).get(kern, {})
     except OSError:
         d = {}
     if d.get('SQ_ACTIVE_INST_VALU') and d.get('GRBM_GUI_ACTIVE'):
         # vector units busy: quad-cycles x 4, summed over the 1024 SIMDs / (1024 SIMDs x the launch's cycles); GRBM_GUI_ACTIVE is
         # the sum over the 8 XCDs of the cycles the launch kept the chip active
         cyc = d['GRBM_GUI_ACTIVE'] / 8.0
-        valu[cfg + ':k_dials'] = {'insts_valu_per_launch': d.get('SQ_INSTS_VALU'), 'active_inst_valu_quadcycles': d['SQ_ACTIVE_INST_VALU'],
+        valu[cfg + ':' + kern] = {'insts_valu_per_launch': d.get('SQ_INSTS_VALU'), 'active_inst_valu_quadcycles': d['SQ_ACTIVE_INST_VALU'],
                                   'wave_quadcycles': d.get('SQ_WAVE_CYCLES'), 'waves': d.get('SQ_WAVES'), 'busy_cycles': d.get('SQ_BUSY_CYCLES'),
                                   'wait_inst_any_quadcycles': d.get('SQ_WAIT_INST_ANY'), 'gui_active_cycles_per_xcd': cyc,
                                   'valu_busy_frac': 4.0 * d['SQ_ACTIVE_INST_VALU'] / (1024.0 * cyc)}
