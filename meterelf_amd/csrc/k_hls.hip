@@ -924,8 +924,8 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
     // buffers lie -- +-6 % between allocations of one process, stable within one (tools/fused_alloc_probe.py), and the bare stream
     // shows the same: each workgroup walking its own long run ("comb") is what the placement hurts, all workgroups taking small
     // consecutive pieces from one counter (a compact front moving through memory) is not.  So a launch whose workgroups would each
-    // stream a long run hands out SMALL segments instead: P = 3 passes including the 4 halo rows (20 rows of a 1080p frame: the halo
-    // rows are hits in the memory-side cache, their neighbours are being read at the same time), at least ~96 KB of pixels.  On the
+    // stream a long run hands out SMALL segments instead: two or three passes including the 4 halo rows (20 rows of a 1080p frame: the halo
+    // rows are hits in the memory-side cache, their neighbours are being read at the same time), at least 64 KB of pixels.  On the
     // same buffers (tools/fused_queue_ab.py, profiles/r06/fused_queue_ab_*.txt): 1080p B = 512 0.749-0.783 ms on every placement
     // against 0.738-0.833 for the static split (mean -3.3 %, worst case -6 %, best case +2 %); coarser segments lose (the round-5
     // A/Bs used 135-540 rows and compared separate processes, i.e. placements).  Short runs (B = 256 640 x 480: 240 rows per
@@ -958,11 +958,13 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
             const double rows_aimed = (double)n * Hs / ((double)wgs * dyn);
             P = (int)((rows_aimed + 4.0) / RC + 0.5);
         } else {
-            // three passes, more for narrow frames (>= 96 KB of pixels per segment); only where a workgroup gets six or more such
-            // segments and the halo stays under a quarter of the rows
-            P = std::max(3, (int)((96.0 * 1024 / ((double)W * 3) + 4.0) / RC + 0.999));
+            // the fewest passes that make a segment of >= 64 KB of pixels with the 4 halo rows at most a quarter of its own rows
+            // (1080p: 3 passes = 20 rows, 115 KB; 640 x 480: 2 passes = 46 rows, 88 KB -- measured best of P = 2 .. 5 for both);
+            // only where a workgroup gets six or more such segments
+            P = std::max(2, (int)((64.0 * 1024 / ((double)W * 3) + 4.0) / RC + 0.999));
+            while (P * RC - 4 < 16 && P < 64) ++P;
             const int own = P * RC - 4;
-            use = own >= 16 && (double)n * H / wgs >= 6.0 * own;
+            use = (double)n * H / wgs >= 6.0 * own;
         }
         if (P * RC - 4 < RC) P = (2 * RC + 3) / RC;                           // at least RC rows of its own
         const int dr0 = std::min(P * RC - 4, Hs), ds = (Hs + dr0 - 1) / dr0;
