@@ -16,6 +16,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "melf_device.h"
 #include <hip/hip_ext.h>
@@ -278,8 +281,35 @@ __global__ __launch_bounds__(256) void k_interval_tables(uint32_t* __restrict__ 
     if (runs > 1) atomicAdd(tables + OFF_NONIV + c, 1u);
 }
 
+// The work queue of a launch is one of the FUSED_QUEUE_SLOTS counters behind the context's tables, and the launch's last workgroup
+// leaves it zeroed.  A slot belongs to ONE stream of ONE context: launches of a stream run one after the other, so the next launch
+// finds its counter at zero, while launches on different streams -- which may run together -- never share one, however many are
+// enqueued.  (Round 5 rotated the slots per launch: two launches 64 apart on different streams could have met in one counter.)
+// A context with more streams than slots: -1, and that launch takes the static split.  Building a context's tables (which zeroes
+// the counters) forgets the streams an earlier context at the same address had.
+static std::mutex g_fused_slot_m;
+static std::map<std::pair<const void*, hipStream_t>, int> g_fused_slot_of;
+static std::map<const void*, int> g_fused_slots_used;
+static int fused_queue_slot(const uint32_t* d_tables, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> g(g_fused_slot_m);
+    auto it = g_fused_slot_of.find({d_tables, stream});
+    if (it != g_fused_slot_of.end()) return it->second;
+    int& n = g_fused_slots_used[d_tables];
+    if (n >= FUSED_QUEUE_SLOTS) return -1;
+    g_fused_slot_of[{d_tables, stream}] = n;
+    return n++;
+}
+static void fused_queue_forget(const uint32_t* d_tables)
+{
+    std::lock_guard<std::mutex> g(g_fused_slot_m);
+    for (auto it = g_fused_slot_of.begin(); it != g_fused_slot_of.end();) it = it->first.first == d_tables ? g_fused_slot_of.erase(it) : std::next(it);
+    g_fused_slots_used.erase(d_tables);
+}
+
 void launch_build_fused_tables(int hue_shift, const int lo[3], const int hi[3], uint32_t* d_tables, hipStream_t stream)
 {
+    fused_queue_forget(d_tables);
     Bounds B;
     for (int c = 0; c < 3; ++c) { B.lo[c] = lo[c]; B.hi[c] = hi[c]; }
     (void)hipMemsetAsync(d_tables, 0, FUSED_BUF_DWORDS * sizeof(uint32_t), stream);   // tables and work queues
@@ -969,11 +999,11 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
         if (P * RC - 4 < RC) P = (2 * RC + 3) / RC;                           // at least RC rows of its own
         const int dr0 = std::min(P * RC - 4, Hs), ds = (Hs + dr0 - 1) / dr0;
         const int dr = (Hs + ds - 1) / ds;                                     // evenly: no short last segment
-        if (use && (long)n * (ds + big_segs) > wgs) {
+        const int qslot = (use && (long)n * (ds + big_segs) > wgs) ? fused_queue_slot(d_tables, stream) : -1;
+        if (qslot >= 0) {
             seg_rows = dr;
             segs = ds;
-            static std::atomic<unsigned> slot{0};
-            wq = d_tables + FUSED_TABLE_DWORDS + 16 * (slot.fetch_add(1) % FUSED_QUEUE_SLOTS);
+            wq = d_tables + FUSED_TABLE_DWORDS + 16 * qslot;
         } else {
             big_segs = big_rows = 0;
         }
@@ -1229,8 +1259,9 @@ size_t launch_stream_probe(const void* d_in, size_t in_bytes, void* d_out, int c
     } else if (chunks_per_block < 0) {
         hipExtLaunchKernelGGL(k_stream_probe_prefetch, dim3(grid), dim3(1024), 0, stream, ev_start, ev_stop, 0, (const u32x4*)d_in, (u32x4*)d_out, nchunks);
     } else if (chunks_per_block > 0) {
-        static std::atomic<unsigned> slot{0};
-        uint32_t* wq = d_tables + FUSED_TABLE_DWORDS + 16 * (slot.fetch_add(1) % FUSED_QUEUE_SLOTS);
+        const int qslot = fused_queue_slot(d_tables, stream);
+        if (qslot < 0) return 0;
+        uint32_t* wq = d_tables + FUSED_TABLE_DWORDS + 16 * qslot;
         hipExtLaunchKernelGGL((k_stream_probe<true>), dim3(grid), dim3(1024), 0, stream, ev_start, ev_stop, 0, (const u32x4*)d_in, (u32x4*)d_out, nchunks,
                               (uint32_t)chunks_per_block, wq);
     } else {

@@ -57,4 +57,29 @@ while time.time() - t0 < budget:
     cases += 1
     px += n * H * W
     del frames, m_auto, m_static, m_two
+# many queue launches outstanding on three streams at once (a slot of the queue ring belongs to one stream of one context)
+(H, W, n) = (1080, 1920, 64)
+base = torch.randint(0, 256, (n + 32, H, W, 3), dtype=torch.uint8, device=dev, generator=g)
+base[:, ::3, :, 2] = 200
+base[:, ::3, :, 1] = 30
+base[:, ::3, :, 0] = 40
+streams = [torch.cuda.Stream() for _ in range(3)]
+outs = [[torch.empty((n, H, W), dtype=torch.uint8, device=dev) for _ in range(4)] for _ in streams]
+os.environ.pop('MELF_FUSED_DYN', None)
+torch.cuda.synchronize()
+LAUNCHES = 40
+for j in range(LAUNCHES):
+    for (si, st) in enumerate(streams):
+        off = (7 * j + 11 * si) % 32
+        ctx.hls_inrange_close_dev(base.data_ptr() + off * H * W * 3, n, H, W, outs[si][j % 4].data_ptr(), stream=st.cuda_stream)
+torch.cuda.synchronize()
+os.environ['MELF_FUSED_DYN'] = '0'
+chk = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+for (si, st) in enumerate(streams):
+    for j in range(LAUNCHES - 4, LAUNCHES):
+        off = (7 * j + 11 * si) % 32
+        ctx.hls_inrange_close_dev(base.data_ptr() + off * H * W * 3, n, H, W, chk.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(chk, outs[si][j % 4]), ('outstanding launches', si, j)
+print('%d queue launches of %d x 1080p outstanding on 3 streams: the last 4 of each stream identical to the static split' % (3 * LAUNCHES, n))
 print('%d cases (%d of them long enough for the queue), %.1f G pixels, masks identical to the static split in all; %.0f s' % (cases, queued, px / 1e9, time.time() - t0))
