@@ -737,7 +737,10 @@ def fused_block(env, ctx, FB, H, W, nbuf, steps, warmup, traffic, label, frames=
         'roofline': {'kernel': 'k_fused_mask', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': tr, 'traffic_source': src,
                      'avg_launch_ms': round(favg, 4), 'launches': fn,
-                     'algorithmic': '%d B/frame x %d frames/launch' % (H * W * 4, FB)},
+                     'algorithmic': '%d B/frame x %d frames/launch' % (H * W * 4, FB),
+                     # the kernel needs the vector units as well (12-15 instructions per pixel): their busy share from the PMC pass
+                     'vector_units_busy': (round(traffic.valu_entry(label + ':k_fused_mask')['valu_busy_frac'], 4)
+                                           if traffic.valu_entry(label + ':k_fused_mask') else None)},
         'stream_ceiling': ceiling,
         'two_streams': two,
     }

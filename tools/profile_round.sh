@@ -52,6 +52,14 @@ python3 tools/pmc_summary.py /tmp/prof/mfma_busy > $OUT/pmc_match_mfma_busy.txt 
 echo "mfma busy done" >> $OUT/progress.txt
 pmc config2 python3 tools/run_stage.py fused --iters 8
 pmc config5 python3 tools/run_stage.py fused --iters 4 --hw 1080x1920 --batch 512 --nbuf 1
+# the fused mask needs the vector units too (12-15 instructions per pixel): their busy share, counters as for k_dials
+for cfg in config2 config5; do
+  if [ $cfg = config2 ]; then args="--iters 8"; else args="--iters 4 --hw 1080x1920 --batch 512 --nbuf 1"; fi
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv \
+      --kernel-include-regex 'k_fused_mask' -d /tmp/prof/valu_fused_$cfg -- python3 tools/run_stage.py fused $args > /dev/null 2>&1 || true
+  python3 tools/pmc_summary.py /tmp/prof/valu_fused_$cfg > $OUT/pmc_fused_valu_$cfg.txt || true
+done
+echo "valu fused done" >> $OUT/progress.txt
 pmc jpeg python3 tools/jpeg_timing.py sample-images1 1024
 # k_jpeg_huff is a latency chain (dependent decode steps of a few waves per workgroup): what its launches issue and how busy
 # they keep the vector units, counters as for k_dials
@@ -86,7 +94,8 @@ for (cfg, kernels) in (('config3', ('k_match_mfma', 'k_match_gen', 'k_prep_lplan
             detail['%s:%s' % (cfg, k)] = bytes_of(d[k])
             per['%s:%s' % (cfg, short)] = bytes_of(d[k])
 valu = {}
-for (cfg, fname, kern) in (('config3', 'dials_config3', 'k_dials'), ('config4', 'dials_config4', 'k_dials'), ('jpeg', 'huff_jpeg', 'k_jpeg_huff')):
+for (cfg, fname, kern) in (('config3', 'dials_config3', 'k_dials'), ('config4', 'dials_config4', 'k_dials'), ('jpeg', 'huff_jpeg', 'k_jpeg_huff'),
+                           ('config2', 'fused_valu_config2', 'k_fused_mask'), ('config5', 'fused_valu_config5', 'k_fused_mask')):
     try:
         d = load(fname).get(kern, {})
     except OSError:
