@@ -990,11 +990,17 @@ static void launch_lut_t(const uint8_t* d_frames, int n, int H, int W, int hue_s
         } else {
             // the fewest passes that make a segment of >= 64 KB of pixels with the 4 halo rows at most a quarter of its own rows
             // (1080p: 3 passes = 20 rows, 115 KB; 640 x 480: 2 passes = 46 rows, 88 KB -- measured best of P = 2 .. 5 for both);
-            // only where a workgroup gets six or more such segments
+            // where a workgroup gets six or more such segments ...
             P = std::max(2, (int)((64.0 * 1024 / ((double)W * 3) + 4.0) / RC + 0.999));
             while (P * RC - 4 < 16 && P < 64) ++P;
             const int own = P * RC - 4;
-            use = (double)n * H / wgs >= 6.0 * own;
+            // ... or where the static split comes out badly: its segments do not go into the workgroups evenly (57 frames of 1080p:
+            // 513 segments for 512 workgroups, a second round for one of them -- the queue is 20 % faster there), measured by the rows
+            // the busiest workgroup gets either way (the queue's: its share with the halo rows, plus one segment of imbalance)
+            const long st_total = (long)n * segs, st_grid = std::min<long>(st_total, wgs);
+            const double st_rows = (double)((st_total + st_grid - 1) / st_grid) * seg_rows;
+            const double q_rows = (double)n * H * (1.0 + 4.0 / own) / wgs + own;
+            use = (double)n * H / wgs >= 6.0 * own || q_rows < 0.9 * st_rows;
         }
         if (P * RC - 4 < RC) P = (2 * RC + 3) / RC;                           // at least RC rows of its own
         const int dr0 = std::min(P * RC - 4, Hs), ds = (Hs + dr0 - 1) / dr0;

@@ -48,12 +48,24 @@ while time.time() - t0 < budget:
     assert torch.equal(m_auto, m_static), ('queue vs static', n, H, W)
     assert torch.equal(m_two, m_static), ('two streams vs static', n, H, W)
     assert int((m_static > 0).sum()) > 0
+    # launch_lut_t's rule, restated (k_hls.hip): does this launch take the queue?
     G16 = W >> 4
     RC = min(1024 // G16, 256)
     P = max(2, int((65536.0 / (W * 3) + 4.0) / RC + 0.999))
     while P * RC - 4 < 16:
         P += 1
-    queued += 1 if n * H / 512.0 >= 6.0 * (P * RC - 4) else 0
+    own = P * RC - 4
+    segs = (512 + n - 1) // n
+    seg_rows = (H + segs - 1) // segs
+    if seg_rows < 32:
+        seg_rows = min(H, 32)
+    segs = (H + seg_rows - 1) // seg_rows
+    st_total = n * segs
+    st_rows = -(-st_total // min(st_total, 512)) * seg_rows
+    q_rows = n * H * (1.0 + 4.0 / own) / 512.0 + own
+    dr0 = min(own, H)
+    ds = -(-H // dr0)
+    queued += 1 if ((n * H / 512.0 >= 6.0 * own or q_rows < 0.9 * st_rows) and n * ds > 512) else 0
     cases += 1
     px += n * H * W
     del frames, m_auto, m_static, m_two
