@@ -203,6 +203,14 @@ def test_fused_mask_other_bounds(env, tmp_path, needle):
             assert np.array_equal(got[f], exp), f
             nz += int((exp > 0).sum())
         assert nz > 0
+        # the same variant through the work queue (a launch of long runs: 600 frames of 240 x 320), against its pieces and the oracle
+        big = rng.integers(0, 256, size=(600, 240, 320, 3), dtype=np.uint8)
+        big[::2] = _blobby(rng, 300, 240, 320)
+        whole = reader.ctx.hls_inrange_close(big)
+        parts = np.concatenate([reader.ctx.hls_inrange_close(big[a:a + 40]) for a in range(0, 600, 40)])
+        assert np.array_equal(parts, whole)
+        for f in (0, 299, 599):
+            assert np.array_equal(whole[f], po.hls_inrange_close(big[f], p.hue_shift, lo, hi)), f
     finally:
         reader.close()
 
