@@ -286,7 +286,8 @@ def match_roofline(P, H, W, kt, frames_total, traffic_entry):
                 'column block in the tuned kernel: the first and last Toeplitz blocks share it); algorithmic MACs only (Toeplitz zero '
                 'padding is not counted), priced against the DENSE i8 MFMA peak.  The match kernels also add up the window sums of TM_CCOEFF '
                 'themselves (k_match_mfma since round 3, k_match_gen since round 4; before, a separate column-sum launch of 8-15 us): '
-                'their launches are 5-10 us longer for that and the step 8-14 us shorter',
+                'their launches are 5-10 us longer for that and the step 8-14 us shorter.  The launch is power-limited and its clock follows the DATA: the same '
+                'launch takes 102 us on frames of one value and 156 on real ones, which are as bad as random bytes (profiles/r06/match_operand_power.txt)',
     }
 
 
