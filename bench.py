@@ -466,7 +466,7 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     out['match_layout'] = ctx.last_match()
     out['kernel_ms'] = {k: round(ms / n, 4) for (k, (ms, n)) in kt_all.items() if n}
     if sustained_s > 0:
-        est = max(elapsed / steps, 1e-5)
+        est = max(elapsed_max / steps, 1e-5)   # (the max over the ranks: every rank runs the same number of steps)
         k = int(sustained_s / est * 1.15) + nbuf
         (el, _r) = run(k, ns_timed)
         ctx.set_frames_resident(False)
@@ -485,7 +485,7 @@ def full_path_block(env, pfile, sample_dir, seed, steps, warmup, B, nbuf, sustai
     ctx.set_frames_resident(False)
     if two_stream_s > 0 and ns == 1:
         # ~1 s of the steps alternating between two caller streams ...
-        est = max(elapsed / steps, 1e-5)
+        est = max(elapsed_max / steps, 1e-5)   # (the max over the ranks: every rank runs the same number of steps)
         k = int(two_stream_s / est * 1.2) + nbuf
         run(max(4, nbuf), 2)
         (el2, recs2) = run(k, 2)
