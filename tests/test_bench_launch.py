@@ -80,3 +80,16 @@ def test_four_ranks_rehearsal_on_one_gpu():
     assert c5['full_path']['dials'] == 6 and c5['full_path']['frames_read_ok'] >= 12
     assert c5['full_path']['parity_gate']['parity_mismatches_vs_gpu'] == 0 and c5['full_path']['parity_gate']['oracle_frames'] == 16
     assert c5['fused_mask']['roofline']['frac'] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_every_default_block():
+    """What a SCALE run executes: EVERY default block with more than one rank (the four-rank rehearsal above skips the long ones).
+    Round 6 put a time-bounded preheat loop around calls that hold barriers and the ranks left it after different counts: this
+    test is here so that such a loop hangs a test, not the driver's scaling run."""
+    line = _run([sys.executable, BENCH, '--gpus', '2', '--backend', 'gloo', '--share-gpu', '--sustained', '0.3', '--batch5', '16',
+                 '--cpu-sample', '16'] + SMALL, timeout=900)
+    assert line['n_gpus'] == 2 and line['value'] > 0 and len(line['per_rank_ms_per_step']) == 2
+    assert line['sustained']['steps'] > 0 and line['two_streams']['records_identical_to_timed_region']
+    assert line['config5']['full_path']['untimed_preheat_steps'] > 0 and line['fused_mask']['untimed_preheat_launches'] > 0
+    assert line['cpu_baseline']['parity_mismatches_vs_gpu'] == 0
