@@ -28,6 +28,9 @@ Objects on the line besides the contract's fields:
   host_fed       the host-pointer entry point (frames in host memory, PCIe inclusive) -- never `value`
   jpeg_decode    the same path fed with JPEG files (decode on the GPU)
   rccl_ranks     all_reduce(1) over the nccl (= RCCL) backend: number of ranks that took part
+Every timed block runs untimed launches first (`untimed_preheat_steps` / `untimed_preheat_launches` on the line: 300 steps in
+front of the headline, 60 ms of launches in front of the fused-mask and config-5 blocks): the chip's clocks settle 20-30 ms after
+a load begins (tools/fused_first_launches.py), and W + K launches right behind a buffer allocation sit inside that.
 """
 import argparse
 import glob
